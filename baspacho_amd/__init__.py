@@ -1,0 +1,343 @@
+"""baspacho_amd -- MI355X-native supernodal sparse Cholesky (host-side Python mirror).
+
+Thin mirror of the reference's public C++ surface (baspacho/baspacho/Solver.h) over the C ABI
+of the HIP library (include/baspacho_amd.h): `create_solver`, `Solver.factor/solve`, block
+accessors, skeleton arrays.  PyTorch is only plumbing here (device memory, streams,
+torch.distributed); numeric work happens in the hand-written HIP kernels.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["Settings", "Solver", "create_solver", "SparseStructure", "BackendHip", "BackendCuda",
+           "BackendRef", "BackendFast", "AddFillComplete", "AddFillForAutoElims",
+           "AddFillForGivenElims", "AddFillNone"]
+
+# Solver.h:189-209
+BackendRef, BackendFast, BackendCuda, BackendHip = 0, 1, 2, 3
+AddFillComplete, AddFillForAutoElims, AddFillForGivenElims, AddFillNone = 0, 1, 2, 3
+
+_I64P = ctypes.POINTER(ctypes.c_int64)
+
+_SKEL_IDS = {
+    "spanStart": 0, "spanToLump": 1, "lumpStart": 2, "lumpToSpan": 3, "spanOffsetInLump": 4,
+    "chainColPtr": 5, "chainRowSpan": 6, "chainData": 7, "chainRowsTillEnd": 8,
+    "boardColPtr": 9, "boardRowLump": 10, "boardChainColOrd": 11, "boardRowPtr": 12,
+    "boardColLump": 13, "boardColOrd": 14,
+}
+
+PROF_KINDS = ["elim_factor", "elim_update", "potrf", "trsm", "update"]
+
+
+class _CSettings(ctypes.Structure):
+    _fields_ = [("find_sparse_elimination_ranges", ctypes.c_int32),
+                ("num_threads", ctypes.c_int32), ("backend", ctypes.c_int32),
+                ("add_fill_policy", ctypes.c_int32),
+                ("computation_model", ctypes.POINTER(ctypes.c_double))]
+
+
+class _CPlanStats(ctypes.Structure):
+    _fields_ = [("flops", ctypes.c_double), ("upd_elems", ctypes.c_double)] + \
+               [(n, ctypes.c_int64) for n in
+                ["num_launches", "num_levels", "num_panels", "num_segs", "num_upd_tasks",
+                 "num_trsm_tasks", "chain_tab_entries", "max_panels_in_level",
+                 "num_atomic_upd_tasks"]]
+
+
+@dataclass
+class Settings:
+    """Solver.h:212-218"""
+    findSparseEliminationRanges: bool = True
+    numThreads: int = 16
+    backend: int = BackendHip
+    addFillPolicy: int = AddFillComplete
+    computationModel: Optional[Sequence[float]] = None  # 20 coefficients, see C header
+
+
+@dataclass
+class SparseStructure:
+    """block CSR pattern (lower triangle incl. diagonal); SparseStructure.h:19-29"""
+    ptrs: np.ndarray
+    inds: np.ndarray
+
+    def __post_init__(self):
+        self.ptrs = np.ascontiguousarray(self.ptrs, dtype=np.int64)
+        self.inds = np.ascontiguousarray(self.inds, dtype=np.int64)
+
+    def order(self):
+        return len(self.ptrs) - 1
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(_lib.load().bsp_last_error().decode("utf-8", "replace"))
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _ptr_of(t):
+    """device pointer of a torch tensor (or a raw int address)"""
+    if isinstance(t, int):
+        return t
+    if not t.is_cuda:
+        raise ValueError("numeric data must live in device memory (Solver.h:184-188)")
+    if not t.is_contiguous():
+        raise ValueError("numeric data must be contiguous")
+    return t.data_ptr()
+
+
+def _suffix(t):
+    import torch
+    if t.dtype == torch.float64:
+        return "f64"
+    if t.dtype == torch.float32:
+        return "f32"
+    raise TypeError("only float64 / float32 data is supported, got %s" % t.dtype)
+
+
+class Solver:
+    """Mirror of BaSpaCho::Solver (Solver.h:34-180).  Do not construct directly: use
+    `create_solver`, `Solver.from_skeleton` or `Solver.from_plan`."""
+
+    def __init__(self, handle):
+        self._lib = _lib.load()
+        self._h = handle
+        self._skel = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.bsp_destroy_solver(h)
+
+    # ---- construction -------------------------------------------------------------------
+    @staticmethod
+    def from_skeleton(span_start, lump_to_span, col_ptr, row_ind, sparse_elim_ranges=()):
+        """Solver(CoalescedBlockMatrixSkel&&, sparseElimRanges, {}, ops)  (Solver.h:37-38)"""
+        lib = _lib.load()
+        ss, l2s, cp, ri = _i64(span_start), _i64(lump_to_span), _i64(col_ptr), _i64(row_ind)
+        er = _i64(sparse_elim_ranges)
+        h = ctypes.c_void_p()
+        _check(lib.bsp_create_solver_from_skeleton(
+            ctypes.c_int64(len(ss) - 1), ss.ctypes.data_as(_I64P), ctypes.c_int64(len(l2s) - 1),
+            l2s.ctypes.data_as(_I64P), cp.ctypes.data_as(_I64P), ri.ctypes.data_as(_I64P),
+            ctypes.c_int64(len(er)), er.ctypes.data_as(_I64P), ctypes.byref(h)))
+        return Solver(h)
+
+    @staticmethod
+    def from_plan(buf):
+        """rebuild a solver from `serialize_plan()` output (e.g. after an RCCL broadcast)"""
+        lib = _lib.load()
+        b = _i64(buf)
+        h = ctypes.c_void_p()
+        _check(lib.bsp_create_solver_from_plan(b.ctypes.data_as(_I64P), ctypes.c_int64(len(b)),
+                                               ctypes.byref(h)))
+        return Solver(h)
+
+    def serialize_plan(self):
+        need = ctypes.c_int64(0)
+        _check(self._lib.bsp_plan_serialize(self._h, None, ctypes.c_int64(0), ctypes.byref(need)))
+        buf = np.empty(need.value, dtype=np.int64)
+        _check(self._lib.bsp_plan_serialize(self._h, buf.ctypes.data_as(_I64P), need,
+                                            ctypes.byref(need)))
+        return buf
+
+    # ---- sizes / structure --------------------------------------------------------------
+    def order(self):
+        return int(self._lib.bsp_order(self._h))
+
+    def dataSize(self):
+        return int(self._lib.bsp_data_size(self._h))
+
+    def canFactorUpToSpan(self):
+        return int(self._lib.bsp_can_factor_up_to_span(self._h))
+
+    def numSpans(self):
+        return int(self._lib.bsp_num_spans(self._h))
+
+    def numLumps(self):
+        return int(self._lib.bsp_num_lumps(self._h))
+
+    def spanVectorOffset(self, span):
+        return int(self._lib.bsp_span_vector_offset(self._h, ctypes.c_int64(span)))
+
+    def spanMatrixOffset(self, span):
+        out = ctypes.c_int64(0)
+        _check(self._lib.bsp_span_matrix_offset(self._h, ctypes.c_int64(span), ctypes.byref(out)))
+        return out.value
+
+    def _array(self, which):
+        p, n = _I64P(), ctypes.c_int64(0)
+        _check(self._lib.bsp_skeleton_array(self._h, which, ctypes.byref(p), ctypes.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.int64)
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def skel(self):
+        """dict of the CoalescedBlockMatrixSkel arrays (CoalescedBlockMatrix.h:88-110)"""
+        if self._skel is None:
+            self._skel = {k: self._array(v) for k, v in _SKEL_IDS.items()}
+        return self._skel
+
+    def paramToSpan(self):
+        return self._array(15)
+
+    def sparseEliminationRanges(self):
+        return self._array(16)
+
+    # ---- accessors ----------------------------------------------------------------------
+    def blockOffset(self, row_param, col_param):
+        """(offset, stride, flipped)  -- PermutedCoalescedAccessor::blockOffset"""
+        off, st, fl = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int32(0)
+        _check(self._lib.bsp_block_offset(self._h, ctypes.c_int64(row_param),
+                                          ctypes.c_int64(col_param), ctypes.byref(off),
+                                          ctypes.byref(st), ctypes.byref(fl)))
+        return off.value, st.value, bool(fl.value)
+
+    def diagBlockOffset(self, param):
+        off, st = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(self._lib.bsp_diag_block_offset(self._h, ctypes.c_int64(param), ctypes.byref(off),
+                                               ctypes.byref(st)))
+        return off.value, st.value
+
+    def deviceAccessor(self):
+        """8 device addresses (spanStart, spanToLump, lumpStart, spanOffsetInLump, chainColPtr,
+        chainRowSpan, chainData, permutation) usable from a caller's HIP kernel"""
+        arr = (_I64P * 8)()
+        _check(self._lib.bsp_device_accessor(self._h, arr))
+        return [ctypes.cast(a, ctypes.c_void_p).value for a in arr]
+
+    # ---- numeric ------------------------------------------------------------------------
+    def setStream(self, stream):
+        """stream: torch.cuda.Stream, raw hipStream_t address, or None (default stream)"""
+        addr = 0 if stream is None else getattr(stream, "cuda_stream", stream)
+        self._lib.bsp_set_stream(self._h, ctypes.c_void_p(addr))
+
+    def _check_data(self, t):
+        if t.numel() != self.dataSize():
+            raise ValueError("data has %d elements, factor needs %d" % (t.numel(), self.dataSize()))
+
+    def factor(self, data):
+        """Solver::factor<T> / factor<std::vector<T*>> (list/tuple of tensors = batch)"""
+        if isinstance(data, (list, tuple)):
+            sfx = _suffix(data[0])
+            for t in data:
+                self._check_data(t)
+            ptrs = (ctypes.c_void_p * len(data))(*[_ptr_of(t) for t in data])
+            _check(getattr(self._lib, "bsp_factor_batched_" + sfx)(self._h, ptrs,
+                                                                   ctypes.c_int32(len(data))))
+        else:
+            self._check_data(data)
+            _check(getattr(self._lib, "bsp_factor_" + _suffix(data))(
+                self._h, ctypes.c_void_p(_ptr_of(data))))
+
+    def factorUpTo(self, data, span_index):
+        self._check_data(data)
+        _check(getattr(self._lib, "bsp_factor_up_to_" + _suffix(data))(
+            self._h, ctypes.c_void_p(_ptr_of(data)), ctypes.c_int64(span_index)))
+
+    def factorFrom(self, data, span_index):
+        self._check_data(data)
+        _check(getattr(self._lib, "bsp_factor_from_" + _suffix(data))(
+            self._h, ctypes.c_void_p(_ptr_of(data)), ctypes.c_int64(span_index)))
+
+    def doElimination(self, data, elim_range_index):
+        """TESTING hook: numCtx->doElimination(internalGetElimCtx(i), ...)"""
+        self._check_data(data)
+        _check(getattr(self._lib, "bsp_do_elimination_" + _suffix(data))(
+            self._h, ctypes.c_void_p(_ptr_of(data)), ctypes.c_int64(elim_range_index)))
+
+    def _solve(self, name, mat, vec, stride, nrhs):
+        self._check_data(mat)
+        if stride is None:
+            stride = self.order()
+        _check(getattr(self._lib, name + _suffix(mat))(
+            self._h, ctypes.c_void_p(_ptr_of(mat)), ctypes.c_void_p(_ptr_of(vec)),
+            ctypes.c_int64(stride), ctypes.c_int32(nrhs)))
+
+    def solve(self, mat, vec, stride=None, nRHS=1):
+        self._solve("bsp_solve_", mat, vec, stride, nRHS)
+
+    def solveL(self, mat, vec, stride=None, nRHS=1):
+        self._solve("bsp_solve_l_", mat, vec, stride, nRHS)
+
+    def solveLt(self, mat, vec, stride=None, nRHS=1):
+        self._solve("bsp_solve_lt_", mat, vec, stride, nRHS)
+
+    # ---- measurement --------------------------------------------------------------------
+    def factorFlops(self):
+        return float(self._lib.bsp_factor_flops(self._h))
+
+    def planStats(self):
+        st = _CPlanStats()
+        _check(self._lib.bsp_plan_stats_full(self._h, ctypes.byref(st)))
+        return {n: getattr(st, n) for n, _ in _CPlanStats._fields_}
+
+    def factorProfiled(self, data):
+        """one factor() with every launch bracketed by HIP events on the execution stream;
+        returns {kernel class: (total ms, launches)}"""
+        self._check_data(data)
+        ms = (ctypes.c_double * 5)()
+        ln = (ctypes.c_int64 * 5)()
+        _check(self._lib.bsp_factor_profiled_f64(self._h, ctypes.c_void_p(_ptr_of(data)), ms, ln))
+        return {k: (ms[i], ln[i]) for i, k in enumerate(PROF_KINDS)}
+
+    # ---- host helpers on the skeleton (CoalescedBlockMatrix.cpp:124-187) ------------------
+    def densify(self, data, fill_upper_half=False, start_span_index=0):
+        """dense numpy copy of host `data` laid out by this solver's skeleton"""
+        sk = self.skel()
+        data = np.asarray(data)
+        off = int(sk["spanStart"][start_span_index])
+        n = self.order() - off
+        dense = np.zeros((n, n), dtype=data.dtype)
+        ls, ss = sk["lumpStart"], sk["spanStart"]
+        for l in range(int(sk["spanToLump"][start_span_index]), self.numLumps()):
+            w = int(ls[l + 1] - ls[l])
+            for c in range(int(sk["chainColPtr"][l]), int(sk["chainColPtr"][l + 1])):
+                sp = int(sk["chainRowSpan"][c])
+                r0, rows = int(ss[sp]) - off, int(ss[sp + 1] - ss[sp])
+                d0 = int(sk["chainData"][c])
+                dense[r0:r0 + rows, int(ls[l]) - off:int(ls[l]) - off + w] = \
+                    data[d0:d0 + rows * w].reshape(rows, w)
+        if fill_upper_half:
+            dense = np.tril(dense) + np.tril(dense, -1).T
+        return dense
+
+    def damp(self, data, alpha, beta):
+        """diagonal <- diagonal * (1 + alpha) + beta, in place on a host numpy array"""
+        sk = self.skel()
+        ls = sk["lumpStart"]
+        w = (ls[1:] - ls[:-1]).astype(np.int64)
+        d0 = sk["chainData"][sk["chainColPtr"][:-1]]
+        idx = np.concatenate([d0[i] + np.arange(w[i]) * (w[i] + 1) for i in range(len(w))])
+        data[idx] = data[idx] * (1 + alpha) + beta
+        return data
+
+
+def create_solver(settings: Optional[Settings], param_sizes, ss: SparseStructure,
+                  sparse_elim_ranges=(), elim_last_ids=()) -> Solver:
+    """createSolver (Solver.h:235-237): symbolic analysis on the host; never touches the GPU."""
+    lib = _lib.load()
+    st = settings or Settings()
+    cs = _CSettings(int(st.findSparseEliminationRanges), int(st.numThreads), int(st.backend),
+                    int(st.addFillPolicy), None)
+    model = None
+    if st.computationModel is not None:
+        model = (ctypes.c_double * 20)(*[float(x) for x in st.computationModel])
+        cs.computation_model = ctypes.cast(model, ctypes.POINTER(ctypes.c_double))
+    ps = _i64(param_sizes)
+    if len(ps) != ss.order():
+        raise ValueError("param_sizes and sparse structure disagree on the number of params")
+    er, el = _i64(sparse_elim_ranges), _i64(sorted(elim_last_ids))
+    h = ctypes.c_void_p()
+    _check(lib.bsp_create_solver(
+        ctypes.byref(cs), ctypes.c_int64(len(ps)), ps.ctypes.data_as(_I64P),
+        ss.ptrs.ctypes.data_as(_I64P), ss.inds.ctypes.data_as(_I64P), ctypes.c_int64(len(er)),
+        er.ctypes.data_as(_I64P), ctypes.c_int64(len(el)), el.ctypes.data_as(_I64P),
+        ctypes.byref(h)))
+    return Solver(h)

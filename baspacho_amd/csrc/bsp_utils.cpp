@@ -1,0 +1,73 @@
+#include "bsp_utils.h"
+
+#include <chrono>
+#include <cmath>
+#include <ctime>
+#include <iomanip>
+
+namespace BaSpaCho {
+
+void throwError(const char* file, int line, const std::string& msg) {
+  using namespace std::chrono;
+  auto now = system_clock::now();
+  std::time_t tt = system_clock::to_time_t(now);
+  struct tm lt;
+  localtime_r(&tt, &lt);
+  auto ms = duration_cast<milliseconds>(now.time_since_epoch()).count() % 1000;
+  std::ostringstream os;
+  os << "[" << std::put_time(&lt, "%T") << "." << std::setfill('0') << std::setw(3) << ms << " "
+     << file << ":" << line << "] Check failed: " << msg;
+  throw std::runtime_error(os.str());
+}
+
+int64_t cumSumVec(std::vector<int64_t>& v) {
+  int64_t running = 0;
+  for (size_t i = 0; i + 1 < v.size(); i++) {
+    int64_t cur = v[i];
+    v[i] = running;
+    running += cur;
+  }
+  v.back() = running;
+  return running;
+}
+
+void rewindVec(std::vector<int64_t>& v, int64_t downTo, int64_t value) {
+  for (int64_t i = (int64_t)v.size() - 1; i > downTo; i--) v[i] = v[i - 1];
+  v[downTo] = value;
+}
+
+std::vector<int64_t> inversePermutation(const std::vector<int64_t>& p) {
+  std::vector<int64_t> inv(p.size());
+  for (size_t i = 0; i < p.size(); i++) inv[p[i]] = (int64_t)i;
+  return inv;
+}
+
+std::vector<int64_t> composePermutations(const std::vector<int64_t>& v,
+                                         const std::vector<int64_t>& w) {
+  BASPACHO_CHECK_EQ(v.size(), w.size());
+  std::vector<int64_t> out(v.size());
+  for (size_t i = 0; i < v.size(); i++) out[i] = v[w[i]];
+  return out;
+}
+
+std::string secondsToString(double secs, int precision) {
+  std::ostringstream os;
+  os << std::fixed << std::setprecision(precision);
+  if (secs < 1e-3) {
+    os << secs * 1e6 << "us";
+  } else if (secs < 1.0) {
+    os << secs * 1e3 << "ms";
+  } else {
+    os << secs << "s";
+  }
+  return os.str();
+}
+
+std::string OpStat::toString() const {
+  std::ostringstream os;
+  os << "#=" << numRuns << ", time=" << secondsToString(totTime)
+     << ", last=" << secondsToString(lastTime) << ", max=" << secondsToString(maxTime);
+  return os.str();
+}
+
+}  // namespace BaSpaCho

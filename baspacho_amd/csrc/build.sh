@@ -1,0 +1,28 @@
+#!/bin/bash
+# Build the MI355X shared library in-tree (gfx950 only).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libbaspacho_amd.so
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -munsafe-fp-atomics"
+SRCS="bsp_utils.cpp sparse_structure.cpp min_degree.cpp computation_model.cpp elimination_tree.cpp skeleton.cpp solver.cpp hip_plan.cpp c_api.cpp"
+mkdir -p ../_build
+OBJS=""
+pids=()
+for f in $SRCS; do
+  o=../_build/${f%.cpp}.o
+  OBJS="$OBJS $o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -name '*.h' -newer "$o" -print -quit)" ] || [ ../../include/baspacho_amd.h -nt "$o" ]; then
+    $HIPCC $FLAGS -x hip -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+o=../_build/hip_backend.o
+OBJS="$OBJS $o"
+if [ ! -f "$o" ] || [ hip_backend.hip -nt "$o" ] || [ -n "$(find . -name '*.h' -newer "$o" -print -quit)" ]; then
+  $HIPCC $FLAGS -c hip_backend.hip -o "$o" &
+  pids+=($!)
+fi
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC -shared -fPIC --offload-arch=gfx950 $OBJS -o $OUT
+echo "built $OUT"

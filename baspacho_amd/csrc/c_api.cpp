@@ -1,0 +1,365 @@
+// C ABI facade (include/baspacho_amd.h) over the C++ Solver.  Exceptions never cross the
+// boundary: they become a non-zero return code + bsp_last_error().
+#include "../../include/baspacho_amd.h"
+
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <unordered_set>
+
+#include "computation_model.h"
+#include "hip_backend.h"
+#include "solver.h"
+
+using namespace BaSpaCho;
+
+struct bsp_solver {
+  SolverPtr solver;
+  ComputationModel model;  // storage for a user-supplied model
+};
+
+static thread_local std::string g_lastError;
+
+const char* bsp_last_error(void) { return g_lastError.c_str(); }
+const char* bsp_version(void) { return "baspacho_amd 0.1 (gfx950)"; }
+
+#define BSP_TRY try {
+#define BSP_CATCH                      \
+  }                                    \
+  catch (const std::exception& e) {    \
+    g_lastError = e.what();            \
+    return 1;                          \
+  }                                    \
+  catch (...) {                        \
+    g_lastError = "unknown exception"; \
+    return 1;                          \
+  }                                    \
+  return 0;
+
+int bsp_create_solver(const bsp_settings* st, int64_t numParams, const int64_t* paramSizes,
+                      const int64_t* ptrs, const int64_t* inds, int64_t numElimRanges,
+                      const int64_t* elimRanges, int64_t numElimLast, const int64_t* elimLast,
+                      bsp_solver** out) {
+  BSP_TRY
+  BASPACHO_CHECK_NOTNULL(out);
+  std::unique_ptr<bsp_solver> h(new bsp_solver);
+  Settings settings;
+  if (st) {
+    settings.findSparseEliminationRanges = st->find_sparse_elimination_ranges != 0;
+    settings.numThreads = st->num_threads;
+    settings.backend = (BackendType)st->backend;
+    settings.addFillPolicy = (AddFillPolicy)st->add_fill_policy;
+    if (st->computation_model) {
+      const double* p = st->computation_model;
+      std::copy(p, p + 4, h->model.potrfParams.begin());
+      std::copy(p + 4, p + 10, h->model.trsmParams.begin());
+      std::copy(p + 10, p + 16, h->model.sygeParams.begin());
+      std::copy(p + 16, p + 20, h->model.asmblParams.begin());
+      settings.computationModel = &h->model;
+    }
+  }
+  std::vector<int64_t> sizes(paramSizes, paramSizes + numParams);
+  SparseStructure ss(std::vector<int64_t>(ptrs, ptrs + numParams + 1),
+                     std::vector<int64_t>(inds, inds + ptrs[numParams]));
+  std::vector<int64_t> ranges(elimRanges, elimRanges + (elimRanges ? numElimRanges : 0));
+  std::unordered_set<int64_t> last(elimLast, elimLast + (elimLast ? numElimLast : 0));
+  h->solver = createSolver(settings, sizes, ss, ranges, last);
+  *out = h.release();
+  BSP_CATCH
+}
+
+int bsp_create_solver_from_skeleton(int64_t numSpans, const int64_t* spanStart, int64_t numLumps,
+                                    const int64_t* lumpToSpan, const int64_t* colPtr,
+                                    const int64_t* rowInd, int64_t numElimRanges,
+                                    const int64_t* elimRanges, bsp_solver** out) {
+  BSP_TRY
+  BASPACHO_CHECK_NOTNULL(out);
+  std::vector<int64_t> ss(spanStart, spanStart + numSpans + 1);
+  std::vector<int64_t> l2s(lumpToSpan, lumpToSpan + numLumps + 1);
+  std::vector<int64_t> cp(colPtr, colPtr + numLumps + 1);
+  std::vector<int64_t> ri(rowInd, rowInd + colPtr[numLumps]);
+  std::vector<int64_t> ranges(elimRanges, elimRanges + (elimRanges ? numElimRanges : 0));
+  CoalescedBlockMatrixSkel skel(ss, l2s, cp, ri);
+  std::unique_ptr<bsp_solver> h(new bsp_solver);
+  h->solver.reset(new Solver(std::move(skel), std::move(ranges), {}, hipOps()));
+  *out = h.release();
+  BSP_CATCH
+}
+
+void bsp_destroy_solver(bsp_solver* s) { delete s; }
+
+int64_t bsp_order(const bsp_solver* s) { return s->solver->order(); }
+int64_t bsp_data_size(const bsp_solver* s) { return s->solver->dataSize(); }
+int64_t bsp_num_spans(const bsp_solver* s) { return s->solver->skel().numSpans(); }
+int64_t bsp_num_lumps(const bsp_solver* s) { return s->solver->skel().numLumps(); }
+int64_t bsp_can_factor_up_to_span(const bsp_solver* s) { return s->solver->canFactorUpToSpan(); }
+int64_t bsp_span_vector_offset(const bsp_solver* s, int64_t span) {
+  return s->solver->spanVectorOffset(span);
+}
+int64_t bsp_span_matrix_offset(const bsp_solver* s, int64_t span, int64_t* out) {
+  BSP_TRY
+  *out = s->solver->spanMatrixOffset(span);
+  BSP_CATCH
+}
+
+int bsp_skeleton_array(const bsp_solver* s, int which, const int64_t** data, int64_t* len) {
+  BSP_TRY
+  const CoalescedBlockMatrixSkel& k = s->solver->skel();
+  const std::vector<int64_t>* v = nullptr;
+  switch (which) {
+    case BSP_SKEL_SPAN_START: v = &k.spanStart; break;
+    case BSP_SKEL_SPAN_TO_LUMP: v = &k.spanToLump; break;
+    case BSP_SKEL_LUMP_START: v = &k.lumpStart; break;
+    case BSP_SKEL_LUMP_TO_SPAN: v = &k.lumpToSpan; break;
+    case BSP_SKEL_SPAN_OFFSET_IN_LUMP: v = &k.spanOffsetInLump; break;
+    case BSP_SKEL_CHAIN_COL_PTR: v = &k.chainColPtr; break;
+    case BSP_SKEL_CHAIN_ROW_SPAN: v = &k.chainRowSpan; break;
+    case BSP_SKEL_CHAIN_DATA: v = &k.chainData; break;
+    case BSP_SKEL_CHAIN_ROWS_TILL_END: v = &k.chainRowsTillEnd; break;
+    case BSP_SKEL_BOARD_COL_PTR: v = &k.boardColPtr; break;
+    case BSP_SKEL_BOARD_ROW_LUMP: v = &k.boardRowLump; break;
+    case BSP_SKEL_BOARD_CHAIN_COL_ORD: v = &k.boardChainColOrd; break;
+    case BSP_SKEL_BOARD_ROW_PTR: v = &k.boardRowPtr; break;
+    case BSP_SKEL_BOARD_COL_LUMP: v = &k.boardColLump; break;
+    case BSP_SKEL_BOARD_COL_ORD: v = &k.boardColOrd; break;
+    case BSP_SKEL_PARAM_TO_SPAN: v = &s->solver->paramToSpan(); break;
+    case BSP_SKEL_SPARSE_ELIM_RANGES: v = &s->solver->sparseEliminationRanges(); break;
+    default: throw std::runtime_error("bsp_skeleton_array: unknown array id");
+  }
+  *data = v->data();
+  *len = (int64_t)v->size();
+  BSP_CATCH
+}
+
+int bsp_block_offset(const bsp_solver* s, int64_t rowParam, int64_t colParam, int64_t* offset,
+                     int64_t* stride, int32_t* flipped) {
+  BSP_TRY
+  const int64_t n = s->solver->skel().numSpans();
+  BASPACHO_CHECK(rowParam >= 0 && rowParam < n && colParam >= 0 && colParam < n);
+  auto acc = s->solver->accessor();
+  const int64_t pr = acc.permutation[rowParam], pc = acc.permutation[colParam];
+  if (!acc.plainAcc.hasBlock(std::max(pr, pc), std::min(pr, pc))) {
+    throw std::runtime_error("bsp_block_offset: block is not in the factor structure");
+  }
+  auto t = acc.blockOffset(rowParam, colParam);
+  *offset = std::get<0>(t);
+  *stride = std::get<1>(t);
+  *flipped = std::get<2>(t) ? 1 : 0;
+  BSP_CATCH
+}
+
+int bsp_diag_block_offset(const bsp_solver* s, int64_t param, int64_t* offset, int64_t* stride) {
+  BSP_TRY
+  BASPACHO_CHECK(param >= 0 && param < s->solver->skel().numSpans());
+  auto p = s->solver->accessor().diagBlockOffset(param);
+  *offset = p.first;
+  *stride = p.second;
+  BSP_CATCH
+}
+
+int bsp_device_accessor(bsp_solver* s, const int64_t* out[8]) {
+  BSP_TRY
+  PermutedCoalescedAccessor a = s->solver->deviceAccessor();
+  out[0] = a.plainAcc.spanStart;
+  out[1] = a.plainAcc.spanToLump;
+  out[2] = a.plainAcc.lumpStart;
+  out[3] = a.plainAcc.spanOffsetInLump;
+  out[4] = a.plainAcc.chainColPtr;
+  out[5] = a.plainAcc.chainRowSpan;
+  out[6] = a.plainAcc.chainData;
+  out[7] = a.permutation;
+  BSP_CATCH
+}
+
+void bsp_set_stream(bsp_solver* s, void* stream) { s->solver->setStream(stream); }
+
+int bsp_factor_f64(bsp_solver* s, double* d) {
+  BSP_TRY
+  s->solver->factor(d);
+  BSP_CATCH
+}
+int bsp_factor_f32(bsp_solver* s, float* d) {
+  BSP_TRY
+  s->solver->factor(d);
+  BSP_CATCH
+}
+int bsp_factor_batched_f64(bsp_solver* s, double* const* ptrs, int32_t batch) {
+  BSP_TRY
+  std::vector<double*> v(ptrs, ptrs + batch);
+  s->solver->factor(&v);
+  BSP_CATCH
+}
+int bsp_factor_batched_f32(bsp_solver* s, float* const* ptrs, int32_t batch) {
+  BSP_TRY
+  std::vector<float*> v(ptrs, ptrs + batch);
+  s->solver->factor(&v);
+  BSP_CATCH
+}
+int bsp_factor_up_to_f64(bsp_solver* s, double* d, int64_t span) {
+  BSP_TRY
+  s->solver->factorUpTo(d, span);
+  BSP_CATCH
+}
+int bsp_factor_from_f64(bsp_solver* s, double* d, int64_t span) {
+  BSP_TRY
+  s->solver->factorFrom(d, span);
+  BSP_CATCH
+}
+int bsp_factor_up_to_f32(bsp_solver* s, float* d, int64_t span) {
+  BSP_TRY
+  s->solver->factorUpTo(d, span);
+  BSP_CATCH
+}
+int bsp_factor_from_f32(bsp_solver* s, float* d, int64_t span) {
+  BSP_TRY
+  s->solver->factorFrom(d, span);
+  BSP_CATCH
+}
+
+template <typename T>
+static void doElim(bsp_solver* s, T* d, int64_t idx) {
+  const auto& ranges = s->solver->sparseEliminationRanges();
+  BASPACHO_CHECK(idx >= 0 && idx + 1 < (int64_t)ranges.size());
+  NumericCtxPtr<T> ctx = s->solver->internalSymbolicContext().createNumericCtx<T>(0, d);
+  ctx->doElimination(s->solver->internalGetElimCtx((size_t)idx), d, ranges[idx], ranges[idx + 1]);
+}
+int bsp_do_elimination_f64(bsp_solver* s, double* d, int64_t idx) {
+  BSP_TRY
+  doElim(s, d, idx);
+  BSP_CATCH
+}
+int bsp_do_elimination_f32(bsp_solver* s, float* d, int64_t idx) {
+  BSP_TRY
+  doElim(s, d, idx);
+  BSP_CATCH
+}
+
+int bsp_solve_f64(bsp_solver* s, const double* m, double* v, int64_t stride, int32_t nrhs) {
+  BSP_TRY
+  s->solver->solve(m, v, stride, nrhs);
+  BSP_CATCH
+}
+int bsp_solve_l_f64(bsp_solver* s, const double* m, double* v, int64_t stride, int32_t nrhs) {
+  BSP_TRY
+  s->solver->solveL(m, v, stride, nrhs);
+  BSP_CATCH
+}
+int bsp_solve_lt_f64(bsp_solver* s, const double* m, double* v, int64_t stride, int32_t nrhs) {
+  BSP_TRY
+  s->solver->solveLt(m, v, stride, nrhs);
+  BSP_CATCH
+}
+int bsp_solve_f32(bsp_solver* s, const float* m, float* v, int64_t stride, int32_t nrhs) {
+  BSP_TRY
+  s->solver->solve(m, v, stride, nrhs);
+  BSP_CATCH
+}
+int bsp_solve_l_f32(bsp_solver* s, const float* m, float* v, int64_t stride, int32_t nrhs) {
+  BSP_TRY
+  s->solver->solveL(m, v, stride, nrhs);
+  BSP_CATCH
+}
+int bsp_solve_lt_f32(bsp_solver* s, const float* m, float* v, int64_t stride, int32_t nrhs) {
+  BSP_TRY
+  s->solver->solveLt(m, v, stride, nrhs);
+  BSP_CATCH
+}
+
+double bsp_factor_flops(const bsp_solver* s) { return s->solver->factorFlops(); }
+
+int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out) {
+  BSP_TRY
+  HipPlanStats p = hipBackendPlanStats(s->solver->internalSymbolicContext(), 0,
+                                       s->solver->skel().numLumps());
+  out->flops = p.flops;
+  out->upd_elems = p.updElems;
+  out->num_launches = p.numLaunches;
+  out->num_levels = p.numLevels;
+  out->num_panels = p.numPanels;
+  out->num_segs = p.numSegs;
+  out->num_upd_tasks = p.numUpdTasks;
+  out->num_trsm_tasks = p.numTrsmTasks;
+  out->chain_tab_entries = p.chainTabEntries;
+  out->max_panels_in_level = p.maxPanelsInLevel;
+  out->num_atomic_upd_tasks = p.numAtomicUpdTasks;
+  BSP_CATCH
+}
+
+int bsp_factor_profiled_f64(bsp_solver* s, double* d, double ms[5], int64_t launches[5]) {
+  BSP_TRY
+  HipKernelProfile prof;
+  SymbolicCtx& sym = s->solver->internalSymbolicContext();
+  hipBackendSetProfile(sym, &prof);
+  try {
+    s->solver->factor(d);
+  } catch (...) {
+    hipBackendSetProfile(sym, nullptr);
+    throw;
+  }
+  hipBackendSetProfile(sym, nullptr);
+  for (int i = 0; i < kProfNumKinds; i++) {
+    ms[i] = prof.ms[i];
+    launches[i] = prof.launches[i];
+  }
+  BSP_CATCH
+}
+
+// ---- plan (de)serialisation: [magic, canFactorUpTo, nSpans, nLumps, nRowInd, nRanges,
+//      spanStart.., lumpToSpan.., colPtr.., rowInd.., ranges.., permutation..]
+static const int64_t kPlanMagic = 0x42535041434d4431LL;  // "BSPACMD1"
+
+int bsp_plan_serialize(const bsp_solver* s, int64_t* buf, int64_t capacity, int64_t* needed) {
+  BSP_TRY
+  const CoalescedBlockMatrixSkel& k = s->solver->skel();
+  const auto& ranges = s->solver->sparseEliminationRanges();
+  const auto& perm = s->solver->paramToSpan();
+  // column pointers / row indices of the lump columns are exactly chainColPtr / chainRowSpan
+  const int64_t nSpans = k.numSpans(), nLumps = k.numLumps();
+  const int64_t nRow = (int64_t)k.chainRowSpan.size(), nRanges = (int64_t)ranges.size();
+  const int64_t total = 6 + (nSpans + 1) + (nLumps + 1) + (nLumps + 1) + nRow + nRanges + nSpans;
+  *needed = total;
+  if (!buf || capacity < total) return 0;
+  int64_t* p = buf;
+  *p++ = kPlanMagic;
+  *p++ = s->solver->canFactorUpToSpan();
+  *p++ = nSpans;
+  *p++ = nLumps;
+  *p++ = nRow;
+  *p++ = nRanges;
+  p = std::copy(k.spanStart.begin(), k.spanStart.end(), p);
+  p = std::copy(k.lumpToSpan.begin(), k.lumpToSpan.end(), p);
+  p = std::copy(k.chainColPtr.begin(), k.chainColPtr.end(), p);
+  p = std::copy(k.chainRowSpan.begin(), k.chainRowSpan.end(), p);
+  p = std::copy(ranges.begin(), ranges.end(), p);
+  p = std::copy(perm.begin(), perm.end(), p);
+  BSP_CATCH
+}
+
+int bsp_create_solver_from_plan(const int64_t* buf, int64_t len, bsp_solver** out) {
+  BSP_TRY
+  BASPACHO_CHECK_NOTNULL(out);
+  BASPACHO_CHECK_GE(len, 6);
+  BASPACHO_CHECK_EQ(buf[0], kPlanMagic);
+  const int64_t canUpTo = buf[1], nSpans = buf[2], nLumps = buf[3], nRow = buf[4],
+                nRanges = buf[5];
+  const int64_t total = 6 + (nSpans + 1) + (nLumps + 1) + (nLumps + 1) + nRow + nRanges + nSpans;
+  BASPACHO_CHECK_EQ(len, total);
+  const int64_t* p = buf + 6;
+  std::vector<int64_t> spanStart(p, p + nSpans + 1);
+  p += nSpans + 1;
+  std::vector<int64_t> lumpToSpan(p, p + nLumps + 1);
+  p += nLumps + 1;
+  std::vector<int64_t> colPtr(p, p + nLumps + 1);
+  p += nLumps + 1;
+  std::vector<int64_t> rowInd(p, p + nRow);
+  p += nRow;
+  std::vector<int64_t> ranges(p, p + nRanges);
+  p += nRanges;
+  std::vector<int64_t> perm(p, p + nSpans);
+  CoalescedBlockMatrixSkel skel(spanStart, lumpToSpan, colPtr, rowInd);
+  std::unique_ptr<bsp_solver> h(new bsp_solver);
+  h->solver.reset(
+      new Solver(std::move(skel), std::move(ranges), std::move(perm), hipOps(), canUpTo));
+  *out = h.release();
+  BSP_CATCH
+}

@@ -1,0 +1,37 @@
+// Extras of the MI355X backend that sit beside the reference boundary (mat_ops.h):
+// per-kernel-class event timing and plan statistics, used by bench.py / the C ABI.
+#pragma once
+
+#include <cstdint>
+
+#include "mat_ops.h"
+
+namespace BaSpaCho {
+
+enum HipProfKind {
+  kProfElimFactor = 0,
+  kProfElimUpdate = 1,
+  kProfPotrf = 2,
+  kProfTrsm = 3,
+  kProfUpdate = 4,
+  kProfNumKinds = 5
+};
+
+struct HipKernelProfile {
+  double ms[kProfNumKinds] = {0, 0, 0, 0, 0};
+  int64_t launches[kProfNumKinds] = {0, 0, 0, 0, 0};
+};
+
+struct HipPlanStats {
+  double flops = 0, updElems = 0;
+  int64_t numLaunches = 0, numLevels = 0, numPanels = 0, numSegs = 0, numUpdTasks = 0,
+          numTrsmTasks = 0, chainTabEntries = 0, maxPanelsInLevel = 0, numAtomicUpdTasks = 0;
+};
+
+// while `prof` is non-null every kernel launch of the context is bracketed by HIP events on
+// the execution stream and accumulated per kernel class (factor calls then synchronise)
+void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof);
+
+HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t upToLump);
+
+}  // namespace BaSpaCho

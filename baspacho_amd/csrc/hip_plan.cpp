@@ -1,0 +1,238 @@
+#include "hip_plan.h"
+
+#include <algorithm>
+#include <map>
+
+namespace BaSpaCho {
+
+using std::vector;
+
+namespace {
+
+struct LumpCols {
+  int64_t width, diagOff, rowsBelow, diagChains, chain0, nChains;
+};
+
+LumpCols lumpCols(const CoalescedBlockMatrixSkel& sk, int64_t l) {
+  LumpCols g;
+  g.width = sk.lumpStart[l + 1] - sk.lumpStart[l];
+  g.chain0 = sk.chainColPtr[l];
+  g.nChains = sk.chainColPtr[l + 1] - g.chain0;
+  g.diagChains = sk.boardChainColOrd[sk.boardColPtr[l] + 1];
+  g.diagOff = sk.chainData[g.chain0];
+  g.rowsBelow =
+      sk.chainRowsTillEnd[g.chain0 + g.nChains - 1] - sk.chainRowsTillEnd[g.chain0 + g.diagChains - 1];
+  return g;
+}
+
+struct PanelBuild {
+  int32_t panel;
+  int32_t level;
+};
+
+}  // namespace
+
+HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_t>& elimRangesIn,
+                         int64_t startLump, int64_t upToLump) {
+  HipPlanHost plan;
+  plan.startLump = startLump;
+  plan.upToLump = upToLump;
+  const int64_t nLumps = sk.numLumps();
+  const int64_t denseFrom = elimRangesIn.empty() ? 0 : elimRangesIn.back();
+  BASPACHO_CHECK_LT(sk.order(), (int64_t)INT32_MAX);
+
+  vector<vector<PanelBuild>> levelBuckets;       // dense levels
+  auto bucketAt = [](vector<vector<PanelBuild>>& buckets, size_t lvl) -> vector<PanelBuild>& {
+    if (buckets.size() <= lvl) buckets.resize(lvl + 1);
+    return buckets[lvl];
+  };
+
+  // per-panel segment ranges (segments of one panel are contiguous in plan.segs)
+  vector<int64_t> panelSegBegin, panelSegEnd;
+
+  // ---- helper: cut a lump into panels; returns number of panels
+  auto addPanels = [&](int64_t l, const LumpCols& g, int32_t lumpRowBase, bool withBoards,
+                       const vector<SegDesc>& boardSegTemplates) {
+    int32_t count = 0;
+    for (int64_t c0 = 0; c0 < g.width; c0 += kPanelWidth, count++) {
+      const int32_t nb = (int32_t)std::min<int64_t>(kPanelWidth, g.width - c0);
+      PanelDesc pd;
+      pd.diagOff = g.diagOff + c0 * g.width + c0;
+      pd.lda = (int32_t)g.width;
+      pd.nb = nb;
+      pd.nRest = (int32_t)(g.width - c0 - nb);
+      pd.rowsBelow = (int32_t)(pd.nRest + g.rowsBelow);
+      pd.lumpRowBase = lumpRowBase;
+      pd.lump = (int32_t)l;
+      const int32_t pIdx = (int32_t)plan.panels.size();
+      plan.panels.push_back(pd);
+      panelSegBegin.push_back((int64_t)plan.segs.size());
+      if (pd.nRest > 0) {
+        SegDesc s{};
+        s.panel = pIdx;
+        s.kind = kSegIntra;
+        s.q0 = 0;
+        s.m = pd.nRest;
+        s.tgtBase = g.diagOff + (c0 + nb) * g.width + (c0 + nb);
+        s.tgtStride = (int32_t)g.width;
+        plan.segs.push_back(s);
+      }
+      if (withBoards) {
+        for (SegDesc s : boardSegTemplates) {
+          s.panel = pIdx;
+          s.q0 += pd.nRest;
+          plan.segs.push_back(s);
+        }
+      }
+      panelSegEnd.push_back((int64_t)plan.segs.size());
+    }
+    return count;
+  };
+
+  // ---- sparse-elimination ranges inside [startLump, upToLump)
+  vector<vector<vector<PanelBuild>>> elimBigBuckets;
+  for (size_t r = 0; r + 1 < elimRangesIn.size(); r++) {
+    const int64_t rb = elimRangesIn[r], re = elimRangesIn[r + 1];
+    if (re > upToLump) break;
+    if (rb < startLump) continue;
+    ElimRangePlan er;
+    er.lumpBegin = rb;
+    er.lumpEnd = re;
+    er.chainBegin = sk.chainColPtr[rb];
+    er.chainEnd = sk.chainColPtr[re];
+    er.chainLumpOff = (int64_t)plan.elimChainLump.size();
+    er.maxWidth = 0;
+    vector<vector<PanelBuild>> big;
+    for (int64_t l = rb; l < re; l++) {
+      LumpCols g = lumpCols(sk, l);
+      er.maxWidth = std::max<int32_t>(er.maxWidth, (int32_t)g.width);
+      for (int64_t c = 0; c < g.nChains; c++) plan.elimChainLump.push_back((int32_t)l);
+      plan.flops += double(g.width) * g.width * g.width / 3.0 +
+                    double(g.rowsBelow) * g.width * g.width +
+                    double(g.rowsBelow) * g.rowsBelow * g.width;
+      if (g.width > kElimSmallMax) {
+        const int32_t first = (int32_t)plan.panels.size();
+        int32_t n = addPanels(l, g, 0, /*withBoards=*/false, {});
+        for (int32_t j = 0; j < n; j++) bucketAt(big, j).push_back({first + j, j});
+      }
+    }
+    elimBigBuckets.push_back(std::move(big));
+    plan.elimRanges.push_back(std::move(er));
+  }
+
+  // ---- dense lumps
+  const int64_t denseBegin = std::max(startLump, denseFrom);
+  vector<int32_t> lastLevelOfLump(nLumps, -1);
+  for (int64_t l = denseBegin; l < upToLump; l++) {
+    LumpCols g = lumpCols(sk, l);
+    plan.flops += double(g.width) * g.width * g.width / 3.0 +
+                  double(g.rowsBelow) * g.width * g.width +
+                  double(g.rowsBelow) * g.rowsBelow * g.width;
+
+    // per-row lookup arrays of the below-diagonal rows
+    const int32_t lumpRowBase = (int32_t)plan.rowChain.size();
+    const int64_t belowChain0 = g.chain0 + g.diagChains;
+    for (int64_t c = belowChain0; c < g.chain0 + g.nChains; c++) {
+      const int64_t span = sk.chainRowSpan[c];
+      const int64_t rows = sk.spanStart[span + 1] - sk.spanStart[span];
+      for (int64_t i = 0; i < rows; i++) {
+        plan.rowChain.push_back((int32_t)(c - belowChain0));
+        plan.rowLocal.push_back((int32_t)i);
+        plan.rowColOff.push_back((int32_t)(sk.spanOffsetInLump[span] + i));
+      }
+    }
+    BASPACHO_CHECK_LT((int64_t)plan.rowChain.size(), (int64_t)INT32_MAX);
+
+    // one segment template per off-diagonal board (q0 relative to the first chain row)
+    vector<SegDesc> boardSegs;
+    const int64_t b0 = sk.boardColPtr[l], bEnd = sk.boardColPtr[l + 1] - 1;  // bEnd = sentinel
+    const int64_t rowsAboveBelow = sk.chainRowsTillEnd[belowChain0 - 1];
+    for (int64_t b = b0 + 1; b < bEnd; b++) {
+      const int64_t t = sk.boardRowLump[b];
+      const int64_t chFirst = sk.boardChainColOrd[b], chNext = sk.boardChainColOrd[b + 1];
+      SegDesc s{};
+      s.kind = kSegBoard;
+      s.q0 = (int32_t)(sk.chainRowsTillEnd[g.chain0 + chFirst - 1] - rowsAboveBelow);
+      s.m = (int32_t)(sk.chainRowsTillEnd[g.chain0 + chNext - 1] -
+                      sk.chainRowsTillEnd[g.chain0 + chFirst - 1]);
+      s.tgtStride = (int32_t)(sk.lumpStart[t + 1] - sk.lumpStart[t]);
+      s.firstChainOrd = (int32_t)(chFirst - g.diagChains);
+      s.chainTabPtr = (int64_t)plan.chainOffTab.size();
+      s.tgtBase = t;  // temporarily: the target lump (replaced below by 0)
+      // offsets, inside column t, of every chain of this column from the board onwards
+      int64_t tc = sk.chainColPtr[t];
+      const int64_t tcEnd = sk.chainColPtr[t + 1];
+      for (int64_t c = g.chain0 + chFirst; c < g.chain0 + g.nChains; c++) {
+        const int64_t span = sk.chainRowSpan[c];
+        while (tc < tcEnd && sk.chainRowSpan[tc] < span) tc++;
+        BASPACHO_CHECK(tc < tcEnd && sk.chainRowSpan[tc] == span);  // fill property
+        plan.chainOffTab.push_back(sk.chainData[tc]);
+      }
+      boardSegs.push_back(s);
+    }
+
+    // level of the first panel: after every planned source column of block-row l
+    int32_t level = 0;
+    for (int64_t q = sk.boardRowPtr[l]; q < sk.boardRowPtr[l + 1] - 1; q++) {
+      const int64_t s = sk.boardColLump[q];
+      if (s >= denseBegin && s < l) level = std::max(level, lastLevelOfLump[s] + 1);
+    }
+    const int32_t first = (int32_t)plan.panels.size();
+    const int32_t n = addPanels(l, g, lumpRowBase, /*withBoards=*/true, boardSegs);
+    for (int32_t j = 0; j < n; j++) bucketAt(levelBuckets, level + j).push_back({first + j, level + j});
+    lastLevelOfLump[l] = level + n - 1;
+  }
+
+  // ---- emit task lists level by level
+  auto emitLevels = [&](const vector<vector<PanelBuild>>& buckets, vector<LevelRange>& out) {
+    for (const auto& bucket : buckets) {
+      LevelRange lr;
+      lr.panelBegin = (int64_t)plan.levelPanels.size();
+      lr.trsmBegin = (int64_t)plan.trsmTasks.size();
+      lr.updBegin = (int64_t)plan.updTasks.size();
+      // how many panels of this level hit each target lump
+      std::map<int64_t, int> hits;
+      for (const auto& pb : bucket) {
+        for (int64_t s = panelSegBegin[pb.panel]; s < panelSegEnd[pb.panel]; s++) {
+          if (plan.segs[s].kind == kSegBoard) hits[plan.segs[s].tgtBase]++;
+        }
+      }
+      for (const auto& pb : bucket) {
+        const PanelDesc& pd = plan.panels[pb.panel];
+        plan.levelPanels.push_back(pb.panel);
+        for (int32_t r = 0; r < pd.rowsBelow; r += kTile) plan.trsmTasks.push_back({pb.panel, r});
+        for (int64_t s = panelSegBegin[pb.panel]; s < panelSegEnd[pb.panel]; s++) {
+          const SegDesc& sd = plan.segs[s];
+          const int32_t atomic = sd.kind == kSegBoard && hits[sd.tgtBase] > 1 ? 1 : 0;
+          for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += kTile) {
+            for (int32_t rT = cT; rT < pd.rowsBelow; rT += kTile) {
+              plan.updTasks.push_back({(int32_t)s, rT, cT, atomic});
+            }
+          }
+          const double R = double(pd.rowsBelow - sd.q0), m = double(sd.m);
+          plan.updElems += m * R - m * (m - 1) / 2;
+        }
+      }
+      lr.panelEnd = (int64_t)plan.levelPanels.size();
+      lr.trsmEnd = (int64_t)plan.trsmTasks.size();
+      lr.updEnd = (int64_t)plan.updTasks.size();
+      plan.maxPanelsInLevel = std::max<int64_t>(plan.maxPanelsInLevel, lr.panelEnd - lr.panelBegin);
+      plan.numLaunches += 1 + (lr.trsmEnd > lr.trsmBegin) + (lr.updEnd > lr.updBegin);
+      out.push_back(lr);
+    }
+  };
+  for (size_t r = 0; r < plan.elimRanges.size(); r++) {
+    emitLevels(elimBigBuckets[r], plan.elimRanges[r].bigLevels);
+    plan.numLaunches += 2;
+  }
+  emitLevels(levelBuckets, plan.levels);
+
+  // board segments carried their target lump in tgtBase only for the atomic analysis
+  for (auto& s : plan.segs) {
+    if (s.kind == kSegBoard) s.tgtBase = 0;
+  }
+  BASPACHO_CHECK_LT((int64_t)plan.segs.size(), (int64_t)INT32_MAX);
+  return plan;
+}
+
+}  // namespace BaSpaCho

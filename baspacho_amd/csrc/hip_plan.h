@@ -1,0 +1,105 @@
+// Device plan of the MI355X backend: everything the numeric kernels need, derived ONCE per
+// (skeleton, lump range) on the host and uploaded as a handful of flat arrays.
+//
+// Design: the reference drives factor() as a host-serial loop of per-lump /
+// per-board library calls (Solver.cpp:198-218).  Here every dense lump is cut into column
+// PANELS of at most kPanelWidth columns; a panel is factored (potrf of its diagonal block,
+// trsm of all rows below) and then pushes its rank-nb update  C = B*B^T  straight into its
+// targets (right-looking), one SEGMENT per target: the rest of its own lump (linear
+// addressing) and every board of the lump column (scatter through a per-(lump,board) chain
+// offset table, replacing prepareAssemble's per-target table rebuild, MatOpsCuda.cu:471-481).
+// Panels are grouped into LEVELS of mutually independent panels (elimination-tree
+// parallelism the reference never exploits); one level = three launches (potrf, trsm, update)
+// whose grids cover all panels of the level.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "skeleton.h"
+
+namespace BaSpaCho {
+
+constexpr int kPanelWidth = 64;   // max panel width nb (K of the update GEMM)
+constexpr int kTile = 64;         // update tile (rows x cols) and trsm row tile
+constexpr int kElimSmallMax = 16; // widest lump handled by the small sparse-elim kernels
+
+struct PanelDesc {
+  int64_t diagOff;     // data offset of the nb x nb diagonal block of the panel
+  int32_t lda;         // row stride (= lump width)
+  int32_t nb;          // panel width
+  int32_t rowsBelow;   // rows below the diagonal block: nRest + chain rows of the lump
+  int32_t nRest;       // rows that still belong to the lump's own diagonal block
+  int32_t lumpRowBase; // index of the lump's first chain row in the rowChain/rowLocal/rowColOff arrays
+  int32_t lump;
+};
+
+enum SegKind : int32_t { kSegIntra = 0, kSegBoard = 1 };
+
+struct SegDesc {
+  int32_t panel;
+  int32_t kind;
+  int32_t q0;            // first below-row index covered by the segment's columns
+  int32_t m;             // number of columns
+  int64_t tgtBase;       // intra: data offset of element (row q=0, col q=0) of the target region
+  int32_t tgtStride;     // row stride of the target lump
+  int32_t firstChainOrd; // board: below-diagonal chain ordinal of the segment's first chain
+  int64_t chainTabPtr;   // board: index into chainOffTab of that chain's entry
+};
+
+struct UpdTask {
+  int32_t seg;
+  int32_t rowTile;  // first below-row index of the tile rows
+  int32_t colTile;  // first below-row index of the tile cols
+  int32_t atomic;   // 1: several panels of this level hit the same target lump
+};
+
+struct TrsmTask {
+  int32_t panel;
+  int32_t rowTile;
+};
+
+struct LevelRange {
+  int64_t panelBegin, panelEnd;  // into levelPanels
+  int64_t trsmBegin, trsmEnd;    // into trsmTasks
+  int64_t updBegin, updEnd;      // into updTasks
+};
+
+// one sparse-elimination range restricted to the planned lump range
+struct ElimRangePlan {
+  int64_t lumpBegin, lumpEnd;
+  int64_t chainBegin, chainEnd;  // absolute chain indices covered by the range
+  int64_t chainLumpOff;          // offset into elimChainLump of chain `chainBegin`
+  int32_t maxWidth;              // widest lump of the range
+  std::vector<LevelRange> bigLevels;  // lumps wider than kElimSmallMax go through panels
+};
+
+struct HipPlanHost {
+  int64_t startLump = 0, upToLump = 0;
+  std::vector<ElimRangePlan> elimRanges;
+  std::vector<int32_t> elimChainLump;  // lump of every chain inside elimination ranges
+
+  std::vector<PanelDesc> panels;
+  std::vector<SegDesc> segs;
+  std::vector<int64_t> chainOffTab;
+  std::vector<int32_t> rowChain, rowLocal, rowColOff;  // per chain row of every dense lump
+
+  std::vector<int32_t> levelPanels;
+  std::vector<TrsmTask> trsmTasks;
+  std::vector<UpdTask> updTasks;
+  std::vector<LevelRange> levels;
+
+  // statistics
+  double flops = 0;          // algorithmic flops of this plan (n^3/3 + r n^2 + r^2 n per lump)
+  double updElems = 0;       // lower-trapezoid elements written by update tiles
+  int64_t numLaunches = 0;
+  int64_t maxPanelsInLevel = 0;
+};
+
+// Build the plan for factoring lumps [startLump, upToLump) (sparse-elimination ranges fully
+// inside the interval are included); `sparseElimRanges` as stored by the Solver.
+HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& skel,
+                         const std::vector<int64_t>& sparseElimRanges, int64_t startLump,
+                         int64_t upToLump);
+
+}  // namespace BaSpaCho

@@ -1,0 +1,535 @@
+// Solver driver.  Follows the call structure of baspacho/baspacho/Solver.cpp:
+//   ctor :22-40, factorLump :42-64, eliminateBoard :66-98, initElimination :117-147,
+//   internalFactorRange :164-219, solve family :221-397, createSolver :611-752.
+// When the backend advertises a fused path (MI355X HIP backend) the per-op loops below are
+// bypassed and the whole range is handed to NumericCtx::factorRange / SolveCtx::solve*Range.
+#include "solver.h"
+
+#include <algorithm>
+#include <iostream>
+#include <numeric>
+
+#include "computation_model.h"
+#include "elimination_tree.h"
+
+namespace BaSpaCho {
+
+using std::vector;
+
+namespace {
+
+// geometry of one lump column, read off the skeleton
+struct ColumnGeom {
+  int64_t width;       // lump size
+  int64_t diagOffset;  // data offset of the square diagonal block
+  int64_t belowOffset; // data offset of the first row below the diagonal block
+  int64_t rowsBelow;   // number of rows below the diagonal block
+  int64_t firstBelowChain;  // chain index (absolute) of the first below-diagonal chain
+  int64_t numBelowChains;
+};
+
+ColumnGeom columnGeom(const CoalescedBlockMatrixSkel& sk, int64_t lump) {
+  ColumnGeom g;
+  g.width = sk.lumpStart[lump + 1] - sk.lumpStart[lump];
+  const int64_t c0 = sk.chainColPtr[lump];
+  const int64_t nChains = sk.chainColPtr[lump + 1] - c0;
+  const int64_t diagChains = sk.boardChainColOrd[sk.boardColPtr[lump] + 1];
+  g.diagOffset = sk.chainData[c0];
+  g.belowOffset = sk.chainData[c0 + diagChains];
+  g.rowsBelow = sk.chainRowsTillEnd[c0 + nChains - 1] - sk.chainRowsTillEnd[c0 + diagChains - 1];
+  g.firstBelowChain = c0 + diagChains;
+  g.numBelowChains = nChains - diagChains;
+  return g;
+}
+
+}  // namespace
+
+Solver::Solver(CoalescedBlockMatrixSkel&& factorSkel_, vector<int64_t>&& sparseElimRanges_,
+               vector<int64_t>&& permutation_, OpsPtr&& ops_, int64_t canFactorUpTo_)
+    : factorSkel(std::move(factorSkel_)),
+      sparseElimRanges(std::move(sparseElimRanges_)),
+      permutation(std::move(permutation_)),
+      canFactorUpTo(canFactorUpTo_ < 0 ? factorSkel.numSpans() : canFactorUpTo_),
+      ops(std::move(ops_)) {
+  BASPACHO_CHECK_NOTNULL(ops.get());
+  BASPACHO_CHECK((int64_t)sparseElimRanges.size() != 1);
+  if (permutation.empty()) {  // raw skeleton: identity ordering
+    permutation.resize(factorSkel.numSpans());
+    std::iota(permutation.begin(), permutation.end(), 0);
+  }
+  symCtx = ops->createSymbolicCtx(factorSkel, permutation);
+  symCtx->setSparseElimRanges(sparseElimRanges);
+  for (size_t r = 0; r + 1 < sparseElimRanges.size(); r++) {
+    elimCtxs.push_back(symCtx->prepareElimination(sparseElimRanges[r], sparseElimRanges[r + 1]));
+  }
+  initElimination();
+}
+
+template <typename T>
+void Solver::factorLump(NumericCtx<T>& numCtx, T* data, int64_t lump) const {
+  ColumnGeom g = columnGeom(factorSkel, lump);
+  numCtx.potrf(g.width, data, g.diagOffset);
+  if (g.rowsBelow > 0) numCtx.trsm(g.width, g.rowsBelow, data, g.diagOffset, g.belowOffset);
+}
+
+namespace {
+
+// shape of the update produced by board `ord` of column `lump`
+struct BoardGeom {
+  int64_t firstChain;   // absolute chain index where the board starts
+  int64_t rectRowBegin; // rows of the column above the board
+  int64_t rowsSub;      // rows of the board itself (m)
+  int64_t rowsFull;     // rows from the board to the end of the column (n)
+  int64_t numBlockRows, numBlockCols;
+  int64_t targetLump;
+};
+
+BoardGeom boardGeom(const CoalescedBlockMatrixSkel& sk, int64_t lump, int64_t ord) {
+  BoardGeom b;
+  const int64_t c0 = sk.chainColPtr[lump];
+  const int64_t b0 = sk.boardColPtr[lump], bEnd = sk.boardColPtr[lump + 1];
+  const int64_t chFirst = sk.boardChainColOrd[b0 + ord];
+  const int64_t chNext = sk.boardChainColOrd[b0 + ord + 1];
+  const int64_t chEnd = sk.boardChainColOrd[bEnd - 1];
+  b.firstChain = c0 + chFirst;
+  b.rectRowBegin = sk.chainRowsTillEnd[c0 + chFirst - 1];
+  b.rowsSub = sk.chainRowsTillEnd[c0 + chNext - 1] - b.rectRowBegin;
+  b.rowsFull = sk.chainRowsTillEnd[c0 + chEnd - 1] - b.rectRowBegin;
+  b.numBlockRows = chEnd - chFirst;
+  b.numBlockCols = chNext - chFirst;
+  b.targetLump = sk.boardRowLump[b0 + ord];
+  return b;
+}
+
+}  // namespace
+
+template <typename T>
+void Solver::eliminateBoard(NumericCtx<T>& numCtx, T* data, int64_t ptr) const {
+  const int64_t srcLump = factorSkel.boardColLump[ptr];
+  const int64_t srcWidth = factorSkel.lumpStart[srcLump + 1] - factorSkel.lumpStart[srcLump];
+  BoardGeom b = boardGeom(factorSkel, srcLump, factorSkel.boardColOrd[ptr]);
+
+  numCtx.saveSyrkGemm(b.rowsSub, b.rowsFull, srcWidth, data, factorSkel.chainData[b.firstChain]);
+
+  const int64_t targetWidth =
+      factorSkel.lumpStart[b.targetLump + 1] - factorSkel.lumpStart[b.targetLump];
+  numCtx.assemble(data, b.rectRowBegin, targetWidth, b.firstChain, b.rowsSub, b.numBlockRows,
+                  b.numBlockCols);
+}
+
+int64_t Solver::boardElimTempSize(int64_t lump, int64_t boardIndexInCol) const {
+  BoardGeom b = boardGeom(factorSkel, lump, boardIndexInCol);
+  return b.rowsSub * b.rowsFull;
+}
+
+void Solver::initElimination() {
+  const int64_t denseFrom = sparseElimRanges.empty() ? 0 : sparseElimRanges.back();
+  const int64_t nLumps = factorSkel.numLumps();
+  startElimRowPtr.assign(nLumps - denseFrom, 0);
+  maxElimTempSize = 0;
+  for (int64_t l = denseFrom; l < nLumps; l++) {
+    // boards of row l, sorted by column lump; skip the sparse-eliminated source columns
+    int64_t r = factorSkel.boardRowPtr[l];
+    const int64_t rEnd = factorSkel.boardRowPtr[l + 1];
+    BASPACHO_CHECK_EQ(factorSkel.boardColLump[rEnd - 1], l);  // last board = diagonal
+    while (factorSkel.boardColLump[r] < denseFrom) r++;
+    BASPACHO_CHECK_LT(r, rEnd);
+    startElimRowPtr[l - denseFrom] = r;
+    for (; r < rEnd && factorSkel.boardColLump[r] < l; r++) {
+      const int64_t src = factorSkel.boardColLump[r], ord = factorSkel.boardColOrd[r];
+      BASPACHO_CHECK_LT(ord, factorSkel.boardColPtr[src + 1] - factorSkel.boardColPtr[src]);
+      BASPACHO_CHECK_EQ(l, factorSkel.boardRowLump[factorSkel.boardColPtr[src] + ord]);
+      maxElimTempSize = std::max(maxElimTempSize, boardElimTempSize(src, ord));
+    }
+  }
+}
+
+double Solver::factorFlops() const {
+  double flops = 0;
+  for (int64_t l = 0; l < factorSkel.numLumps(); l++) {
+    ColumnGeom g = columnGeom(factorSkel, l);
+    double n = double(g.width), r = double(g.rowsBelow);
+    flops += n * n * n / 3.0 + r * n * n + r * r * n;
+  }
+  return flops;
+}
+
+template <typename T>
+void Solver::factor(T* data, bool verbose) const {
+  factorUpTo(data, factorSkel.numSpans(), verbose);
+}
+
+template <typename T>
+void Solver::factorUpTo(T* data, int64_t spanIndex, bool verbose) const {
+  internalFactorRange(data, 0, spanIndex, verbose);
+}
+
+template <typename T>
+void Solver::factorFrom(T* data, int64_t spanIndex, bool verbose) const {
+  internalFactorRange(data, spanIndex, factorSkel.numSpans(), verbose);
+}
+
+template <typename T>
+void Solver::internalFactorRange(T* data, int64_t startSpanIndex, int64_t endSpanIndex,
+                                 bool verbose) const {
+  BASPACHO_CHECK_GE(startSpanIndex, 0);
+  BASPACHO_CHECK_LE(startSpanIndex, endSpanIndex);
+  BASPACHO_CHECK_LT(endSpanIndex, (int64_t)factorSkel.spanOffsetInLump.size());
+  BASPACHO_CHECK_EQ(factorSkel.spanOffsetInLump[startSpanIndex], 0);
+  BASPACHO_CHECK_EQ(factorSkel.spanOffsetInLump[endSpanIndex], 0);
+  BASPACHO_CHECK_LE(endSpanIndex, canFactorUpTo);
+  const int64_t startLump = factorSkel.spanToLump[startSpanIndex];
+  const int64_t upToLump = factorSkel.spanToLump[endSpanIndex];
+
+  NumericCtxPtr<T> numCtx = symCtx->createNumericCtx<T>(maxElimTempSize, data);
+
+  // a partial range may not cut through a sparse-elimination range
+  for (size_t r = 0; r + 1 < sparseElimRanges.size(); r++) {
+    const int64_t rb = sparseElimRanges[r], re = sparseElimRanges[r + 1];
+    if (re > upToLump) {
+      BASPACHO_CHECK_EQ(rb, upToLump);
+      break;
+    }
+    if (startLump > rb) BASPACHO_CHECK_GE(startLump, re);
+  }
+
+  if (numCtx->hasFusedFactor()) {
+    if (verbose) {
+      std::cout << "Fused factor, lumps [" << startLump << ", " << upToLump << ")" << std::endl;
+    }
+    numCtx->factorRange(data, startLump, upToLump);
+    return;
+  }
+
+  // ---- reference-style per-op loop (for backends without a fused path)
+  for (size_t r = 0; r + 1 < sparseElimRanges.size(); r++) {
+    const int64_t rb = sparseElimRanges[r], re = sparseElimRanges[r + 1];
+    if (re > upToLump) return;
+    if (startLump > rb) continue;
+    if (verbose) std::cout << "Elim set: " << r << " (" << rb << ".." << re << ")" << std::endl;
+    numCtx->doElimination(*elimCtxs[r], data, rb, re);
+  }
+
+  const int64_t denseFrom = sparseElimRanges.empty() ? 0 : sparseElimRanges.back();
+  if (verbose) std::cout << "Block-Fact from: " << denseFrom << std::endl;
+
+  for (int64_t l = std::max(startLump, denseFrom); l < factorSkel.numLumps(); l++) {
+    numCtx->prepareAssemble(l);
+    // off-diagonal boards of row l: one update per source column
+    for (int64_t r = startElimRowPtr[l - denseFrom], rEnd = factorSkel.boardRowPtr[l + 1] - 1;
+         r < rEnd; r++) {
+      const int64_t src = factorSkel.boardColLump[r];
+      if (src >= upToLump) break;
+      if (src < startLump) continue;
+      eliminateBoard(*numCtx, data, r);
+    }
+    if (l < upToLump) factorLump(*numCtx, data, l);
+  }
+}
+
+template <typename T>
+void Solver::solve(const T* matData, T* vecData, int64_t stride, int nRHS) const {
+  SolveCtxPtr<T> slvCtx = symCtx->createSolveCtx<T>(nRHS, matData);
+  internalSolveLRange(*slvCtx, matData, 0, factorSkel.numSpans(), vecData, stride, nRHS);
+  internalSolveLtRange(*slvCtx, matData, 0, factorSkel.numSpans(), vecData, stride, nRHS);
+}
+
+template <typename T>
+void Solver::solveL(const T* matData, T* vecData, int64_t stride, int nRHS) const {
+  solveLUpTo(matData, factorSkel.numSpans(), vecData, stride, nRHS);
+}
+
+template <typename T>
+void Solver::solveLt(const T* matData, T* vecData, int64_t stride, int nRHS) const {
+  solveLtUpTo(matData, factorSkel.numSpans(), vecData, stride, nRHS);
+}
+
+template <typename T>
+void Solver::solveLUpTo(const T* matData, int64_t spanIndex, T* vecData, int64_t stride,
+                        int nRHS) const {
+  SolveCtxPtr<T> slvCtx = symCtx->createSolveCtx<T>(nRHS, matData);
+  internalSolveLRange(*slvCtx, matData, 0, spanIndex, vecData, stride, nRHS);
+}
+
+template <typename T>
+void Solver::solveLtUpTo(const T* matData, int64_t spanIndex, T* vecData, int64_t stride,
+                         int nRHS) const {
+  SolveCtxPtr<T> slvCtx = symCtx->createSolveCtx<T>(nRHS, matData);
+  internalSolveLtRange(*slvCtx, matData, 0, spanIndex, vecData, stride, nRHS);
+}
+
+template <typename T>
+void Solver::solveLFrom(const T* matData, int64_t spanIndex, T* vecData, int64_t stride,
+                        int nRHS) const {
+  SolveCtxPtr<T> slvCtx = symCtx->createSolveCtx<T>(nRHS, matData);
+  internalSolveLRange(*slvCtx, matData, spanIndex, factorSkel.numSpans(), vecData, stride, nRHS);
+}
+
+template <typename T>
+void Solver::solveLtFrom(const T* matData, int64_t spanIndex, T* vecData, int64_t stride,
+                         int nRHS) const {
+  SolveCtxPtr<T> slvCtx = symCtx->createSolveCtx<T>(nRHS, matData);
+  internalSolveLtRange(*slvCtx, matData, spanIndex, factorSkel.numSpans(), vecData, stride, nRHS);
+}
+
+template <typename T>
+void Solver::internalSolveLRange(SolveCtx<T>& slvCtx, const T* matData, int64_t startSpanIndex,
+                                 int64_t endSpanIndex, T* vecData, int64_t stride,
+                                 int nRHS) const {
+  BASPACHO_CHECK_GE(startSpanIndex, 0);
+  BASPACHO_CHECK_LE(startSpanIndex, endSpanIndex);
+  BASPACHO_CHECK_LT(endSpanIndex, (int64_t)factorSkel.spanOffsetInLump.size());
+  BASPACHO_CHECK_EQ(factorSkel.spanOffsetInLump[startSpanIndex], 0);
+  BASPACHO_CHECK_EQ(factorSkel.spanOffsetInLump[endSpanIndex], 0);
+  const int64_t startLump = factorSkel.spanToLump[startSpanIndex];
+  const int64_t upToLump = factorSkel.spanToLump[endSpanIndex];
+
+  if (slvCtx.hasFusedSolve()) {
+    slvCtx.solveLRange(matData, startLump, upToLump, vecData, stride);
+    return;
+  }
+
+  for (size_t r = 0; r + 1 < sparseElimRanges.size(); r++) {
+    const int64_t rb = sparseElimRanges[r], re = sparseElimRanges[r + 1];
+    if (re > upToLump) {
+      BASPACHO_CHECK_EQ(rb, upToLump);
+      return;
+    }
+    if (startLump > rb) {
+      BASPACHO_CHECK_GE(startLump, re);
+      continue;
+    }
+    slvCtx.sparseElimSolveL(*elimCtxs[r], matData, rb, re, vecData, stride);
+  }
+  const int64_t denseFrom =
+      std::max(startLump, sparseElimRanges.empty() ? int64_t(0) : sparseElimRanges.back());
+
+  if (factorSkel.numSpans() == factorSkel.numLumps() && slvCtx.hasFragmentedOps() && nRHS == 1) {
+    slvCtx.fragmentedSolveL(matData, denseFrom, upToLump, vecData);
+    return;
+  }
+  for (int64_t l = denseFrom; l < upToLump; l++) {
+    ColumnGeom g = columnGeom(factorSkel, l);
+    const int64_t vecOff = factorSkel.lumpStart[l];
+    slvCtx.solveL(matData, g.diagOffset, g.width, vecData, vecOff, stride);
+    if (g.rowsBelow == 0) continue;
+    slvCtx.gemv(matData, g.belowOffset, g.rowsBelow, g.width, vecData, vecOff, stride, -1.0);
+    slvCtx.assembleVec(g.firstBelowChain, g.numBelowChains, vecData, stride);
+  }
+}
+
+template <typename T>
+void Solver::internalSolveLtRange(SolveCtx<T>& slvCtx, const T* matData, int64_t startSpanIndex,
+                                  int64_t endSpanIndex, T* vecData, int64_t stride,
+                                  int nRHS) const {
+  BASPACHO_CHECK_GE(startSpanIndex, 0);
+  BASPACHO_CHECK_LE(startSpanIndex, endSpanIndex);
+  BASPACHO_CHECK_LT(endSpanIndex, (int64_t)factorSkel.spanOffsetInLump.size());
+  BASPACHO_CHECK_EQ(factorSkel.spanOffsetInLump[startSpanIndex], 0);
+  BASPACHO_CHECK_EQ(factorSkel.spanOffsetInLump[endSpanIndex], 0);
+  const int64_t startLump = factorSkel.spanToLump[startSpanIndex];
+  const int64_t upToLump = factorSkel.spanToLump[endSpanIndex];
+
+  if (slvCtx.hasFusedSolve()) {
+    slvCtx.solveLtRange(matData, startLump, upToLump, vecData, stride);
+    return;
+  }
+
+  const int64_t denseFrom =
+      std::max(startLump, sparseElimRanges.empty() ? int64_t(0) : sparseElimRanges.back());
+  const int64_t spansInRange = factorSkel.lumpToSpan[upToLump] - factorSkel.lumpToSpan[denseFrom];
+  if (spansInRange == upToLump - denseFrom && slvCtx.hasFragmentedOps() && nRHS == 1) {
+    slvCtx.fragmentedSolveLt(matData, denseFrom, upToLump, vecData);
+  } else {
+    for (int64_t l = upToLump - 1; l >= denseFrom; l--) {
+      ColumnGeom g = columnGeom(factorSkel, l);
+      const int64_t vecOff = factorSkel.lumpStart[l];
+      if (g.rowsBelow > 0) {
+        slvCtx.assembleVecT(vecData, stride, g.firstBelowChain, g.numBelowChains);
+        slvCtx.gemvT(matData, g.belowOffset, g.rowsBelow, g.width, vecData, vecOff, stride, -1.0);
+      }
+      slvCtx.solveLt(matData, g.diagOffset, g.width, vecData, vecOff, stride);
+    }
+  }
+
+  for (int64_t r = (int64_t)sparseElimRanges.size() - 2; r >= 0; r--) {
+    const int64_t rb = sparseElimRanges[r], re = sparseElimRanges[r + 1];
+    if (re > upToLump) {
+      BASPACHO_CHECK_LE(rb, upToLump);
+      continue;
+    }
+    if (rb < startLump) {
+      BASPACHO_CHECK_GE(startLump, re);
+      return;
+    }
+    slvCtx.sparseElimSolveLt(*elimCtxs[r], matData, rb, re, vecData, stride);
+  }
+}
+
+void Solver::printStats() const {
+  std::cout << "Matrix stats:\n  data size......: " << factorSkel.dataSize()
+            << "\n  solve temp data: " << maxElimTempSize << std::endl;
+  for (size_t r = 0; r + 1 < sparseElimRanges.size(); r++) {
+    std::cout << "  elim set [" << sparseElimRanges[r] << ".." << sparseElimRanges[r + 1]
+              << "]: " << elimCtxs[r]->elimStat.toString() << std::endl;
+  }
+  std::cout << "Factor timings and call stats:"
+            << "\n  largest node size: " << symCtx->potrfBiggestN
+            << "\n  potrf: " << symCtx->potrfStat.toString()
+            << "\n  trsm: " << symCtx->trsmStat.toString() << "\n  syrk/gemm("
+            << symCtx->syrkCalls << "+" << symCtx->gemmCalls
+            << "): " << symCtx->sygeStat.toString()
+            << "\n  asmbl: " << symCtx->asmblStat.toString() << std::endl;
+}
+
+void Solver::enableStats(bool enable) {
+  for (auto& e : elimCtxs) e->elimStat.enabled = enable;
+  symCtx->potrfStat.enabled = enable;
+  symCtx->trsmStat.enabled = enable;
+  symCtx->sygeStat.enabled = enable;
+  symCtx->asmblStat.enabled = enable;
+}
+
+void Solver::resetStats() {
+  for (auto& e : elimCtxs) e->elimStat.reset();
+  symCtx->potrfBiggestN = 0;
+  symCtx->potrfStat.reset();
+  symCtx->trsmStat.reset();
+  symCtx->syrkCalls = symCtx->gemmCalls = 0;
+  symCtx->sygeStat.reset();
+  symCtx->asmblStat.reset();
+}
+
+#define BSP_INSTANTIATE(T)                                                                     \
+  template void Solver::factor<T>(T*, bool) const;                                             \
+  template void Solver::factorUpTo<T>(T*, int64_t, bool) const;                                \
+  template void Solver::factorFrom<T>(T*, int64_t, bool) const;                                \
+  template void Solver::solve<T>(const T*, T*, int64_t, int) const;                            \
+  template void Solver::solveL<T>(const T*, T*, int64_t, int) const;                           \
+  template void Solver::solveLt<T>(const T*, T*, int64_t, int) const;                          \
+  template void Solver::solveLUpTo<T>(const T*, int64_t, T*, int64_t, int) const;              \
+  template void Solver::solveLtUpTo<T>(const T*, int64_t, T*, int64_t, int) const;             \
+  template void Solver::solveLFrom<T>(const T*, int64_t, T*, int64_t, int) const;              \
+  template void Solver::solveLtFrom<T>(const T*, int64_t, T*, int64_t, int) const;
+
+BSP_INSTANTIATE(double)
+BSP_INSTANTIATE(float)
+BSP_INSTANTIATE(std::vector<double*>)
+BSP_INSTANTIATE(std::vector<float*>)
+#undef BSP_INSTANTIATE
+
+static OpsPtr getBackend(const Settings& settings) {
+  if (settings.backend == BackendHip || settings.backend == BackendCuda) return hipOps();
+  throw std::runtime_error(
+      "baspacho_amd: only the MI355X HIP backend (BackendHip, alias BackendCuda) is part of "
+      "this build; the CPU restatement lives under oracle/ as test infrastructure");
+}
+
+SolverPtr createSolver(const Settings& settings, const vector<int64_t>& paramSize,
+                       const SparseStructure& ssIn, const vector<int64_t>& sparseElimRanges,
+                       const std::unordered_set<int64_t>& elimLastIds) {
+  BASPACHO_CHECK(settings.addFillPolicy == AddFillComplete || elimLastIds.empty());
+  BASPACHO_CHECK((int64_t)sparseElimRanges.size() != 1);
+  BASPACHO_CHECK_EQ((int64_t)paramSize.size(), ssIn.order());
+  const int64_t nParams = (int64_t)paramSize.size();
+  const int64_t givenElimEnd = sparseElimRanges.empty() ? 0 : sparseElimRanges.back();
+  if (!sparseElimRanges.empty()) {
+    BASPACHO_CHECK(isStrictlyIncreasing(sparseElimRanges, 0, sparseElimRanges.size()));
+    BASPACHO_CHECK_LE(givenElimEnd, nParams);
+    for (int64_t id : elimLastIds) BASPACHO_CHECK_GE(id, givenElimEnd);
+  }
+
+  // fill created by the user-given (un-reordered) elimination ranges
+  SparseStructure ss = ssIn;
+  if (settings.addFillPolicy != AddFillNone) {
+    for (size_t e = 0; e + 1 < sparseElimRanges.size(); e++) {
+      ss = ss.addIndependentEliminationFill(sparseElimRanges[e], sparseElimRanges[e + 1]);
+    }
+  }
+
+  if (settings.addFillPolicy == AddFillNone || settings.addFillPolicy == AddFillForGivenElims) {
+    // identity ordering, one lump per parameter
+    vector<int64_t> spanStart(paramSize.begin(), paramSize.end());
+    spanStart.push_back(0);
+    cumSumVec(spanStart);
+    vector<int64_t> lumpToSpan(nParams + 1), identity(nParams);
+    std::iota(lumpToSpan.begin(), lumpToSpan.end(), 0);
+    std::iota(identity.begin(), identity.end(), 0);
+    SparseStructure cols = ss.transpose();
+    CoalescedBlockMatrixSkel skel(spanStart, lumpToSpan, cols.ptrs, cols.inds);
+    vector<int64_t> ranges = sparseElimRanges;
+    return SolverPtr(new Solver(std::move(skel), std::move(ranges), std::move(identity),
+                                getBackend(settings),
+                                settings.addFillPolicy == AddFillNone ? 0 : givenElimEnd));
+  }
+
+  // fill-reducing ordering of what is left after the given eliminations
+  SparseStructure bottom = ss.extractRightBottom(givenElimEnd);
+  vector<int64_t> perm = bottom.fillReducingPermutation();
+  vector<int64_t> noCrossPoints;
+  if (!elimLastIds.empty()) {  // stable partition: "last" ids go to the end
+    vector<int64_t> head, tail;
+    for (int64_t p : perm) (elimLastIds.count(p + givenElimEnd) ? tail : head).push_back(p);
+    noCrossPoints.push_back((int64_t)head.size());
+    perm = head;
+    perm.insert(perm.end(), tail.begin(), tail.end());
+  }
+  vector<int64_t> invPerm = inversePermutation(perm);
+  SparseStructure sortedBottom = bottom.symmetricPermutation(invPerm, false);
+
+  const int64_t nBottom = nParams - givenElimEnd;
+  vector<int64_t> sortedBottomSize(nBottom);
+  for (int64_t i = 0; i < nBottom; i++) sortedBottomSize[invPerm[i]] = paramSize[givenElimEnd + i];
+
+  const ComputationModel* model =
+      settings.computationModel ? settings.computationModel : &ComputationModel::model_Hip_MI355X;
+
+  EliminationTree et(sortedBottomSize, sortedBottom, model);
+  et.buildTree();
+  et.processTree(settings.findSparseEliminationRanges, noCrossPoints,
+                 settings.addFillPolicy == AddFillForAutoElims);
+  et.computeAggregateStruct(settings.addFillPolicy == AddFillForAutoElims);
+
+  // total ordering: identity on the given-elimination prefix, (etree o AMD) on the rest
+  vector<int64_t> bottomInvPerm = composePermutations(et.permInverse, invPerm);
+  vector<int64_t> fullInvPerm(nParams);
+  std::iota(fullInvPerm.begin(), fullInvPerm.begin() + givenElimEnd, 0);
+  for (int64_t i = 0; i < nBottom; i++) fullInvPerm[givenElimEnd + i] = givenElimEnd + bottomInvPerm[i];
+
+  vector<int64_t> fullSpanStart(nParams + 1, 0);
+  leftPermute(fullSpanStart.begin(), fullInvPerm, paramSize);
+  cumSumVec(fullSpanStart);
+
+  vector<int64_t> fullLumpToSpan(givenElimEnd);
+  std::iota(fullLumpToSpan.begin(), fullLumpToSpan.end(), 0);
+  shiftConcat(fullLumpToSpan, givenElimEnd, et.lumpToSpan.begin(), et.lumpToSpan.end());
+  BASPACHO_CHECK_EQ((int64_t)fullSpanStart.size() - 1, fullLumpToSpan.back());
+
+  // the first columns (given eliminations) come from the un-merged permuted structure
+  SparseStructure sortedCols = ss.symmetricPermutation(fullInvPerm, false).transpose();
+  const int64_t prefixEntries = sortedCols.ptrs[givenElimEnd];
+  vector<int64_t> fullColStart(sortedCols.ptrs.begin(), sortedCols.ptrs.begin() + givenElimEnd);
+  shiftConcat(fullColStart, prefixEntries, et.colStart.begin(), et.colStart.end());
+  BASPACHO_CHECK_EQ(fullColStart.size(), fullLumpToSpan.size());
+  vector<int64_t> fullRowParam(sortedCols.inds.begin(), sortedCols.inds.begin() + prefixEntries);
+  shiftConcat(fullRowParam, givenElimEnd, et.rowParam.begin(), et.rowParam.end());
+  BASPACHO_CHECK_EQ((int64_t)fullRowParam.size(), fullColStart.back());
+
+  CoalescedBlockMatrixSkel skel(fullSpanStart, fullLumpToSpan, fullColStart, fullRowParam);
+
+  // given ranges followed by the automatically detected ones (shifted past the prefix)
+  vector<int64_t> fullRanges = sparseElimRanges;
+  if (!et.sparseElimRanges.empty()) {
+    shiftConcat(fullRanges, givenElimEnd,
+                et.sparseElimRanges.begin() + (sparseElimRanges.empty() ? 0 : 1),
+                et.sparseElimRanges.end());
+  }
+  if (fullRanges.size() == 1) fullRanges.clear();
+  const int64_t fullElimEnd = fullRanges.empty() ? 0 : fullRanges.back();
+
+  return SolverPtr(new Solver(std::move(skel), std::move(fullRanges), std::move(fullInvPerm),
+                              getBackend(settings),
+                              settings.addFillPolicy == AddFillForAutoElims ? fullElimEnd : nParams));
+}
+
+}  // namespace BaSpaCho

@@ -1,0 +1,178 @@
+/*
+ * baspacho_amd.h -- C ABI of the MI355X-native supernodal sparse Cholesky.
+ *
+ * Plain C boundary (pointers + sizes, no C++/torch types) that a foreign-function binding
+ * (ctypes, pybind, cgo, JNI ...) binds instead of the reference's C++ classes.  Each entry
+ * point names the reference interface it stands for (paths relative to
+ * /root/reference/baspacho/baspacho/).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; bsp_last_error() returns the
+ *     message of the last failure on the calling thread (reference: BASPACHO_CHECK_* throw
+ *     std::runtime_error, DebugMacros.h:17-50 / Utils.cpp:33-37);
+ *   - index arrays are int64_t as in the reference (CoalescedBlockMatrix.h:88-110);
+ *   - numeric data pointers are DEVICE pointers (Solver.h:184-188: GPU engines expect device
+ *     memory); the caller owns them; factor works in place;
+ *   - `stream` is a hipStream_t (NULL = default stream);
+ *   - one factor()/solve() at a time per solver (Solver is not re-entrant).
+ */
+#ifndef BASPACHO_AMD_H_
+#define BASPACHO_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bsp_solver bsp_solver;
+
+/* Solver.h:189-218  (BackendType, AddFillPolicy, Settings) */
+enum { BSP_BACKEND_REF = 0, BSP_BACKEND_FAST = 1, BSP_BACKEND_CUDA = 2, BSP_BACKEND_HIP = 3 };
+enum {
+  BSP_FILL_COMPLETE = 0,
+  BSP_FILL_FOR_AUTO_ELIMS = 1,
+  BSP_FILL_FOR_GIVEN_ELIMS = 2,
+  BSP_FILL_NONE = 3
+};
+
+typedef struct bsp_settings {
+  int32_t find_sparse_elimination_ranges; /* default 1 */
+  int32_t num_threads;                    /* ignored by the HIP engine */
+  int32_t backend;                        /* BSP_BACKEND_HIP (CUDA accepted as alias) */
+  int32_t add_fill_policy;                /* BSP_FILL_COMPLETE */
+  /* optional cost model of the supernode-merge heuristic (ComputationModel.h:56-109):
+     potrf[4], trsm[6], syge[6], asmbl[4]; NULL = built-in MI355X model */
+  const double* computation_model;
+} bsp_settings;
+
+const char* bsp_last_error(void);
+const char* bsp_version(void);
+
+/* createSolver(settings, paramSizes, SparseStructure{ptrs,inds}, sparseElimRanges, elimLastIds)
+   Solver.h:235-237, Solver.cpp:611-752.  ptrs/inds: block CSR of the LOWER triangle incl.
+   diagonal.  Symbolic analysis only: does not touch the GPU. */
+int bsp_create_solver(const bsp_settings* settings, int64_t num_params, const int64_t* param_sizes,
+                      const int64_t* ptrs, const int64_t* inds, int64_t num_elim_ranges,
+                      const int64_t* elim_ranges, int64_t num_elim_last, const int64_t* elim_last,
+                      bsp_solver** out);
+
+/* Solver::Solver(CoalescedBlockMatrixSkel&&, sparseElimRanges, permutation, ops)
+   Solver.h:37-38 -- solver from a RAW skeleton, as the reference's tests build it
+   (tests/FactorTest.cpp:43-65).  col_ptr/row_ind: per-lump sorted row spans (csc). */
+int bsp_create_solver_from_skeleton(int64_t num_spans, const int64_t* span_start,
+                                    int64_t num_lumps, const int64_t* lump_to_span,
+                                    const int64_t* col_ptr, const int64_t* row_ind,
+                                    int64_t num_elim_ranges, const int64_t* elim_ranges,
+                                    bsp_solver** out);
+
+void bsp_destroy_solver(bsp_solver* s);
+
+/* Solver::order / dataSize / canFactorUpToSpan, skel().numSpans()/numLumps()  Solver.h:111-131 */
+int64_t bsp_order(const bsp_solver* s);
+int64_t bsp_data_size(const bsp_solver* s);
+int64_t bsp_num_spans(const bsp_solver* s);
+int64_t bsp_num_lumps(const bsp_solver* s);
+int64_t bsp_can_factor_up_to_span(const bsp_solver* s);
+int64_t bsp_span_vector_offset(const bsp_solver* s, int64_t span);
+int64_t bsp_span_matrix_offset(const bsp_solver* s, int64_t span, int64_t* out);
+
+/* Skeleton arrays (CoalescedBlockMatrix.h:88-110); pointer stays valid while the solver lives */
+enum {
+  BSP_SKEL_SPAN_START = 0,
+  BSP_SKEL_SPAN_TO_LUMP = 1,
+  BSP_SKEL_LUMP_START = 2,
+  BSP_SKEL_LUMP_TO_SPAN = 3,
+  BSP_SKEL_SPAN_OFFSET_IN_LUMP = 4,
+  BSP_SKEL_CHAIN_COL_PTR = 5,
+  BSP_SKEL_CHAIN_ROW_SPAN = 6,
+  BSP_SKEL_CHAIN_DATA = 7,
+  BSP_SKEL_CHAIN_ROWS_TILL_END = 8,
+  BSP_SKEL_BOARD_COL_PTR = 9,
+  BSP_SKEL_BOARD_ROW_LUMP = 10,
+  BSP_SKEL_BOARD_CHAIN_COL_ORD = 11,
+  BSP_SKEL_BOARD_ROW_PTR = 12,
+  BSP_SKEL_BOARD_COL_LUMP = 13,
+  BSP_SKEL_BOARD_COL_ORD = 14,
+  BSP_SKEL_PARAM_TO_SPAN = 15,     /* Solver::paramToSpan()            Solver.h:136-137 */
+  BSP_SKEL_SPARSE_ELIM_RANGES = 16 /* Solver::sparseEliminationRanges  Solver.h:133-134 */
+};
+int bsp_skeleton_array(const bsp_solver* s, int which, const int64_t** data, int64_t* len);
+
+/* PermutedCoalescedAccessor::blockOffset / diagBlockOffset  Accessor.h:145-166
+   (param indices in USER order; flipped = stored block is the transpose).  Fails when the
+   block is not part of the factor structure. */
+int bsp_block_offset(const bsp_solver* s, int64_t row_param, int64_t col_param, int64_t* offset,
+                     int64_t* stride, int32_t* flipped);
+int bsp_diag_block_offset(const bsp_solver* s, int64_t param, int64_t* offset, int64_t* stride);
+
+/* Solver::deviceAccessor()  Solver.h:47-48 / MatOpsCuda.cu:85-92: the 8 device arrays
+   (spanStart, spanToLump, lumpStart, spanOffsetInLump, chainColPtr, chainRowSpan, chainData,
+   permutation), in that order, for use inside a caller's HIP kernel. */
+int bsp_device_accessor(bsp_solver* s, const int64_t* out_device_arrays[8]);
+
+void bsp_set_stream(bsp_solver* s, void* stream);
+
+/* Solver::factor<double|float>  Solver.h:60-61, Solver.cpp:149-151 */
+int bsp_factor_f64(bsp_solver* s, double* dev_data);
+int bsp_factor_f32(bsp_solver* s, float* dev_data);
+/* Solver::factor<std::vector<T*>>  (batched, identical structure)  Solver.cpp:459-460;
+   dev_ptrs is a HOST array of `batch` device pointers */
+int bsp_factor_batched_f64(bsp_solver* s, double* const* dev_ptrs, int32_t batch);
+int bsp_factor_batched_f32(bsp_solver* s, float* const* dev_ptrs, int32_t batch);
+/* Solver::factorUpTo / factorFrom  Solver.h:75-76, 96-97 */
+int bsp_factor_up_to_f64(bsp_solver* s, double* dev_data, int64_t span_index);
+int bsp_factor_from_f64(bsp_solver* s, double* dev_data, int64_t span_index);
+int bsp_factor_up_to_f32(bsp_solver* s, float* dev_data, int64_t span_index);
+int bsp_factor_from_f32(bsp_solver* s, float* dev_data, int64_t span_index);
+/* TESTING hook of the reference: numCtx->doElimination(solver.internalGetElimCtx(i), ...)
+   (Solver.h:139-145, tests/FactorTest.cpp:158-160) */
+int bsp_do_elimination_f64(bsp_solver* s, double* dev_data, int64_t elim_range_index);
+int bsp_do_elimination_f32(bsp_solver* s, float* dev_data, int64_t elim_range_index);
+
+/* Solver::solve / solveL / solveLt  Solver.h:64-73 (vectors in internal order, column-major
+   order x nRHS with leading dimension `stride`) */
+int bsp_solve_f64(bsp_solver* s, const double* dev_mat, double* dev_vec, int64_t stride,
+                  int32_t nrhs);
+int bsp_solve_l_f64(bsp_solver* s, const double* dev_mat, double* dev_vec, int64_t stride,
+                    int32_t nrhs);
+int bsp_solve_lt_f64(bsp_solver* s, const double* dev_mat, double* dev_vec, int64_t stride,
+                     int32_t nrhs);
+int bsp_solve_f32(bsp_solver* s, const float* dev_mat, float* dev_vec, int64_t stride,
+                  int32_t nrhs);
+int bsp_solve_l_f32(bsp_solver* s, const float* dev_mat, float* dev_vec, int64_t stride,
+                    int32_t nrhs);
+int bsp_solve_lt_f32(bsp_solver* s, const float* dev_mat, float* dev_vec, int64_t stride,
+                     int32_t nrhs);
+
+/* ---- measurement helpers (no reference counterpart; Solver::printStats is the analogue) */
+/* algorithmic flops of a full factor: sum over lumps n^3/3 + r n^2 + r^2 n */
+double bsp_factor_flops(const bsp_solver* s);
+
+typedef struct bsp_plan_stats {
+  double flops, upd_elems;
+  int64_t num_launches, num_levels, num_panels, num_segs, num_upd_tasks, num_trsm_tasks,
+      chain_tab_entries, max_panels_in_level, num_atomic_upd_tasks;
+} bsp_plan_stats;
+int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out);
+
+/* kernel classes timed by bsp_factor_profiled_* (HIP events on the execution stream) */
+enum {
+  BSP_PROF_ELIM_FACTOR = 0,
+  BSP_PROF_ELIM_UPDATE = 1,
+  BSP_PROF_POTRF = 2,
+  BSP_PROF_TRSM = 3,
+  BSP_PROF_UPDATE = 4,
+  BSP_PROF_NUM_KINDS = 5
+};
+int bsp_factor_profiled_f64(bsp_solver* s, double* dev_data, double ms[5], int64_t launches[5]);
+
+/* Symbolic plan as one flat int64 buffer, so that rank 0 can analyse once and broadcast it
+   (RCCL) to the ranks that factor the other matrices of a batch. */
+int bsp_plan_serialize(const bsp_solver* s, int64_t* buf, int64_t capacity, int64_t* needed);
+int bsp_create_solver_from_plan(const int64_t* buf, int64_t len, bsp_solver** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BASPACHO_AMD_H_ */
