@@ -71,6 +71,55 @@ class SparseStructure:
     def order(self):
         return len(self.ptrs) - 1
 
+    # SparseStructure.h:34-55 (executed by the C++ host library)
+    def transpose(self):
+        return _ss_op(self, SS_TRANSPOSE)
+
+    def clear(self, clearLower=True):
+        return _ss_op(self, SS_CLEAR, flag=int(clearLower))
+
+    def symmetricPermutation(self, mapPerm, lowerHalf=True):
+        return _ss_op(self, SS_SYM_PERMUTATION, mapPerm, int(lowerHalf))
+
+    def addIndependentEliminationFill(self, start, end):
+        return _ss_op(self, SS_INDEP_ELIM_FILL, [start, end])
+
+    def addFullEliminationFill(self):
+        return _ss_op(self, SS_FULL_ELIM_FILL)
+
+    def fillReducingPermutation(self):
+        return _ss_op(self, SS_FILL_REDUCING_PERM)
+
+    def extractRightBottom(self, start):
+        return _ss_op(self, SS_EXTRACT_RIGHT_BOTTOM, [start])
+
+
+SS_TRANSPOSE, SS_CLEAR, SS_SYM_PERMUTATION, SS_INDEP_ELIM_FILL, SS_FULL_ELIM_FILL, \
+    SS_FILL_REDUCING_PERM, SS_EXTRACT_RIGHT_BOTTOM = range(7)
+
+
+def _ss_op(ss, op, arg=(), flag=0):
+    lib = _lib.load()
+    n = ss.order()
+    a = _i64(arg)
+    cap = max(16, 4 * len(ss.inds) + n)
+    while True:
+        out_ptrs = np.zeros(n + 2, dtype=np.int64)
+        out_inds = np.zeros(cap, dtype=np.int64)
+        on, onnz = ctypes.c_int64(0), ctypes.c_int64(0)
+        rc = lib.bsp_sparse_structure_op(
+            op, ctypes.c_int64(n), ss.ptrs.ctypes.data_as(_I64P), ss.inds.ctypes.data_as(_I64P),
+            a.ctypes.data_as(_I64P), ctypes.c_int64(len(a)), ctypes.c_int32(flag),
+            out_ptrs.ctypes.data_as(_I64P), out_inds.ctypes.data_as(_I64P), ctypes.c_int64(cap),
+            ctypes.byref(on), ctypes.byref(onnz))
+        if rc != 0 and onnz.value > cap:
+            cap = onnz.value
+            continue
+        _check(rc)
+        if op == SS_FILL_REDUCING_PERM:
+            return out_inds[:onnz.value].copy()
+        return SparseStructure(out_ptrs[:on.value + 1].copy(), out_inds[:onnz.value].copy())
+
 
 def _check(rc):
     if rc != 0:

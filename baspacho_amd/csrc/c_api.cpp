@@ -363,3 +363,45 @@ int bsp_create_solver_from_plan(const int64_t* buf, int64_t len, bsp_solver** ou
   *out = h.release();
   BSP_CATCH
 }
+
+int bsp_sparse_structure_op(int op, int64_t n, const int64_t* ptrs, const int64_t* inds,
+                            const int64_t* arg, int64_t argLen, int32_t flag, int64_t* outPtrs,
+                            int64_t* outInds, int64_t capacity, int64_t* outN, int64_t* outNnz) {
+  BSP_TRY
+  SparseStructure ss(std::vector<int64_t>(ptrs, ptrs + n + 1),
+                     std::vector<int64_t>(inds, inds + ptrs[n]));
+  SparseStructure res;
+  switch (op) {
+    case BSP_SS_TRANSPOSE: res = ss.transpose(); break;
+    case BSP_SS_CLEAR: res = ss.clear(flag != 0); break;
+    case BSP_SS_SYM_PERMUTATION: {
+      BASPACHO_CHECK_EQ(argLen, n);
+      res = ss.symmetricPermutation(std::vector<int64_t>(arg, arg + n), flag != 0);
+      break;
+    }
+    case BSP_SS_INDEP_ELIM_FILL:
+      BASPACHO_CHECK_EQ(argLen, 2);
+      res = ss.addIndependentEliminationFill(arg[0], arg[1]);
+      break;
+    case BSP_SS_FULL_ELIM_FILL: res = ss.addFullEliminationFill(); break;
+    case BSP_SS_FILL_REDUCING_PERM: {
+      std::vector<int64_t> perm = ss.fillReducingPermutation();
+      *outN = n;
+      *outNnz = (int64_t)perm.size();
+      if (capacity < (int64_t)perm.size()) throw std::runtime_error("output capacity too small");
+      std::copy(perm.begin(), perm.end(), outInds);
+      return 0;
+    }
+    case BSP_SS_EXTRACT_RIGHT_BOTTOM:
+      BASPACHO_CHECK_EQ(argLen, 1);
+      res = ss.extractRightBottom(arg[0]);
+      break;
+    default: throw std::runtime_error("bsp_sparse_structure_op: unknown op");
+  }
+  *outN = res.order();
+  *outNnz = (int64_t)res.inds.size();
+  if (capacity < (int64_t)res.inds.size()) throw std::runtime_error("output capacity too small");
+  std::copy(res.ptrs.begin(), res.ptrs.end(), outPtrs);
+  std::copy(res.inds.begin(), res.inds.end(), outInds);
+  BSP_CATCH
+}

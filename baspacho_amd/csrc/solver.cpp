@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <iostream>
 #include <numeric>
+#include <chrono>
+#include <cstdlib>
 
 #include "computation_model.h"
 #include "elimination_tree.h"
@@ -463,9 +465,21 @@ SolverPtr createSolver(const Settings& settings, const vector<int64_t>& paramSiz
                                 settings.addFillPolicy == AddFillNone ? 0 : givenElimEnd));
   }
 
+  const bool timing = std::getenv("BSP_TIMING") != nullptr;
+  auto tic = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    std::cerr << "[createSolver] " << what << ": "
+              << std::chrono::duration<double>(now - tic).count() << " s" << std::endl;
+    tic = now;
+  };
+
   // fill-reducing ordering of what is left after the given eliminations
   SparseStructure bottom = ss.extractRightBottom(givenElimEnd);
+  lap("elim fill + extract");
   vector<int64_t> perm = bottom.fillReducingPermutation();
+  lap("min-degree ordering");
   vector<int64_t> noCrossPoints;
   if (!elimLastIds.empty()) {  // stable partition: "last" ids go to the end
     vector<int64_t> head, tail;
@@ -486,9 +500,12 @@ SolverPtr createSolver(const Settings& settings, const vector<int64_t>& paramSiz
 
   EliminationTree et(sortedBottomSize, sortedBottom, model);
   et.buildTree();
+  lap("etree build");
   et.processTree(settings.findSparseEliminationRanges, noCrossPoints,
                  settings.addFillPolicy == AddFillForAutoElims);
+  lap("etree process (ranges + merges)");
   et.computeAggregateStruct(settings.addFillPolicy == AddFillForAutoElims);
+  lap("aggregate structure");
 
   // total ordering: identity on the given-elimination prefix, (etree o AMD) on the rest
   vector<int64_t> bottomInvPerm = composePermutations(et.permInverse, invPerm);
@@ -516,6 +533,7 @@ SolverPtr createSolver(const Settings& settings, const vector<int64_t>& paramSiz
   BASPACHO_CHECK_EQ((int64_t)fullRowParam.size(), fullColStart.back());
 
   CoalescedBlockMatrixSkel skel(fullSpanStart, fullLumpToSpan, fullColStart, fullRowParam);
+  lap("skeleton");
 
   // given ranges followed by the automatically detected ones (shifted past the prefix)
   vector<int64_t> fullRanges = sparseElimRanges;

@@ -172,6 +172,30 @@ int bsp_factor_profiled_f64(bsp_solver* s, double* dev_data, double ms[5], int64
 int bsp_plan_serialize(const bsp_solver* s, int64_t* buf, int64_t capacity, int64_t* needed);
 int bsp_create_solver_from_plan(const int64_t* buf, int64_t len, bsp_solver** out);
 
+/* Host-side block-pattern operations of the symbolic phase (SparseStructure.h:34-55), exposed
+   for bindings and tests.  `arg`/`flag` per op:
+     TRANSPOSE            -                                  SparseStructure::transpose
+     CLEAR                flag = clearLower                  SparseStructure::clear
+     SYM_PERMUTATION      arg = mapPerm[n], flag = lowerHalf SparseStructure::symmetricPermutation
+     INDEP_ELIM_FILL      arg = {start, end}                 addIndependentEliminationFill
+     FULL_ELIM_FILL       -                                  addFullEliminationFill
+     FILL_REDUCING_PERM   -  (out_inds = perm[n], out_ptrs untouched)  fillReducingPermutation
+     EXTRACT_RIGHT_BOTTOM arg = {start}                      extractRightBottom
+   out_ptrs needs n+1 entries; the call fails if out_inds (capacity entries) is too small,
+   reporting the needed size in *out_nnz. */
+enum {
+  BSP_SS_TRANSPOSE = 0,
+  BSP_SS_CLEAR = 1,
+  BSP_SS_SYM_PERMUTATION = 2,
+  BSP_SS_INDEP_ELIM_FILL = 3,
+  BSP_SS_FULL_ELIM_FILL = 4,
+  BSP_SS_FILL_REDUCING_PERM = 5,
+  BSP_SS_EXTRACT_RIGHT_BOTTOM = 6
+};
+int bsp_sparse_structure_op(int op, int64_t n, const int64_t* ptrs, const int64_t* inds,
+                            const int64_t* arg, int64_t arg_len, int32_t flag, int64_t* out_ptrs,
+                            int64_t* out_inds, int64_t capacity, int64_t* out_n, int64_t* out_nnz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,124 @@
+"""CPU: the C-ABI library loads, exports every symbol declared in include/baspacho_amd.h, and its
+host-only entry points (symbolic analysis, accessors, plan serialisation) behave."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import baspacho_amd as B
+from baspacho_amd import _lib
+from baspacho_amd import testing as T
+from helpers import solver_random
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported():
+    hdr = open(os.path.join(ROOT, "include", "baspacho_amd.h")).read()
+    names = set(re.findall(r"\b(bsp_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) > 30
+    lib = _lib.load()
+    for n in sorted(names):
+        assert hasattr(lib, n), n
+    assert b"gfx950" in lib.bsp_version()
+
+
+def test_cpu_backends_are_refused():
+    sol, ps, ss = solver_random(57)
+    for backend in (B.BackendRef, B.BackendFast):
+        with pytest.raises(RuntimeError, match="oracle"):
+            B.create_solver(B.Settings(backend=backend), ps, ss)
+    B.create_solver(B.Settings(backend=B.BackendCuda), ps, ss)  # alias of the HIP engine
+
+
+def test_accessor_matches_skeleton():
+    """AccessorTest: blockOffset/diagBlockOffset through the permutation, incl. flipped blocks"""
+    sol, ps, ss = solver_random(63)
+    sk = sol.skel()
+    p2s = sol.paramToSpan()
+    data = np.arange(sol.dataSize(), dtype=np.float64)
+    dense = sol.densify(data, fill_upper_half=False)
+    n = len(ps)
+    checked = 0
+    for r in range(n):
+        for k in range(int(ss.ptrs[r]), int(ss.ptrs[r + 1])):
+            c = int(ss.inds[k])
+            off, stride, flipped = sol.blockOffset(r, c)
+            sr, sc = int(p2s[r]), int(p2s[c])
+            assert flipped == (sr < sc)
+            lo, hi = min(sr, sc), max(sr, sc)
+            assert data[off] == dense[int(sk["spanStart"][hi]), int(sk["spanStart"][lo])]
+            assert stride == sk["lumpStart"][sk["spanToLump"][lo] + 1] - \
+                sk["lumpStart"][sk["spanToLump"][lo]]
+            checked += 1
+        off, stride = sol.diagBlockOffset(r)
+        s = int(p2s[r])
+        assert data[off] == dense[int(sk["spanStart"][s]), int(sk["spanStart"][s])]
+        assert sol.order() == int(ps.sum())
+    assert checked > n
+    with pytest.raises(RuntimeError):
+        sol.blockOffset(n + 5, 0)
+
+
+def test_permutation_and_fill_properties():
+    """EliminationTreeTest / CreateSolverTest properties: the factor skeleton contains the
+    permuted original pattern; lumps partition the spans; sizes are permuted consistently"""
+    for seed in range(8):
+        sol, ps, ss = solver_random(70 + seed, model="openblas" if seed % 2 else "hip")
+        p2s = sol.paramToSpan()
+        assert sorted(p2s.tolist()) == list(range(len(ps)))
+        sk = sol.skel()
+        sizes = np.diff(sk["spanStart"])
+        assert np.array_equal(sizes[p2s], ps)
+        for r in range(len(ps)):
+            for k in range(int(ss.ptrs[r]), int(ss.ptrs[r + 1])):
+                sol.blockOffset(r, int(ss.inds[k]))  # raises if the block is missing
+        # elimination ranges are made of single-span lumps
+        for l in range(int(sol.sparseEliminationRanges()[-1]) if len(sol.sparseEliminationRanges()) else 0):
+            assert sk["lumpToSpan"][l + 1] - sk["lumpToSpan"][l] == 1
+
+
+def test_plan_serialisation_roundtrip():
+    sol, _, _ = solver_random(57, fill=0.03, elim=(0, 60))
+    buf = sol.serialize_plan()
+    clone = B.Solver.from_plan(buf)
+    a, b = sol.skel(), clone.skel()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(sol.paramToSpan(), clone.paramToSpan())
+    assert np.array_equal(sol.sparseEliminationRanges(), clone.sparseEliminationRanges())
+    assert clone.canFactorUpToSpan() == sol.canFactorUpToSpan()
+    assert clone.planStats() == sol.planStats()
+    with pytest.raises(RuntimeError):
+        B.Solver.from_plan(buf[:-3])
+
+
+def test_flops_formula_and_plan_stats():
+    sol, _, _ = solver_random(58)
+    sk = sol.skel()
+    flops = 0.0
+    for l in range(sol.numLumps()):
+        n = float(sk["lumpStart"][l + 1] - sk["lumpStart"][l])
+        c0, c1 = int(sk["chainColPtr"][l]), int(sk["chainColPtr"][l + 1])
+        r = float(sk["chainRowsTillEnd"][c1 - 1]) - n
+        flops += n ** 3 / 3 + r * n * n + r * r * n
+    assert abs(sol.factorFlops() - flops) <= 1e-9 * flops
+    st = sol.planStats()
+    assert abs(st["flops"] - flops) <= 1e-9 * flops
+    assert st["num_panels"] >= sol.numLumps() - (int(sol.sparseEliminationRanges()[-1]) if len(
+        sol.sparseEliminationRanges()) else 0)
+
+
+def test_block_tridiagonal_config_c1():
+    """BASELINE config 0: 3334 x (3x3) block tridiagonal, symbolic analysis + oracle factor"""
+    from oracle import cref
+    ss = T.block_tridiagonal(3334)
+    sol = B.create_solver(B.Settings(), np.full(3334, 3), ss)
+    assert sol.order() == 10002
+    data = T.random_data(sol.dataSize(), -1, 1, 37)
+    sol.damp(data, 0.0, sol.order() * 1.2)
+    A = sol.densify(data, fill_upper_half=True)
+    cref.factor(sol.skel(), data, sol.sparseEliminationRanges())
+    L = np.tril(sol.densify(data))
+    assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) < 1e-12

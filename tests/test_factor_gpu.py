@@ -1,0 +1,233 @@
+"""GPU parity tests of the HIP factor path, through the C ABI, against the CPU oracle and the
+dense Cholesky (numpy).  Mirrors the reference's FactorTest / CudaFactorTest /
+BatchedCudaFactorTest / CreateSolverTest protocols and tolerances:
+   fp64: 1e-10 (fixed tiny case), 1e-8 (random families);  fp32: 1e-5 / 5e-5
+   (tests/FactorTest.cpp:32-41).  Errors are Frobenius norms of the lower triangle."""
+import numpy as np
+import pytest
+
+import baspacho_amd as B
+from baspacho_amd import testing as T
+from oracle import cref
+from oracle import skel as OS
+from helpers import solver_random, spd_data, dense_lower_chol, lower_of, to_dev
+
+pytestmark = pytest.mark.gpu
+
+EPS = {np.float64: (1e-10, 1e-8), np.float32: (1e-5, 5e-5)}
+
+
+def _gpu_factor(sol, data):
+    d = to_dev(data)
+    sol.factor(d)
+    return d.cpu().numpy()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tiny_coalesced_factor(golden, dtype):
+    """FactorTest.CoalescedFactor / CudaFactor.CoalescedFactor (tests/FactorTest.cpp:43-65)"""
+    g = golden["tiny_factor"]
+    a = g["answer"]
+    sol = B.Solver.from_skeleton(g["spanStart"], g["lumpToSpan"], a["groupedPtrs"],
+                                 a["groupedInds"])
+    data = np.arange(13, 13 + sol.dataSize(), dtype=np.float64)
+    sol.damp(data, float(g["damp_alpha"]), float(g["damp_beta"]))
+    got = _gpu_factor(sol, data.astype(dtype))
+    err = np.linalg.norm(lower_of(sol, got) - np.array(a["L_lower"]))
+    assert err < EPS[dtype][0] * (1 if dtype == np.float64 else 20), err
+
+
+@pytest.mark.parametrize("model", ["openblas", "hip"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_coalesced_factor_many(dtype, model):
+    """FactorTest.CoalescedFactor_Many (tests/FactorTest.cpp:75-107): 20 random patterns"""
+    for i in range(20):
+        sol, _, _ = solver_random(57 + i, model=model, find_ranges=False)
+        data = spd_data(sol, 9 + i, dtype=dtype)
+        L, _ = dense_lower_chol(sol, data)
+        got = _gpu_factor(sol, data)
+        err = np.linalg.norm(lower_of(sol, got) - L)
+        assert err < EPS[dtype][1], (i, err)
+        # and against the oracle, element by element on the same skeleton
+        ref = data.copy()
+        cref.factor(sol.skel(), ref, sol.sparseEliminationRanges())
+        assert np.linalg.norm(lower_of(sol, got) - lower_of(sol, ref)) < EPS[dtype][1]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sparse_elim_many(dtype):
+    """FactorTest.SparseElim_Many (tests/FactorTest.cpp:129-167): doElimination alone, compare
+    the eliminated columns only"""
+    for i in range(20):
+        sol, _, _ = solver_random(57 + i, fill=0.03, elim=(0, 60))
+        ranges = sol.sparseEliminationRanges()
+        assert len(ranges) >= 2
+        data = spd_data(sol, 9 + i, dtype=dtype)
+        L, _ = dense_lower_chol(sol, data)
+        d = to_dev(data)
+        sol.doElimination(d, 0)
+        got = d.cpu().numpy()
+        ncol = int(sol.skel()["lumpStart"][ranges[1]])
+        err = np.linalg.norm((lower_of(sol, got) - L)[:, :ncol])
+        assert err < EPS[dtype][0] * (1 if dtype == np.float64 else 5), (i, err)
+        # the Schur-complement part must match the oracle's doElimination too
+        ref = data.copy()
+        cref.do_elimination(sol.skel(), ref, int(ranges[0]), int(ranges[1]))
+        assert np.linalg.norm(lower_of(sol, got) - lower_of(sol, ref)) < EPS[dtype][1]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sparse_elim_and_factor_many(dtype):
+    """FactorTest.SparseElimAndFactor_Many (tests/FactorTest.cpp:185-219)"""
+    for i in range(20):
+        sol, _, _ = solver_random(57 + i, fill=0.03, elim=(0, 60))
+        assert len(sol.sparseEliminationRanges()) >= 2
+        data = spd_data(sol, 9 + i, dtype=dtype)
+        L, _ = dense_lower_chol(sol, data)
+        got = _gpu_factor(sol, data)
+        err = np.linalg.norm(lower_of(sol, got) - L)
+        assert err < EPS[dtype][1], (i, err)
+
+
+def test_given_elim_ranges_and_wide_elim_lumps():
+    """user-given elimination range whose lumps are wider than the small-kernel limit (16):
+    they must go through the panel kernels inside doElimination"""
+    size = 60
+    cols = T.make_independent_elim_set(T.random_cols(size, 0.08, 91), 0, 25)
+    ss = T.columns_to_structure(cols)
+    ps = np.where(np.arange(size) % 5 == 0, 23, 4).astype(np.int64)  # some 23-wide params
+    sol = B.create_solver(B.Settings(), ps, ss, [0, 25])
+    assert sol.sparseEliminationRanges().tolist()[:2] == [0, 25]
+    data = spd_data(sol, 5)
+    L, _ = dense_lower_chol(sol, data)
+    got = _gpu_factor(sol, data)
+    assert np.linalg.norm(lower_of(sol, got) - L) < 1e-8
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_batched_factor(dtype):
+    """BatchedCudaFactorTest (tests/BatchedCudaFactorTest.cpp:44-158): several matrices of one
+    structure in one call; every matrix must match its own dense Cholesky"""
+    batch_sizes = T.random_vec(6, 3, 31, 37)
+    for i, bs in enumerate(batch_sizes):
+        sol, _, _ = solver_random(57 + i, fill=0.03, elim=(0, 60) if i % 2 else None)
+        datas = [spd_data(sol, 100 * i + q, dtype=dtype) for q in range(int(bs))]
+        devs = [to_dev(d) for d in datas]
+        sol.factor(devs)
+        for q in range(int(bs)):
+            L, _ = dense_lower_chol(sol, datas[q])
+            err = np.linalg.norm(lower_of(sol, devs[q].cpu().numpy()) - L)
+            assert err < EPS[dtype][1], (i, q, err)
+
+
+@pytest.mark.parametrize("elim_set,last_ids", [(False, False), (True, False), (False, True),
+                                               (True, True)])
+def test_create_solver_policies(elim_set, last_ids):
+    """CreateSolverTest (tests/CreateSolverTest.cpp:43-140): fill policies x given elimination
+    ranges x elimLastIds; a partial factor leaves the Schur complement in the bottom-right"""
+    for i in range(5):
+        n_params = 215
+        cols = T.random_cols(n_params, 0.03, 57 + i)
+        ranges = []
+        if elim_set:
+            cols = T.make_independent_elim_set(cols, 0, 150)
+            ranges = [0, 90]
+        else:
+            cols = T.make_independent_elim_set(cols, 0, 60)
+        last = set()
+        if last_ids:
+            last = {105, 123, 165, 194, 209, 214}
+            if not elim_set:
+                last |= {0, 30, 49, 87}
+        ss = T.columns_to_structure(cols)
+        ps = T.random_vec(n_params, 2, 3, 47)
+        policies = [B.AddFillComplete]
+        if not last_ids:
+            policies += [B.AddFillForAutoElims, B.AddFillForGivenElims, B.AddFillNone]
+        for pol in policies:
+            sol = B.create_solver(B.Settings(addFillPolicy=pol), ps, ss, ranges, last)
+            up_to = sol.canFactorUpToSpan()
+            if pol == B.AddFillComplete:
+                assert up_to == n_params
+            if pol == B.AddFillNone:
+                assert up_to == 0
+            if pol == B.AddFillForGivenElims and elim_set:
+                assert up_to == 90
+            data = spd_data(sol, 9 + 4 * i, beta_factor=2.0)
+            L, A = dense_lower_chol(sol, data)
+            bar = int(sol.skel()["spanStart"][up_to])
+            want = np.tril(L.copy())
+            # bottom-right = Schur complement of the un-factored part
+            want[bar:, bar:] = np.tril(A[bar:, bar:] - L[bar:, :bar] @ L[bar:, :bar].T)
+            d = to_dev(data)
+            sol.factorUpTo(d, up_to)
+            got = lower_of(sol, d.cpu().numpy())
+            assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-9, (i, pol)
+            if last:
+                s = len(last)
+                assert sol.skel()["spanOffsetInLump"][sol.numSpans() - s] == 0
+                p2s = sol.paramToSpan()
+                assert all(p2s[e] >= sol.numSpans() - s for e in last)
+
+
+def test_factor_up_to_then_from():
+    """PartialFactorSolveTest: factorUpTo(k) followed by factorFrom(k) == factor"""
+    sol, _, _ = solver_random(61, fill=0.03, elim=(0, 60))
+    data = spd_data(sol, 3)
+    L, _ = dense_lower_chol(sol, data)
+    ranges = sol.sparseEliminationRanges()
+    sk = sol.skel()
+    dense_from = int(ranges[-1]) if len(ranges) else 0
+    mid_lump = (dense_from + sol.numLumps()) // 2
+    mid_span = int(sk["lumpToSpan"][mid_lump])
+    d = to_dev(data)
+    sol.factorUpTo(d, mid_span)
+    sol.factorFrom(d, mid_span)
+    assert np.linalg.norm(lower_of(sol, d.cpu().numpy()) - L) < 1e-8
+
+
+def test_bal_like_and_grid_against_oracle():
+    """larger structured cases (sizes the oracle finishes in seconds): a bundle-adjustment shaped
+    problem with a given point-elimination range, and a grid; compared with the oracle on the
+    same skeleton via the relative residual of the factors"""
+    sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=60, num_pts=6000, band=8, seed=5)
+    sol = B.create_solver(B.Settings(), sizes, ss, [0, 6000])
+    data = spd_data(sol, 11, beta_factor=1.2)
+    ref = data.copy()
+    cref.factor(sol.skel(), ref, sol.sparseEliminationRanges())
+    got = _gpu_factor(sol, data)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-12
+
+    ss = T.gen_grid(24, 24, 1.0, 2, 37)
+    sol = B.create_solver(B.Settings(), np.full(24 * 24, 3), ss)
+    data = spd_data(sol, 12, beta_factor=1.2)
+    L, A = dense_lower_chol(sol, data)
+    got = _gpu_factor(sol, data)
+    Lg = lower_of(sol, got)
+    assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < 1e-10
+    assert np.linalg.norm(Lg - L) < 1e-8
+
+
+def test_wide_dense_lump_residual():
+    """one wide supernode (multi-panel, intra-lump trailing updates): north-star residual
+    ||L L^T - A|| / ||A|| < 1e-10 in fp64"""
+    n = 700
+    cols = [set(range(i, n)) for i in range(n)]
+    ss = T.columns_to_structure(cols)
+    sol = B.create_solver(B.Settings(), np.ones(n, dtype=np.int64), ss)
+    data = spd_data(sol, 21, beta_factor=1.2)
+    _, A = dense_lower_chol(sol, data)
+    Lg = lower_of(sol, _gpu_factor(sol, data))
+    assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < 1e-10
+
+
+def test_errors_are_loud():
+    """wrong-size data and CPU backends must fail with an exception, not fall back"""
+    sol, ps, ss = solver_random(57)
+    import torch
+    with pytest.raises(ValueError):
+        sol.factor(torch.zeros(3, dtype=torch.float64, device="cuda"))
+    with pytest.raises(ValueError):
+        sol.factor(torch.zeros(sol.dataSize(), dtype=torch.float64))  # host memory
+    with pytest.raises(RuntimeError):
+        B.create_solver(B.Settings(backend=B.BackendFast), ps, ss)
