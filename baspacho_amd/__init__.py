@@ -357,6 +357,23 @@ class Solver:
             dense = np.tril(dense) + np.tril(dense, -1).T
         return dense
 
+    def lowerMask(self):
+        """boolean mask over the numeric data: False on the strictly-upper entries of the square
+        diagonal blocks (stored but meaningless, CoalescedBlockMatrix.h:23-37), True elsewhere"""
+        sk = self.skel()
+        ls = sk["lumpStart"]
+        w = (ls[1:] - ls[:-1]).astype(np.int64)
+        d0 = sk["chainData"][sk["chainColPtr"][:-1]]
+        mask = np.ones(self.dataSize(), dtype=bool)
+        for width in np.unique(w):
+            if width < 2:
+                continue
+            i, j = np.triu_indices(int(width), 1)
+            upper = (i * width + j).astype(np.int64)
+            starts = d0[w == width]
+            mask[(starts[:, None] + upper[None, :]).ravel()] = False
+        return mask
+
     def damp(self, data, alpha, beta):
         """diagonal <- diagonal * (1 + alpha) + beta, in place on a host numpy array"""
         sk = self.skel()

@@ -149,7 +149,7 @@ def test_oracle_random_factor_and_solve(seed):
 @pytest.mark.parametrize("seed", range(4))
 def test_oracle_sparse_elim(seed):
     """FactorTest.SparseElim_Many / SparseElimAndFactor_Many on the oracle"""
-    sol, _, _ = solver_random(57 + seed, fill=0.03, elim=(0, 60))
+    sol, _, _ = solver_random(57 + seed, fill=0.03, elim=(0, 60), ranges=[0, 60])
     ranges = sol.sparseEliminationRanges()
     assert len(ranges) >= 2
     sk = sol.skel()
