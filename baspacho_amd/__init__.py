@@ -41,7 +41,9 @@ class _CSettings(ctypes.Structure):
 
 
 class _CPlanStats(ctypes.Structure):
-    _fields_ = [("flops", ctypes.c_double), ("upd_elems", ctypes.c_double)] + \
+    _fields_ = [(n, ctypes.c_double) for n in
+                ["flops", "upd_elems", "upd_flops", "elim_pair_elems", "elim_pair_flops",
+                 "elim_col_elems"]] + \
                [(n, ctypes.c_int64) for n in
                 ["num_launches", "num_levels", "num_panels", "num_segs", "num_upd_tasks",
                  "num_trsm_tasks", "chain_tab_entries", "max_panels_in_level",

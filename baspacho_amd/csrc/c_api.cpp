@@ -273,6 +273,10 @@ int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out) {
                                        s->solver->skel().numLumps());
   out->flops = p.flops;
   out->upd_elems = p.updElems;
+  out->upd_flops = p.updFlops;
+  out->elim_pair_elems = p.elimPairElems;
+  out->elim_pair_flops = p.elimPairFlops;
+  out->elim_col_elems = p.elimColElems;
   out->num_launches = p.numLaunches;
   out->num_levels = p.numLevels;
   out->num_panels = p.numPanels;

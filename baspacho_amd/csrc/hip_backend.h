@@ -23,7 +23,8 @@ struct HipKernelProfile {
 };
 
 struct HipPlanStats {
-  double flops = 0, updElems = 0;
+  double flops = 0, updElems = 0, updFlops = 0, elimPairElems = 0, elimPairFlops = 0,
+         elimColElems = 0;
   int64_t numLaunches = 0, numLevels = 0, numPanels = 0, numSegs = 0, numUpdTasks = 0,
           numTrsmTasks = 0, chainTabEntries = 0, maxPanelsInLevel = 0, numAtomicUpdTasks = 0;
 };

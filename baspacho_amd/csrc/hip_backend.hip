@@ -383,6 +383,10 @@ HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t up
   HipPlanStats s;
   s.flops = p.flops;
   s.updElems = p.updElems;
+  s.updFlops = p.updFlops;
+  s.elimPairElems = p.elimPairElems;
+  s.elimPairFlops = p.elimPairFlops;
+  s.elimColElems = p.elimColElems;
   s.numLaunches = p.numLaunches;
   s.numLevels = (int64_t)p.levels.size();
   s.numPanels = (int64_t)p.panels.size();

@@ -107,6 +107,20 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       LumpCols g = lumpCols(sk, l);
       er.maxWidth = std::max<int32_t>(er.maxWidth, (int32_t)g.width);
       for (int64_t c = 0; c < g.nChains; c++) plan.elimChainLump.push_back((int32_t)l);
+      {
+        // pair updates of this column: for chains i<=j below the diagonal, |sj| x |si| elements
+        // (lower triangle only when i==j)
+        double rowsAfter = 0, pairElems = 0;
+        for (int64_t c = g.chain0 + g.nChains - 1; c >= g.chain0 + g.diagChains; c--) {
+          const int64_t span = sk.chainRowSpan[c];
+          const double sz = double(sk.spanStart[span + 1] - sk.spanStart[span]);
+          pairElems += sz * (sz + 1) / 2 + rowsAfter * sz;
+          rowsAfter += sz;
+        }
+        plan.elimPairElems += pairElems;
+        plan.elimPairFlops += 2.0 * g.width * pairElems;
+        plan.elimColElems += double(g.width) * (g.width + g.rowsBelow);
+      }
       plan.flops += double(g.width) * g.width * g.width / 3.0 +
                     double(g.rowsBelow) * g.width * g.width +
                     double(g.rowsBelow) * g.rowsBelow * g.width;
@@ -211,6 +225,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           }
           const double R = double(pd.rowsBelow - sd.q0), m = double(sd.m);
           plan.updElems += m * R - m * (m - 1) / 2;
+          plan.updFlops += 2.0 * pd.nb * (m * R - m * (m - 1) / 2);
         }
       }
       lr.panelEnd = (int64_t)plan.levelPanels.size();

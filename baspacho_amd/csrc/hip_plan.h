@@ -92,6 +92,10 @@ struct HipPlanHost {
   // statistics
   double flops = 0;          // algorithmic flops of this plan (n^3/3 + r n^2 + r^2 n per lump)
   double updElems = 0;       // lower-trapezoid elements written by update tiles
+  double updFlops = 0;       // 2 * nb * (lower-trapezoid elements), summed over segments
+  double elimPairElems = 0;  // target elements touched by sparse-elimination pair updates
+  double elimPairFlops = 0;  // 2 * n * (pair elements)
+  double elimColElems = 0;   // numeric elements of the sparse-eliminated columns
   int64_t numLaunches = 0;
   int64_t maxPanelsInLevel = 0;
 };

@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""bench.py -- fp64 factor() throughput of the MI355X backend on the BAL-871-shaped Schur problem.
+
+A "step" = one Solver::factor() of one matrix resident in HBM (per rank).  Protocol follows the
+reference's BAL_bench (benchmarking/BaAtLargeBench.cpp:44-97,155-171): structure only from the
+problem (points first, size 3; cameras after, size 9; one block per observation), sparse
+elimination range {0, numPts}, numeric data = uniform(-1,1) seed 37 then damp(0, 1.2*order),
+warm-up factor, timed factor on device-resident data (H2D excluded).  The BAL file is not
+available offline, so the structure comes from the committed synthetic generator
+(baspacho_amd/testing.py: gen_bal_synthetic, 871 cameras / 527480 points / 2.79 M observations).
+
+N>1: one process per GPU; rank 0 runs the symbolic analysis and broadcasts the flat symbolic
+plan over RCCL; every rank then factors its own matrix of that structure (batched mode sharded
+over the GPUs, no collective inside a factorisation) -> weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import baspacho_amd as B  # noqa: E402
+from baspacho_amd import testing as T  # noqa: E402
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix (= vector) peak, AMD datasheet
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_problem(name):
+    if name == "bal871":
+        sizes, ss, cam, pt = T.gen_bal_synthetic()
+        return sizes, ss, [0, 527480], "synthetic BAL-871 stand-in: 871 cams x 9, 527480 pts x 3, %d obs" % len(cam)
+    if name == "bal-small":
+        sizes, ss, cam, pt = T.gen_bal_synthetic(num_cams=120, num_pts=40000, band=16)
+        return sizes, ss, [0, 40000], "synthetic BAL-like: 120 cams, 40000 pts, %d obs" % len(cam)
+    if name == "flat50k":
+        ss = T.gen_flat(16667, 3.0e-4, 37)
+        return np.full(16667, 3, dtype=np.int64), ss, [], "FLAT 16667 x 3, fill 3e-4"
+    if name == "grid82":
+        ss = T.gen_grid(82, 82, 1.0, 2, 37)
+        return np.full(82 * 82, 3, dtype=np.int64), ss, [], "GRID 82x82 conn 2 x 3"
+    if name == "tridiag":
+        return np.full(3334, 3, dtype=np.int64), T.block_tridiagonal(3334), [], "block-tridiagonal 3334 x 3"
+    raise ValueError(name)
+
+
+def structure_index(sol, device):
+    """(row, col) of every numeric element + mask of the meaningful (row >= col) ones, on device"""
+    sk = sol.skel()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    ccp, crs, cd = sk["chainColPtr"], sk["chainRowSpan"], sk["chainData"]
+    n_chains = len(crs)
+    lump_of_chain = np.repeat(np.arange(len(ccp) - 1), np.diff(ccp))
+    width = (sk["lumpStart"][1:] - sk["lumpStart"][:-1])[lump_of_chain]
+    rows = (sk["spanStart"][1:] - sk["spanStart"][:-1])[crs]
+    nelem = dev(rows * width)
+    chain_id = torch.repeat_interleave(torch.arange(n_chains, device=device), nelem)
+    local = torch.arange(int(cd[-1]), device=device) - dev(cd[:-1])[chain_id]
+    w = dev(width)[chain_id]
+    r = dev(sk["spanStart"][crs])[chain_id] + local // w
+    c = dev(sk["lumpStart"][lump_of_chain])[chain_id] + local % w
+    return r, c, r >= c
+
+
+def residual_probe(sol, A_dev, L_dev, device, nprobe=2, seed=5):
+    """size-independent check of L L^T = A at full size: ||L (L^T x) - A x|| / ||A x|| for
+    random x, with A and L applied as block-sparse operators built from the skeleton"""
+    r, c, low = structure_index(sol, device)
+    r, c = r[low], c[low]
+    a, l = A_dev[low], L_dev[low]
+    diag = r == c
+    n = sol.order()
+    worst = 0.0
+    for p in range(nprobe):
+        x = torch.from_numpy(T.random_data(n, -1, 1, seed + p)).to(device)
+        # A x with A = low + low^T - diag
+        ax = torch.zeros(n, dtype=torch.float64, device=device)
+        ax.index_add_(0, r, a * x[c])
+        ax.index_add_(0, c[~diag], a[~diag] * x[r[~diag]])
+        # L (L^T x)
+        y = torch.zeros(n, dtype=torch.float64, device=device)
+        y.index_add_(0, c, l * x[r])
+        z = torch.zeros(n, dtype=torch.float64, device=device)
+        z.index_add_(0, r, l * y[c])
+        worst = max(worst, float((z - ax).norm() / ax.norm()))
+    return worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="bal871")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, "launch with torchrun --nproc-per-node == --gpus"
+
+    # ---- symbolic analysis on rank 0, plan broadcast over RCCL ------------------------------
+    t_sym = 0.0
+    desc = ""
+    if rank == 0:
+        sizes, ss, ranges, desc = build_problem(args.workload)
+        t0 = time.time()
+        sol = B.create_solver(B.Settings(), sizes, ss, ranges)
+        t_sym = time.time() - t0
+        plan = torch.from_numpy(sol.serialize_plan()).to(device)
+        plan_len = torch.tensor([plan.numel()], dtype=torch.int64, device=device)
+    if world > 1:
+        if rank != 0:
+            plan_len = torch.zeros(1, dtype=torch.int64, device=device)
+        dist.broadcast(plan_len, src=0)
+        if rank != 0:
+            plan = torch.empty(int(plan_len.item()), dtype=torch.int64, device=device)
+        dist.broadcast(plan, src=0)
+        if rank != 0:
+            sol = B.Solver.from_plan(plan.cpu().numpy())
+    sol.setStream(torch.cuda.current_stream(device))
+
+    # ---- numeric data: one matrix per rank, K+W pristine copies resident in HBM -------------
+    order, flops = sol.order(), sol.factorFlops()
+    host = T.random_data(sol.dataSize(), -1.0, 1.0, 37 + rank)
+    sol.damp(host, 0.0, order * 1.2)
+    A_dev = torch.from_numpy(host).to(device)
+    n_buf = args.steps + args.warmup
+    bufs = [A_dev.clone() for _ in range(n_buf)]
+    torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        sol.factor(bufs[i])
+    torch.cuda.synchronize(device)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sol.factor(bufs[args.warmup + i])
+    torch.cuda.synchronize(device)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * flops * args.steps / elapsed / 1e9
+
+    out = {
+        "metric": "factor_gflops_fp64_bal871_schur" if args.workload == "bal871"
+        else "factor_gflops_fp64_" + args.workload,
+        "value": round(value, 2), "unit": "GF/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "description": desc, "order": order,
+                   "data_MB": round(sol.dataSize() * 8 / 1e6, 1), "matrices_per_gpu": 1,
+                   "factor_GF_per_matrix": round(flops / 1e9, 3),
+                   "parallelism": "batch-shard x%d (plan broadcast over RCCL)" % world},
+    }
+
+    if rank == 0:
+        # ---- parity at full size: residual probe of the last timed factor -------------------
+        out["residual_probe"] = residual_probe(sol, A_dev, bufs[-1], device)
+        st = sol.planStats()
+        out["plan"] = {k: st[k] for k in ("num_launches", "num_levels", "num_panels",
+                                          "num_upd_tasks", "num_atomic_upd_tasks")}
+        out["analysis_s"] = round(t_sym, 3)
+
+        # ---- roofline of the dominant kernel, HIP events on the execution stream ------------
+        if not args.no_profile:
+            work = A_dev.clone()
+            prof = sol.factorProfiled(work)
+            tot = sum(v[0] for v in prof.values())
+            out["kernel_ms"] = {k: [round(v[0], 4), v[1]] for k, v in prof.items()}
+            dom = max(prof, key=lambda k: prof[k][0])
+            ms, launches = prof[dom]
+            if dom in ("update", "potrf", "trsm"):
+                fl = {"update": st["upd_flops"]}.get(dom, 0.0)
+                if dom == "update":
+                    ach = fl / (ms * 1e-3) / 1e12
+                    out["roofline"] = {"kernel": "updateTile<double>", "bound": "mfma",
+                                       "achieved": round(ach, 3), "peak": PEAK_FP64_MFMA_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": round(ach / PEAK_FP64_MFMA_TFLOPS, 4),
+                                       "traffic": None, "launches": launches,
+                                       "avg_launch_ms": round(ms / max(launches, 1), 5),
+                                       "algorithmic_flops_per_launch": fl / max(launches, 1),
+                                       "share_of_factor": round(ms / tot, 3)}
+            if "roofline" not in out:
+                # HBM-bound kernels: algorithmic bytes = read+write every element of the
+                # eliminated columns once (16 B) + RMW of every pair-update target element (16 B)
+                byt = {"elim_update": 16.0 * st["elim_pair_elems"] + 8.0 * st["elim_col_elems"],
+                       "elim_factor": 16.0 * st["elim_col_elems"]}.get(dom, 0.0)
+                ach = byt / (ms * 1e-3) / 1e9
+                out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1),
+                                   "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                                   "launches": launches,
+                                   "avg_launch_ms": round(ms / max(launches, 1), 5),
+                                   "algorithmic_bytes_per_launch": byt / max(launches, 1),
+                                   "share_of_factor": round(ms / tot, 3)}
+            # secondary kernels, for the record
+            sec = {}
+            if prof["update"][0] > 0:
+                sec["update_TFLOPs"] = round(st["upd_flops"] / (prof["update"][0] * 1e-3) / 1e12, 3)
+            if prof["elim_update"][0] > 0:
+                b = 16.0 * st["elim_pair_elems"] + 8.0 * st["elim_col_elems"]
+                sec["elim_update_GBs"] = round(b / (prof["elim_update"][0] * 1e-3) / 1e9, 1)
+            if prof["elim_factor"][0] > 0:
+                sec["elim_factor_GBs"] = round(16.0 * st["elim_col_elems"] /
+                                               (prof["elim_factor"][0] * 1e-3) / 1e9, 1)
+            out["kernel_rates"] = sec
+
+        # ---- CPU baseline: the BackendFast restatement (oracle/blas_factor.c) on host cores --
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                from oracle import cref
+                cores = os.cpu_count() or 1
+                _, blas_desc = cref.blas_lib(cores)
+                hostA = host.copy()
+                skh = cref.SkelHandle(sol.skel())
+                t0 = time.perf_counter()
+                elim_s = cref.blas_factor(skh, hostA, sol.sparseEliminationRanges(), cores)
+                dt = time.perf_counter() - t0
+                out["cpu_baseline"] = {
+                    "value": round(flops / dt / 1e9, 2), "unit": "GF/s", "cores": cores,
+                    "kind": "port", "seconds": round(dt, 3), "elim_seconds": round(elim_s, 3),
+                    "sample": "1 full factor() of the same matrix (same plan, same data)",
+                    "blas": blas_desc}
+                out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+            except Exception as e:  # the baseline is a report, never a reason to fail the bench
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out))
+
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,7 +150,7 @@ int bsp_solve_lt_f32(bsp_solver* s, const float* dev_mat, float* dev_vec, int64_
 double bsp_factor_flops(const bsp_solver* s);
 
 typedef struct bsp_plan_stats {
-  double flops, upd_elems;
+  double flops, upd_elems, upd_flops, elim_pair_elems, elim_pair_flops, elim_col_elems;
   int64_t num_launches, num_levels, num_panels, num_segs, num_upd_tasks, num_trsm_tasks,
       chain_tab_entries, max_panels_in_level, num_atomic_upd_tasks;
 } bsp_plan_stats;

@@ -126,3 +126,56 @@ def solve_lt(sk, data, vec, ldc, nrhs, start_lump=0, up_to_lump=None):
 def solve(sk, data, vec, ldc, nrhs):
     solve_l(sk, data, vec, ldc, nrhs)
     return solve_lt(sk, data, vec, ldc, nrhs)
+
+
+# ---- BLAS restatement of BackendFast (cpu_baseline of bench.py) --------------------------------
+_blas = None
+
+
+def find_openblas():
+    """system libopenblas if present, else the OpenBLAS bundled in the scipy wheel"""
+    import glob
+    cands = []
+    for d in ("/usr/lib/x86_64-linux-gnu", "/usr/lib64", "/usr/lib", "/opt/OpenBLAS/lib"):
+        cands += sorted(glob.glob(os.path.join(d, "libopenblas*.so*")))
+    try:
+        import scipy
+        cands += sorted(glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs",
+                                               "libscipy_openblas*.so")))
+    except Exception:
+        pass
+    return cands[0] if cands else None
+
+
+def blas_lib(num_threads=0):
+    """load oracle/liboracle_blas.so and bind it to an OpenBLAS; returns (lib, description)"""
+    global _blas
+    if _blas is None:
+        build()
+        lib_ = ctypes.CDLL(os.path.join(_HERE, "liboracle_blas.so"))
+        lib_.orc_blas_desc.restype = ctypes.c_char_p
+        path = find_openblas()
+        if path is None:
+            raise RuntimeError("no OpenBLAS found for the CPU baseline")
+        rc = lib_.orc_blas_init(path.encode(), ctypes.c_int(num_threads))
+        if rc != 0:
+            raise RuntimeError("orc_blas_init: " + lib_.orc_blas_desc().decode())
+        _blas = lib_
+    return _blas, _blas.orc_blas_desc().decode()
+
+
+def blas_factor(sk, data, elim_ranges=(), num_threads=0):
+    """Solver::factor on the BLAS restatement (fp64, in place); returns seconds spent in the
+    sparse-elimination part"""
+    lib_, _ = blas_lib(num_threads)
+    h = sk if isinstance(sk, SkelHandle) else SkelHandle(sk)
+    assert data.dtype == np.float64 and data.flags["C_CONTIGUOUS"]
+    ranges = np.ascontiguousarray(elim_ranges, dtype=np.int64)
+    elim_s = ctypes.c_double(0)
+    rc = lib_.orc_blas_factor_f64(ctypes.byref(h.c), ranges.ctypes.data_as(_I64P),
+                                  ctypes.c_int64(len(ranges)),
+                                  data.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                  ctypes.byref(elim_s))
+    if rc != 0:
+        raise RuntimeError("oracle blas factor failed: %d" % rc)
+    return elim_s.value

@@ -162,3 +162,15 @@ def test_oracle_sparse_elim(seed):
     full = data.copy()
     cref.factor(sk, full, ranges)
     assert np.linalg.norm(lower_of(sol, full) - L) < 1e-8
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_blas_baseline_matches_plain_oracle(seed):
+    """the BackendFast restatement (cpu_baseline of bench.py) against the plain-loop oracle"""
+    sol, _, _ = solver_random(57 + seed, fill=0.03, elim=(0, 60), ranges=[0, 60] if seed else ())
+    sk = sol.skel()
+    data = spd_data(sol, 9 + seed)
+    a, b = data.copy(), data.copy()
+    cref.factor(sk, a, sol.sparseEliminationRanges())
+    cref.blas_factor(sk, b, sol.sparseEliminationRanges())
+    assert np.linalg.norm(lower_of(sol, a) - lower_of(sol, b)) < 1e-9
