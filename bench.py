@@ -53,45 +53,16 @@ def build_problem(name):
     raise ValueError(name)
 
 
-def structure_index(sol, device):
-    """(row, col) of every numeric element + mask of the meaningful (row >= col) ones, on device"""
-    sk = sol.skel()
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    ccp, crs, cd = sk["chainColPtr"], sk["chainRowSpan"], sk["chainData"]
-    n_chains = len(crs)
-    lump_of_chain = np.repeat(np.arange(len(ccp) - 1), np.diff(ccp))
-    width = (sk["lumpStart"][1:] - sk["lumpStart"][:-1])[lump_of_chain]
-    rows = (sk["spanStart"][1:] - sk["spanStart"][:-1])[crs]
-    nelem = dev(rows * width)
-    chain_id = torch.repeat_interleave(torch.arange(n_chains, device=device), nelem)
-    local = torch.arange(int(cd[-1]), device=device) - dev(cd[:-1])[chain_id]
-    w = dev(width)[chain_id]
-    r = dev(sk["spanStart"][crs])[chain_id] + local // w
-    c = dev(sk["lumpStart"][lump_of_chain])[chain_id] + local % w
-    return r, c, r >= c
-
-
-def residual_probe(sol, A_dev, L_dev, device, nprobe=2, seed=5):
-    """size-independent check of L L^T = A at full size: ||L (L^T x) - A x|| / ||A x|| for
-    random x, with A and L applied as block-sparse operators built from the skeleton"""
-    r, c, low = structure_index(sol, device)
-    r, c = r[low], c[low]
-    a, l = A_dev[low], L_dev[low]
-    diag = r == c
-    n = sol.order()
+def residual_probe(sol, host_A, L_dev, nprobe=2, seed=5):
+    """size-independent check of L L^T = A at FULL size: ||L (L^T x) - A x|| / ||A x|| for random
+    x, A and L applied as block-sparse operators through the skeleton (checker = oracle/)"""
+    from oracle import cref
+    L = L_dev.cpu().numpy()
+    skh = cref.SkelHandle(sol.skel())
     worst = 0.0
     for p in range(nprobe):
-        x = torch.from_numpy(T.random_data(n, -1, 1, seed + p)).to(device)
-        # A x with A = low + low^T - diag
-        ax = torch.zeros(n, dtype=torch.float64, device=device)
-        ax.index_add_(0, r, a * x[c])
-        ax.index_add_(0, c[~diag], a[~diag] * x[r[~diag]])
-        # L (L^T x)
-        y = torch.zeros(n, dtype=torch.float64, device=device)
-        y.index_add_(0, c, l * x[r])
-        z = torch.zeros(n, dtype=torch.float64, device=device)
-        z.index_add_(0, r, l * y[c])
-        worst = max(worst, float((z - ax).norm() / ax.norm()))
+        x = T.random_data(sol.order(), -1, 1, seed + p)
+        worst = max(worst, float(cref.probe_residual(skh, host_A, L, x)))
     return worst
 
 
@@ -185,7 +156,7 @@ def main():
 
     if rank == 0:
         # ---- parity at full size: residual probe of the last timed factor -------------------
-        out["residual_probe"] = residual_probe(sol, A_dev, bufs[-1], device)
+        out["residual_probe"] = residual_probe(sol, host, bufs[-1])
         st = sol.planStats()
         out["plan"] = {k: st[k] for k in ("num_launches", "num_levels", "num_panels",
                                           "num_upd_tasks", "num_atomic_upd_tasks")}

@@ -179,3 +179,15 @@ def blas_factor(sk, data, elim_ranges=(), num_threads=0):
     if rc != 0:
         raise RuntimeError("oracle blas factor failed: %d" % rc)
     return elim_s.value
+
+
+def probe_residual(sk, A, L, x):
+    """|| L (L^T x) - A x || / || A x || through the skeleton (fp64 host arrays)"""
+    h = sk if isinstance(sk, SkelHandle) else SkelHandle(sk)
+    out = np.zeros(2, dtype=np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib().orc_probe_residual_f64(ctypes.byref(h.c), A.ctypes.data_as(dp), L.ctypes.data_as(dp),
+                                      x.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    if rc != 0:
+        raise RuntimeError("probe failed")
+    return out[0] / out[1]

@@ -28,3 +28,56 @@ static int64_t orc_bisect(const int64_t* a, int64_t size, int64_t needle) {
 #include "ref_factor_impl.inc"
 #undef REAL
 #undef FN
+
+/* Size-independent parity probe (test/measurement helper, no reference counterpart):
+   out[0] = || L (L^T x) - A x ||_2, out[1] = || A x ||_2, with A (symmetric, lower triangle
+   stored) and L applied as block-sparse operators laid out by the skeleton.  Strictly-upper
+   entries of the square diagonal blocks are ignored (CoalescedBlockMatrix.h:23-37). */
+int orc_probe_residual_f64(const orc_skel* sk, const double* A, const double* L, const double* x,
+                           double* out) {
+  int64_t n = sk->spanStart[sk->numSpans];
+  double* ax = (double*)calloc((size_t)n, sizeof(double));
+  double* y = (double*)calloc((size_t)n, sizeof(double));
+  double* z = (double*)calloc((size_t)n, sizeof(double));
+  if (!ax || !y || !z) return -2;
+  for (int pass = 0; pass < 2; pass++) {
+    for (int64_t l = 0; l < sk->numLumps; l++) {
+      int64_t w = sk->lumpStart[l + 1] - sk->lumpStart[l], gc0 = sk->lumpStart[l];
+      for (int64_t c = sk->chainColPtr[l]; c < sk->chainColPtr[l + 1]; c++) {
+        int64_t span = sk->chainRowSpan[c];
+        int64_t gr0 = sk->spanStart[span], rows = sk->spanStart[span + 1] - gr0;
+        const double* a = A + sk->chainData[c];
+        const double* f = L + sk->chainData[c];
+        for (int64_t r = 0; r < rows; r++) {
+          int64_t gr = gr0 + r;
+          int64_t qEnd = gr - gc0 + 1 < w ? gr - gc0 + 1 : w; /* columns with gc <= gr */
+          if (pass == 0) {
+            double accA = 0, xr = x[gr];
+            for (int64_t q = 0; q < qEnd; q++) {
+              double av = a[r * w + q];
+              accA += av * x[gc0 + q];
+              if (gc0 + q != gr) ax[gc0 + q] += av * xr;
+              y[gc0 + q] += f[r * w + q] * xr;
+            }
+            ax[gr] += accA;
+          } else {
+            double accZ = 0;
+            for (int64_t q = 0; q < qEnd; q++) accZ += f[r * w + q] * y[gc0 + q];
+            z[gr] += accZ;
+          }
+        }
+      }
+    }
+  }
+  double d = 0, na = 0;
+  for (int64_t i = 0; i < n; i++) {
+    d += (z[i] - ax[i]) * (z[i] - ax[i]);
+    na += ax[i] * ax[i];
+  }
+  out[0] = sqrt(d);
+  out[1] = sqrt(na);
+  free(ax);
+  free(y);
+  free(z);
+  return 0;
+}
