@@ -93,22 +93,15 @@ def main():
     # ---- symbolic analysis on rank 0, plan broadcast over RCCL ------------------------------
     t_sym = 0.0
     desc = ""
+    sol = None
     if rank == 0:
         sizes, ss, ranges, desc = build_problem(args.workload)
         t0 = time.time()
         sol = B.create_solver(B.Settings(), sizes, ss, ranges)
         t_sym = time.time() - t0
-        plan = torch.from_numpy(sol.serialize_plan()).to(device)
-        plan_len = torch.tensor([plan.numel()], dtype=torch.int64, device=device)
     if world > 1:
-        if rank != 0:
-            plan_len = torch.zeros(1, dtype=torch.int64, device=device)
-        dist.broadcast(plan_len, src=0)
-        if rank != 0:
-            plan = torch.empty(int(plan_len.item()), dtype=torch.int64, device=device)
-        dist.broadcast(plan, src=0)
-        if rank != 0:
-            sol = B.Solver.from_plan(plan.cpu().numpy())
+        from baspacho_amd.distributed import broadcast_solver
+        sol = broadcast_solver(sol, src=0, device=device)
     sol.setStream(torch.cuda.current_stream(device))
 
     # ---- numeric data: one matrix per rank, K+W pristine copies resident in HBM -------------
