@@ -228,7 +228,7 @@ struct HipNumericCtx : NumericCtx<T> {
       }
       if (nT) {
         timer.begin(kProfTrsm);
-        hipk::trsmPanel<BT><<<dim3(nT, gy.y), 64, 0, sym.stream>>>(
+        hipk::trsmPanel<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
             plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin, ref);
         timer.end();
       }

@@ -186,32 +186,91 @@ __global__ __launch_bounds__(256) void elimUpdate(SkelDev sk, const int32_t* cha
 template <typename T>
 __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
                                                   const int32_t* levelPanels, DataRef<T> dref) {
-  constexpr int LD = kPanelWidth + 1;
-  __shared__ T S[kPanelWidth * LD];
+  // Thread (i,g) = (tid/4, tid%4) keeps the 16 entries k = 4*kk+g of row i in registers, so the
+  // quad of row i holds column block J (columns 4J..4J+3) in its registers a[J].  One step per
+  // 4-column pivot block (16 steps, one barrier each): the block is published through LDS
+  // (double buffered); every thread factors the 4x4 pivot redundantly, solves its own row and the
+  // rows k it needs against it, and applies the rank-4 update to its registers.  Branch-free
+  // (selects) apart from wave-uniform conditions.  Strictly-upper entries are carried as finite
+  // mirror values and never written back; rows/columns beyond nb are padded with the identity.
+  __shared__ T blk[2][kPanelWidth][4];
   const PanelDesc pd = panels[levelPanels[blockIdx.x]];
   T* A = pickData(dref) + pd.diagOff;
   const int nb = pd.nb, lda = pd.lda, tid = threadIdx.x;
-  for (int e = tid; e < nb * nb; e += 256) {
-    int i = e / nb, j = e - i * nb;
-    if (j <= i) S[i * LD + j] = A[(int64_t)i * lda + j];
+  const int i = tid >> 2, g = tid & 3;
+  const int iLd = min(i, nb - 1);
+  T a[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; kk++) {
+    const int k = 4 * kk + g;
+    const T v = A[(int64_t)iLd * lda + min(k, iLd)];
+    a[kk] = (i < nb && k <= i) ? v : ((i >= nb && k == i) ? T(1) : T(0));
   }
+  blk[0][i][g] = a[0];
   __syncthreads();
-  for (int j = 0; j < nb; j++) {
-    const T d = sqrt(S[j * LD + j]);
-    __syncthreads();
-    if (tid == 0) S[j * LD + j] = d;
-    if (tid > j && tid < nb) S[tid * LD + j] /= d;
-    __syncthreads();
-    const int rem = nb - j - 1;
-    for (int e = tid; e < rem * rem; e += 256) {
-      int a = e / rem, b = e - a * rem;
-      if (b <= a) S[(j + 1 + a) * LD + (j + 1 + b)] -= S[(j + 1 + a) * LD + j] * S[(j + 1 + b) * LD + j];
+  const int nSteps = (nb + 3) >> 2;
+#pragma unroll 1
+  for (int J = 0; J < nSteps; J++) {
+    const T(*cur)[4] = blk[J & 1];
+    T(*nxt)[4] = blk[(J + 1) & 1];
+    const int j0 = 4 * J;
+    // 4x4 pivot block (lower part), factored redundantly by every thread
+    const T p00 = cur[j0][0];
+    const T p10 = cur[j0 + 1][0], p11 = cur[j0 + 1][1];
+    const T p20 = cur[j0 + 2][0], p21 = cur[j0 + 2][1], p22 = cur[j0 + 2][2];
+    const T p30 = cur[j0 + 3][0], p31 = cur[j0 + 3][1], p32 = cur[j0 + 3][2], p33 = cur[j0 + 3][3];
+    const T i0 = rsqrt(p00);
+    const T l00 = p00 * i0, l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+    const T q11 = p11 - l10 * l10;
+    const T i1 = rsqrt(q11);
+    const T l11 = q11 * i1, l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+    const T q22 = p22 - l20 * l20 - l21 * l21;
+    const T i2 = rsqrt(q22);
+    const T l22 = q22 * i2, l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+    const T q33 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
+    const T i3 = rsqrt(q33);
+    const T l33 = q33 * i3;
+    // own row against the pivot
+    const T r0 = cur[i][0], r1 = cur[i][1], r2 = cur[i][2], r3 = cur[i][3];
+    T c0 = r0 * i0;
+    T c1 = (r1 - c0 * l10) * i1;
+    T c2 = (r2 - c0 * l20 - c1 * l21) * i2;
+    T c3 = (r3 - c0 * l30 - c1 * l31 - c2 * l32) * i3;
+    const bool below = i >= j0 + 4;
+    // final values of column block J for this row
+    {
+      const int di = i - j0;  // row inside the pivot block when 0..3
+      const T lrow0 = di == 0 ? l00 : di == 1 ? l10 : di == 2 ? l20 : l30;
+      const T lrow1 = di == 1 ? l11 : di == 2 ? l21 : l31;
+      const T lrow2 = di == 2 ? l22 : l32;
+      const T inPiv = g == 0 ? lrow0 : g == 1 ? lrow1 : g == 2 ? lrow2 : l33;
+      const T solved = g == 0 ? c0 : g == 1 ? c1 : g == 2 ? c2 : c3;
+      const bool pivRow = di >= 0 && di < 4;
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) {
+        if (kk == J) a[kk] = below ? solved : ((pivRow && g <= di) ? inPiv : a[kk]);
+      }
+    }
+    if (!below) c0 = c1 = c2 = c3 = T(0);
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+      if (kk > J) {  // wave-uniform
+        const int k = 4 * kk + g;
+        const T s0 = cur[k][0], s1 = cur[k][1], s2 = cur[k][2], s3 = cur[k][3];
+        const T d0 = s0 * i0;
+        const T d1 = (s1 - d0 * l10) * i1;
+        const T d2 = (s2 - d0 * l20 - d1 * l21) * i2;
+        const T d3 = (s3 - d0 * l30 - d1 * l31 - d2 * l32) * i3;
+        a[kk] -= c0 * d0 + c1 * d1 + c2 * d2 + c3 * d3;
+        if (kk == J + 1) nxt[i][g] = a[kk];  // publish the next column block
+      }
     }
     __syncthreads();
   }
-  for (int e = tid; e < nb * nb; e += 256) {
-    int i = e / nb, j = e - i * nb;
-    if (j <= i) A[(int64_t)i * lda + j] = S[i * LD + j];
+#pragma unroll
+  for (int kk = 0; kk < 16; kk++) {
+    const int k = 4 * kk + g;
+    if (i < nb && k <= i) A[(int64_t)i * lda + k] = a[kk];
   }
 }
 
@@ -221,45 +280,88 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
 // that both the coalesced fill and the per-lane column walk are bank-conflict free).
 // Replaces cublas?trsm LEFT/UPPER/OP_C (MatOpsCuda.cu:550-566, 757-781).
 // ------------------------------------------------------------------------------------------
+// body for panels of width <= NB (NB in {8,16,32,64}); thread (r,g) = (tid/4, tid%4) owns the
+// entries k = 8*m + 2*g + h (m < NB/8, h < 2) of row r in registers; the pivot value x_j is
+// broadcast inside the quad with a shuffle, L(k,j) comes from LDS.  Ls is zero above the diagonal
+// and beyond nb, invDiag is zero beyond nb: the body needs no per-lane conditions.
+template <typename T, int NB>
+__device__ __forceinline__ void trsmRows(const T* __restrict__ Ls, const T* __restrict__ invDiag,
+                                         T* P, int lda, int nb, int rows, int tid) {
+  constexpr int LDL = kPanelWidth + 1, M = NB / 8;
+  const int r = tid >> 2, g = tid & 3;
+  const bool active = r < rows;
+  T* row = P + (int64_t)(active ? r : 0) * lda;
+  T x[M][2];
+#pragma unroll
+  for (int m = 0; m < M; m++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int k = 8 * m + 2 * g + h;
+      const T v = row[min(k, nb - 1)];
+      x[m][h] = (active && k < nb) ? v : T(0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    const int mj = j >> 3, gj = (j >> 1) & 3, hj = j & 1;
+    T xj = x[mj][hj] * invDiag[j];
+    xj = __shfl(xj, gj, 4);
+#pragma unroll
+    for (int m = mj; m < M; m++) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int k = 8 * m + 2 * g + h;
+        x[m][h] -= xj * Ls[k * LDL + j];  // zero for k < j; the k == j entry is overwritten below
+      }
+    }
+    x[mj][hj] = (g == gj) ? xj : x[mj][hj];
+  }
+#pragma unroll
+  for (int m = 0; m < M; m++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int k = 8 * m + 2 * g + h;
+      if (active && k < nb) row[k] = x[m][h];
+    }
+  }
+}
+
 template <typename T>
-__global__ __launch_bounds__(64) void trsmPanel(const PanelDesc* panels, const TrsmTask* tasks,
-                                                DataRef<T> dref) {
-  constexpr int LDL = kPanelWidth + 1, LDX = kTile + 1;
+__global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const TrsmTask* tasks,
+                                                 DataRef<T> dref) {
+  constexpr int LDL = kPanelWidth + 1;
   __shared__ T Ls[kPanelWidth * LDL];
-  __shared__ T xs[kPanelWidth * LDX];
+  __shared__ T invDiag[kPanelWidth];
   const TrsmTask task = tasks[blockIdx.x];
   const PanelDesc pd = panels[task.panel];
   T* data = pickData(dref);
   const T* A = data + pd.diagOff;
-  const int nb = pd.nb, lda = pd.lda, lane = threadIdx.x;
+  const int nb = pd.nb, lda = pd.lda, tid = threadIdx.x;
   T* P = data + pd.diagOff + (int64_t)(nb + task.rowTile) * lda;
   const int rows = min(kTile, pd.rowsBelow - task.rowTile);
+  const int nbPad = nb <= 8 ? 8 : nb <= 16 ? 16 : nb <= 32 ? 32 : 64;
 
-  for (int e = lane; e < nb * nb; e += 64) {
-    int i = e / nb, j = e - i * nb;
-    if (j <= i) Ls[i * LDL + j] = A[(int64_t)i * lda + j];
-  }
-  for (int e = lane; e < rows * nb; e += 64) {
-    int r = e / nb, j = e - r * nb;
-    xs[j * LDX + r] = P[(int64_t)r * lda + j];
-  }
-  __syncthreads();
-  if (lane < rows) {
-    for (int j = 0; j < nb; j++) {
-      T s0 = xs[j * LDX + lane], s1 = T(0);
-      int i = 0;
-      for (; i + 1 < j; i += 2) {
-        s0 -= xs[i * LDX + lane] * Ls[j * LDL + i];
-        s1 -= xs[(i + 1) * LDX + lane] * Ls[j * LDL + i + 1];
+  // lane = column, one row per wave per pass; zero above the diagonal and in the padding
+  {
+    const int j = tid & 63;
+    for (int i = tid >> 6; i < nbPad; i += 4) {
+      if (j < nbPad) {
+        T v = T(0);
+        if (i < nb && j <= i) v = A[(int64_t)i * lda + j];
+        Ls[i * LDL + j] = v;
       }
-      if (i < j) s0 -= xs[i * LDX + lane] * Ls[j * LDL + i];
-      xs[j * LDX + lane] = (s0 + s1) / Ls[j * LDL + j];
     }
   }
+  if (tid < kPanelWidth) invDiag[tid] = tid < nb ? T(1) / A[(int64_t)tid * lda + tid] : T(0);
   __syncthreads();
-  for (int e = lane; e < rows * nb; e += 64) {
-    int r = e / nb, j = e - r * nb;
-    P[(int64_t)r * lda + j] = xs[j * LDX + r];
+  if (nb <= 8) {
+    trsmRows<T, 8>(Ls, invDiag, P, lda, nb, rows, tid);
+  } else if (nb <= 16) {
+    trsmRows<T, 16>(Ls, invDiag, P, lda, nb, rows, tid);
+  } else if (nb <= 32) {
+    trsmRows<T, 32>(Ls, invDiag, P, lda, nb, rows, tid);
+  } else {
+    trsmRows<T, 64>(Ls, invDiag, P, lda, nb, rows, tid);
   }
 }
 
@@ -319,18 +421,40 @@ __global__ __launch_bounds__(256) void updateTile(const PanelDesc* panels, const
   const bool diagTile = task.rowTile == task.colTile;
   const int segEnd = sd.q0 + sd.m;
 
-  // stage the two row tiles (rows beyond the panel / segment and the K padding are zero)
-  for (int e = tid; e < kTile * kPad; e += 256) {
-    const int r = e / kPad, k = e - r * kPad;
-    const int qa = task.rowTile + r;
-    T va = T(0);
-    if (k < nb && qa < pd.rowsBelow) va = P[(int64_t)qa * lda + k];
-    As[r * LD + k] = va;
+  // stage the two row tiles: lane = k, wave w takes rows w, w+4, ...; all 16 (32) loads are
+  // issued before the first LDS write so that they are in flight together.  Rows beyond the
+  // panel / segment and the K padding are zero (addresses are clamped, values masked).
+  {
+    const int k = lane;
+    const int kc = min(k, nb - 1);
+    T va[16], vb[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int r = wave + 4 * it;
+      const int qa = min(task.rowTile + r, pd.rowsBelow - 1);
+      va[it] = P[(int64_t)qa * lda + kc];
+    }
     if (!diagTile) {
-      const int qb = task.colTile + r;
-      T vb = T(0);
-      if (k < nb && qb < segEnd) vb = P[(int64_t)qb * lda + k];
-      Bs[r * LD + k] = vb;
+#pragma unroll
+      for (int it = 0; it < 16; it++) {
+        const int r = wave + 4 * it;
+        const int qb = min(task.colTile + r, segEnd - 1);
+        vb[it] = P[(int64_t)qb * lda + kc];
+      }
+    }
+    if (k < kPad) {
+#pragma unroll
+      for (int it = 0; it < 16; it++) {
+        const int r = wave + 4 * it;
+        As[r * LD + k] = (k < nb && task.rowTile + r < pd.rowsBelow) ? va[it] : T(0);
+      }
+      if (!diagTile) {
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+          const int r = wave + 4 * it;
+          Bs[r * LD + k] = (k < nb && task.colTile + r < segEnd) ? vb[it] : T(0);
+        }
+      }
     }
   }
   // per-row / per-column target addressing of this tile
@@ -374,29 +498,46 @@ __global__ __launch_bounds__(256) void updateTile(const PanelDesc* panels, const
       acc10 = Mfma<T>::run(a1, b0, acc10);
       acc11 = Mfma<T>::run(a1, b1, acc11);
     }
-    auto scatter = [&](const Acc& acc, int r0, int c0) {
+    // Scatter.  Non-atomic targets: gather all 16 old values first (independent loads in
+    // flight together), then subtract and store -- a read-modify-write per element would
+    // serialise 16 memory round trips.
+    const Acc* accs[4] = {&acc00, &acc01, &acc10, &acc11};
+    T* ptr[16];
+    bool ok[16];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int r0 = wr + (t >> 1) * 16, c0 = wc + (t & 1) * 16;
       const int cIn = c0 + li;
       const int qc = task.colTile + cIn;
-      if (qc >= segEnd) return;
       const int32_t co = colOff[cIn];
 #pragma unroll
       for (int reg = 0; reg < 4; reg++) {
         const int rIn = r0 + Mfma<T>::row(lane, reg);
         const int qr = task.rowTile + rIn;
-        if (qr < pd.rowsBelow && qr >= qc) {
-          T* p = data + rowBase[rIn] + co;
-          if (task.atomic) {
-            atomicSub(p, acc[reg]);
-          } else {
-            *p -= acc[reg];
-          }
+        ok[t * 4 + reg] = qc < segEnd && qr < pd.rowsBelow && qr >= qc;
+        ptr[t * 4 + reg] = data + rowBase[rIn] + co;
+      }
+    }
+    if (task.atomic) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          if (ok[t * 4 + reg]) atomicSub(ptr[t * 4 + reg], (*accs[t])[reg]);
         }
       }
-    };
-    scatter(acc00, wr, wc);
-    scatter(acc01, wr, wc + 16);
-    scatter(acc10, wr + 16, wc);
-    scatter(acc11, wr + 16, wc + 16);
+    } else {
+      T old[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) old[e] = *ptr[e];  // masked-off entries point at valid memory
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          if (ok[t * 4 + reg]) *ptr[t * 4 + reg] = old[t * 4 + reg] - (*accs[t])[reg];
+        }
+      }
+    }
   }
 }
 

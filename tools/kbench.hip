@@ -1,0 +1,77 @@
+// Developer micro-benchmark of the panel kernels on a dense n x n lump (not part of the product).
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -Ibaspacho_amd/csrc tools/kbench.hip -o /tmp/kbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "hip_kernels.h"
+using namespace BaSpaCho;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__global__ void clockProbe(long long* out, int iters) {
+  long long c0 = clock64(), w0 = wall_clock64();
+  double x = threadIdx.x;
+  for (int i = 0; i < iters; i++) x = x * 1.0000001 + 0.5;
+  long long c1 = clock64(), w1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (long long)x; }
+}
+
+template <typename F>
+float timeIt(F&& f, int reps) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  f();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  for (int i = 0; i < reps; i++) f();
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps * 1000.f;  // us
+}
+
+int main(int argc, char** argv) {
+  int n = argc > 1 ? atoi(argv[1]) : 7839;
+  int c0 = argc > 2 ? atoi(argv[2]) : 0;  // panel start column
+  size_t elems = (size_t)n * n;
+  std::vector<double> h(elems);
+  for (size_t i = 0; i < elems; i++) h[i] = ((i * 2654435761u) % 1000) / 1000.0 - 0.5;
+  for (int i = 0; i < n; i++) h[(size_t)i * n + i] = n * 1.2;
+  double* d; CK(hipMalloc(&d, elems * 8)); CK(hipMemcpy(d, h.data(), elems * 8, hipMemcpyHostToDevice));
+
+  long long* dc; CK(hipMalloc(&dc, 64));
+  for (int blocks : {1, 256}) {
+    clockProbe<<<blocks, 64>>>(dc, 100000); long long hc[3]; CK(hipMemcpy(hc, dc, 24, hipMemcpyDeviceToHost));
+    printf("clockProbe blocks=%d: shader cycles %lld, wall ticks(100MHz) %lld -> %.2f GHz\n", blocks, hc[0], hc[1], hc[0] / (hc[1] * 10.0));
+  }
+
+  const int nb = 64;
+  PanelDesc pd{}; pd.diagOff = (int64_t)c0 * n + c0; pd.lda = n; pd.nb = nb; pd.nRest = n - c0 - nb; pd.rowsBelow = pd.nRest; pd.lumpRowBase = 0; pd.lump = 0;
+  SegDesc sd{}; sd.panel = 0; sd.kind = kSegIntra; sd.q0 = 0; sd.m = pd.nRest; sd.tgtBase = (int64_t)(c0 + nb) * n + (c0 + nb); sd.tgtStride = n;
+  std::vector<TrsmTask> tt; for (int r = 0; r < pd.rowsBelow; r += kTile) tt.push_back({0, r});
+  std::vector<UpdTask> ut;
+  for (int cT = 0; cT < sd.m; cT += kTile) for (int rT = cT; rT < pd.rowsBelow; rT += kTile) ut.push_back({0, rT, cT, 0});
+  std::vector<UpdTask> utA = ut; for (auto& t : utA) t.atomic = 1;
+  int32_t lp = 0;
+  PanelDesc* dpd; SegDesc* dsd; TrsmTask* dtt; UpdTask* dut; UpdTask* dutA; int32_t* dlp;
+  CK(hipMalloc(&dpd, sizeof pd)); CK(hipMemcpy(dpd, &pd, sizeof pd, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dsd, sizeof sd)); CK(hipMemcpy(dsd, &sd, sizeof sd, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dtt, tt.size() * sizeof(TrsmTask))); CK(hipMemcpy(dtt, tt.data(), tt.size() * sizeof(TrsmTask), hipMemcpyHostToDevice));
+  CK(hipMalloc(&dut, ut.size() * sizeof(UpdTask))); CK(hipMemcpy(dut, ut.data(), ut.size() * sizeof(UpdTask), hipMemcpyHostToDevice));
+  CK(hipMalloc(&dutA, ut.size() * sizeof(UpdTask))); CK(hipMemcpy(dutA, utA.data(), ut.size() * sizeof(UpdTask), hipMemcpyHostToDevice));
+  CK(hipMalloc(&dlp, 4)); CK(hipMemcpy(dlp, &lp, 4, hipMemcpyHostToDevice));
+  hipk::DataRef<double> ref{d, nullptr};
+
+  printf("n=%d panel at %d: rowsBelow=%d trsmTasks=%zu updTasks=%zu\n", n, c0, pd.rowsBelow, tt.size(), ut.size());
+  float us;
+  us = timeIt([&] { hipk::potrfPanel<double><<<1, 256>>>(dpd, dlp, ref); }, 50);
+  printf("potrfPanel        : %8.1f us\n", us);
+  us = timeIt([&] { hipk::trsmPanel<double><<<(unsigned)tt.size(), 256>>>(dpd, dtt, ref); }, 50);
+  printf("trsmPanel         : %8.1f us  (%zu tasks)\n", us, tt.size());
+  double updFlops = 0; { double R = pd.rowsBelow, m = sd.m; updFlops = 2.0 * nb * (m * R - m * (m - 1) / 2); }
+  us = timeIt([&] { hipk::updateTile<double><<<(unsigned)ut.size(), 256>>>(dpd, dsd, dut, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
+  printf("updateTile plain  : %8.1f us  -> %.2f TF/s\n", us, updFlops / us / 1e6);
+  us = timeIt([&] { hipk::updateTile<double><<<(unsigned)ut.size(), 256>>>(dpd, dsd, dutA, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
+  printf("updateTile atomic : %8.1f us  -> %.2f TF/s\n", us, updFlops / us / 1e6);
+  CK(hipDeviceSynchronize());
+  return 0;
+}
