@@ -59,7 +59,7 @@ struct DevBuf {
 struct DevPlan {
   HipPlanHost host;
   DevBuf panels, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
-      updTasks, elimChainLump;
+      updTasks, elimChainLump, elimItems, elimPairOffJ, elimPairOffI;
   void upload() {
     panels.upload(host.panels);
     segs.upload(host.segs);
@@ -71,6 +71,9 @@ struct DevPlan {
     trsmTasks.upload(host.trsmTasks);
     updTasks.upload(host.updTasks);
     elimChainLump.upload(host.elimChainLump);
+    elimItems.upload(host.elimItems);
+    elimPairOffJ.upload(host.elimPairOffJ);
+    elimPairOffI.upload(host.elimPairOffI);
   }
 };
 
@@ -265,7 +268,16 @@ struct HipNumericCtx : NumericCtx<T> {
     timer.end();
     launchLevels(plan, er.bigLevels, ref, timer);
     const int64_t nChains = er.chainEnd - er.chainBegin;
-    if (nChains > 0) {
+    if (er.useGather) {
+      const int64_t nItems = er.itemEnd - er.itemBegin;
+      if (nItems > 0) {
+        timer.begin(kProfElimUpdate);
+        hipk::elimGather<BT><<<dim3((unsigned)((nItems + 3) / 4), gy), 256, 0, sym.stream>>>(
+            plan.elimItems.as<ElimGatherItem>() + er.itemBegin, plan.elimPairOffJ.as<uint32_t>(),
+            plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems);
+        timer.end();
+      }
+    } else if (nChains > 0) {
       timer.begin(kProfElimUpdate);
       hipk::elimUpdate<BT><<<dim3((unsigned)((nChains + 3) / 4), gy), 256, 0, sym.stream>>>(
           sk, plan.elimChainLump.as<int32_t>() + er.chainLumpOff, ref, er.chainBegin, er.chainEnd);

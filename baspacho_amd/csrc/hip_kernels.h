@@ -179,6 +179,94 @@ __global__ __launch_bounds__(256) void elimUpdate(SkelDev sk, const int32_t* cha
 }
 
 // ------------------------------------------------------------------------------------------
+// K2g  sparse-elimination update, GATHER form (atomic-free, deterministic).  One wave owns one
+// target block (sj,si) and the list of source chain pairs that contribute to it (sorted by target
+// at plan time): it accumulates  sum_l B_j(l) * B_i(l)^T  in registers (each lane up to 4 output
+// elements) and subtracts the sum from the target once.  Pair offsets are fetched 64 at a time
+// (one coalesced load per lane) and broadcast with readlane; the small source blocks are read
+// straight from HBM/L2 (each is |s| x n contiguous values).  Replaces the per-pair atomics of
+// sparse_elim_straight_kernel (MatOpsCuda.cu:235-331) for ranges whose blocks fit a wave.
+// ------------------------------------------------------------------------------------------
+template <typename T, int N>
+__device__ __forceinline__ T dotRows(const T* __restrict__ a, const T* __restrict__ b, int n) {
+  T s = T(0);
+  if (N > 0) {
+#pragma unroll
+    for (int k = 0; k < N; k++) s += a[k] * b[k];
+  } else {
+    for (int k = 0; k < n; k++) s += a[k] * b[k];
+  }
+  return s;
+}
+
+template <typename T, int N, int SLOTS>
+__device__ __forceinline__ void gatherAccumulate(const T* data, const uint32_t* offJ,
+                                                 const uint32_t* offI, int pairBegin, int pairEnd,
+                                                 int n, int lane, const int (&rowK)[4],
+                                                 const int (&colK)[4], T (&acc)[4]) {
+  for (int base = pairBegin; base < pairEnd; base += 64) {
+    const int cnt = min(64, pairEnd - base);
+    const uint32_t myJ = lane < cnt ? offJ[base + lane] : 0u;
+    const uint32_t myI = lane < cnt ? offI[base + lane] : 0u;
+#pragma unroll 2
+    for (int t = 0; t < cnt; t++) {
+      const T* Bj = data + (uint32_t)__builtin_amdgcn_readlane((int)myJ, t);
+      const T* Bi = data + (uint32_t)__builtin_amdgcn_readlane((int)myI, t);
+#pragma unroll
+      for (int s = 0; s < SLOTS; s++) acc[s] += dotRows<T, N>(Bj + rowK[s], Bi + colK[s], n);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, const uint32_t* offJ,
+                                                  const uint32_t* offI, DataRef<T> dref,
+                                                  int numItems) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + wave;
+  if (idx >= numItems) return;
+  const ElimGatherItem it = items[idx];
+  T* data = pickData(dref);
+  const int rows = it.rows, cols = it.cols, n = it.n;
+  const int total = rows * cols;
+  // per-lane output elements e = lane + 64*s  ->  (r, q); offsets of the operand rows
+  int rowK[4], colK[4], tgt[4];
+  bool ok[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int e = lane + 64 * s;
+    ok[s] = e < total;
+    const int ee = ok[s] ? e : 0;
+    const int r = ee / cols, q = ee - r * cols;
+    rowK[s] = r * n;
+    colK[s] = q * n;
+    tgt[s] = r * it.tgtStride + q;
+    if ((it.flags & 2) && q > r) ok[s] = false;  // diagonal target block: lower triangle only
+  }
+  T acc[4] = {T(0), T(0), T(0), T(0)};
+  const int slots = (total + 63) >> 6;
+  if (n == 3 && slots <= 2) {
+    gatherAccumulate<T, 3, 2>(data, offJ, offI, it.pairBegin, it.pairEnd, n, lane, rowK, colK, acc);
+  } else if (slots <= 2) {
+    gatherAccumulate<T, 0, 2>(data, offJ, offI, it.pairBegin, it.pairEnd, n, lane, rowK, colK, acc);
+  } else {
+    gatherAccumulate<T, 0, 4>(data, offJ, offI, it.pairBegin, it.pairEnd, n, lane, rowK, colK, acc);
+  }
+  T* target = data + it.tgtOff;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    if (ok[s]) {
+      if (it.flags & 1) {
+        atomicSub(target + tgt[s], acc[s]);
+      } else {
+        target[tgt[s]] -= acc[s];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K3  panel potrf: in-place Cholesky of the nb x nb (nb <= 64) diagonal block of a panel, one
 // workgroup per panel, whole block in LDS.  Replaces cusolverDn?potrf / potrfBatched
 // (MatOpsCuda.cu:508-548, 727-755) on the panel granularity.

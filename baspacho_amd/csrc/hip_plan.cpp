@@ -1,6 +1,9 @@
 #include "hip_plan.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <iostream>
 #include <map>
 
 namespace BaSpaCho {
@@ -23,6 +26,125 @@ LumpCols lumpCols(const CoalescedBlockMatrixSkel& sk, int64_t l) {
   g.rowsBelow =
       sk.chainRowsTillEnd[g.chain0 + g.nChains - 1] - sk.chainRowsTillEnd[g.chain0 + g.diagChains - 1];
   return g;
+}
+
+// Gather form of the pair updates of one elimination range (see ElimGatherItem): enumerate every
+// (column l, chains i<=j) pair, bucket by target chain, order by (target span, source width) and
+// cut into work items.  Falls back (useGather=false -> atomic scatter kernel) when offsets do not
+// fit 32 bits or a target block is larger than a wave handles.
+void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, ElimRangePlan& er) {
+  er.useGather = false;
+  if (sk.dataSize() >= (int64_t(1) << 32)) return;
+  const bool timing = std::getenv("BSP_TIMING") != nullptr;
+  auto tic = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    std::cerr << "[elim gather plan] " << what << ": "
+              << std::chrono::duration<double>(now - tic).count() << " s" << std::endl;
+    tic = now;
+  };
+  struct Pair {
+    int32_t si, width;  // column span of the target block, width of the source lump
+    uint32_t offJ, offI;
+  };
+  // map span -> chain index inside the current target lump (rebuilt when the target changes)
+  std::vector<int64_t> chainOfSpan(sk.numSpans(), -1);
+  int64_t mappedLump = -1;
+  auto mapTarget = [&](int64_t t) {
+    if (t == mappedLump) return;
+    for (int64_t c = sk.chainColPtr[t]; c < sk.chainColPtr[t + 1]; c++) chainOfSpan[sk.chainRowSpan[c]] = c;
+    mappedLump = t;
+  };
+  // enumerate(f): f(targetChain, si, width, offJ, offI) for every pair; false if unsupported
+  auto enumerate = [&](auto&& f) -> bool {
+    for (int64_t l = er.lumpBegin; l < er.lumpEnd; l++) {
+      LumpCols g = lumpCols(sk, l);
+      if (g.width > 255) return false;
+      const int64_t cBegin = g.chain0 + g.diagChains, cEnd = g.chain0 + g.nChains;
+      for (int64_t i = cBegin; i < cEnd; i++) {
+        const int64_t si = sk.chainRowSpan[i];
+        const int64_t siSize = sk.spanStart[si + 1] - sk.spanStart[si];
+        mapTarget(sk.spanToLump[si]);
+        for (int64_t j = i; j < cEnd; j++) {
+          const int64_t sj = sk.chainRowSpan[j];
+          if ((sk.spanStart[sj + 1] - sk.spanStart[sj]) * siSize > kGatherMaxElems) return false;
+          const int64_t tc = chainOfSpan[sj];
+          f(tc, si, g.width, sk.chainData[j], sk.chainData[i]);
+        }
+      }
+    }
+    return true;
+  };
+  // pass 1: count per target chain; pass 2: fill the buckets in place
+  const int64_t nChainsTot = (int64_t)sk.chainRowSpan.size();
+  std::vector<int64_t> bucketPtr(nChainsTot + 1, 0);
+  int64_t nPairs = 0;
+  if (!enumerate([&](int64_t tc, int64_t, int64_t, int64_t, int64_t) {
+        bucketPtr[tc + 1]++;
+        nPairs++;
+      })) {
+    return;
+  }
+  lap("count pairs");
+  if (nPairs >= (int64_t)INT32_MAX) return;
+  for (int64_t c = 0; c < nChainsTot; c++) bucketPtr[c + 1] += bucketPtr[c];
+  std::vector<Pair> sorted((size_t)nPairs);
+  {
+    std::vector<int64_t> cursor(bucketPtr.begin(), bucketPtr.end() - 1);
+    mappedLump = -1;
+    enumerate([&](int64_t tc, int64_t si, int64_t width, int64_t oj, int64_t oi) {
+      sorted[cursor[tc]++] = Pair{(int32_t)si, (int32_t)width, (uint32_t)oj, (uint32_t)oi};
+    });
+  }
+  lap("bucket by target chain");
+  plan.elimPairOffJ.reserve(plan.elimPairOffJ.size() + (size_t)nPairs);
+  plan.elimPairOffI.reserve(plan.elimPairOffI.size() + (size_t)nPairs);
+  er.itemBegin = (int64_t)plan.elimItems.size();
+  for (int64_t c = 0; c < nChainsTot; c++) {
+    const int64_t b = bucketPtr[c], e = bucketPtr[c + 1];
+    if (b == e) continue;
+    std::sort(sorted.begin() + b, sorted.begin() + e, [](const Pair& x, const Pair& y) {
+      return x.si != y.si ? x.si < y.si : x.width < y.width;
+    });
+    const int64_t sj = sk.chainRowSpan[c];
+    const int64_t rows = sk.spanStart[sj + 1] - sk.spanStart[sj];
+    int64_t q = b;
+    while (q < e) {
+      int64_t q1 = q;  // [q, q1): same target block
+      while (q1 < e && sorted[q1].si == sorted[q].si) q1++;
+      const int64_t si = sorted[q].si;
+      const int64_t t = sk.spanToLump[si];
+      const size_t firstItem = plan.elimItems.size();
+      int64_t u = q;
+      while (u < q1) {  // split by source width and by length
+        int64_t u1 = u;
+        while (u1 < q1 && sorted[u1].width == sorted[u].width && u1 - u < kGatherMaxPairs) u1++;
+        ElimGatherItem it{};
+        it.tgtOff = sk.chainData[c] + sk.spanOffsetInLump[si];
+        it.pairBegin = (int32_t)plan.elimPairOffJ.size();
+        for (int64_t k = u; k < u1; k++) {
+          plan.elimPairOffJ.push_back(sorted[k].offJ);
+          plan.elimPairOffI.push_back(sorted[k].offI);
+        }
+        it.pairEnd = (int32_t)plan.elimPairOffJ.size();
+        it.tgtStride = (int32_t)(sk.lumpStart[t + 1] - sk.lumpStart[t]);
+        it.rows = (int16_t)rows;
+        it.cols = (int16_t)(sk.spanStart[si + 1] - sk.spanStart[si]);
+        it.n = (int16_t)sorted[u].width;
+        it.flags = (int16_t)(sj == si ? 2 : 0);
+        plan.elimItems.push_back(it);
+        u = u1;
+      }
+      if (plan.elimItems.size() - firstItem > 1) {
+        for (size_t k = firstItem; k < plan.elimItems.size(); k++) plan.elimItems[k].flags |= 1;
+      }
+      q = q1;
+    }
+  }
+  er.itemEnd = (int64_t)plan.elimItems.size();
+  er.useGather = true;
+  lap("sort + emit items");
 }
 
 struct PanelBuild {
@@ -131,6 +253,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       }
     }
     elimBigBuckets.push_back(std::move(big));
+    buildElimGather(sk, plan, er);
     plan.elimRanges.push_back(std::move(er));
   }
 

@@ -65,6 +65,21 @@ struct LevelRange {
   int64_t updBegin, updEnd;      // into updTasks
 };
 
+// One work item of the gather-form sparse-elimination update: a target block (sj,si) of the
+// factor and the list of source chain pairs (one per eliminated column holding both sj and si)
+// whose products B_j * B_i^T are summed into it.  Pairs are referenced by 32-bit element offsets.
+struct ElimGatherItem {
+  int64_t tgtOff;     // data offset of the target block
+  int32_t pairBegin;  // into elimPairOffJ / elimPairOffI
+  int32_t pairEnd;
+  int32_t tgtStride;  // row stride of the target lump
+  int16_t rows, cols; // |sj|, |si|
+  int16_t n;          // width of the source lumps of this item
+  int16_t flags;      // bit0: target shared with other items (atomic), bit1: diagonal block
+};
+constexpr int kGatherMaxElems = 256;   // rows*cols handled per wave (4 per lane)
+constexpr int kGatherMaxPairs = 2048;  // pairs per work item (longer lists are split)
+
 // one sparse-elimination range restricted to the planned lump range
 struct ElimRangePlan {
   int64_t lumpBegin, lumpEnd;
@@ -72,12 +87,16 @@ struct ElimRangePlan {
   int64_t chainLumpOff;          // offset into elimChainLump of chain `chainBegin`
   int32_t maxWidth;              // widest lump of the range
   std::vector<LevelRange> bigLevels;  // lumps wider than kElimSmallMax go through panels
+  bool useGather = false;             // pair updates in gather form (atomic-free) ...
+  int64_t itemBegin = 0, itemEnd = 0; // ... over these ElimGatherItems
 };
 
 struct HipPlanHost {
   int64_t startLump = 0, upToLump = 0;
   std::vector<ElimRangePlan> elimRanges;
   std::vector<int32_t> elimChainLump;  // lump of every chain inside elimination ranges
+  std::vector<ElimGatherItem> elimItems;
+  std::vector<uint32_t> elimPairOffJ, elimPairOffI;
 
   std::vector<PanelDesc> panels;
   std::vector<SegDesc> segs;
