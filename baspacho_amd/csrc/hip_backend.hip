@@ -58,10 +58,11 @@ struct DevBuf {
 
 struct DevPlan {
   HipPlanHost host;
-  DevBuf panels, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
+  DevBuf panels, srcs, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
       updTasks, elimChainLump, elimItems, elimPairOffJ, elimPairOffI;
   void upload() {
     panels.upload(host.panels);
+    srcs.upload(host.srcs);
     segs.upload(host.segs);
     chainOffTab.upload(host.chainOffTab);
     rowChain.upload(host.rowChain);
@@ -238,7 +239,7 @@ struct HipNumericCtx : NumericCtx<T> {
       if (nU) {
         timer.begin(kProfUpdate);
         hipk::updateTile<BT><<<dim3(nU, gy.y), 256, 0, sym.stream>>>(
-            plan.panels.as<PanelDesc>(), plan.segs.as<SegDesc>(),
+            plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(),
             plan.updTasks.as<UpdTask>() + lr.updBegin, plan.chainOffTab.as<int64_t>(),
             plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(), plan.rowColOff.as<int32_t>(),
             ref);

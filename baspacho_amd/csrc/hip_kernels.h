@@ -488,7 +488,7 @@ struct Mfma<float> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void updateTile(const PanelDesc* panels, const SegDesc* segs,
+__global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const SegDesc* segs,
                                                   const UpdTask* tasks, const int64_t* chainOffTab,
                                                   const int32_t* rowChain, const int32_t* rowLocal,
                                                   const int32_t* rowColOff, DataRef<T> dref) {
@@ -500,51 +500,14 @@ __global__ __launch_bounds__(256) void updateTile(const PanelDesc* panels, const
 
   const UpdTask task = tasks[blockIdx.x];
   const SegDesc sd = segs[task.seg];
-  const PanelDesc pd = panels[sd.panel];
+  const SrcDesc pd = srcs[sd.src];  // (named pd: rowsBelow / nRest / lumpRowBase as for a panel)
   T* data = pickData(dref);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nb = pd.nb, lda = pd.lda;
-  const int kPad = (nb + 3) & ~3;
-  const T* P = data + pd.diagOff + (int64_t)nb * lda;  // first row below the diagonal block
+  const int K = pd.K, lda = pd.lda;
+  const T* P = data + pd.off;  // first row below the source columns
   const bool diagTile = task.rowTile == task.colTile;
   const int segEnd = sd.q0 + sd.m;
 
-  // stage the two row tiles: lane = k, wave w takes rows w, w+4, ...; all 16 (32) loads are
-  // issued before the first LDS write so that they are in flight together.  Rows beyond the
-  // panel / segment and the K padding are zero (addresses are clamped, values masked).
-  {
-    const int k = lane;
-    const int kc = min(k, nb - 1);
-    T va[16], vb[16];
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const int r = wave + 4 * it;
-      const int qa = min(task.rowTile + r, pd.rowsBelow - 1);
-      va[it] = P[(int64_t)qa * lda + kc];
-    }
-    if (!diagTile) {
-#pragma unroll
-      for (int it = 0; it < 16; it++) {
-        const int r = wave + 4 * it;
-        const int qb = min(task.colTile + r, segEnd - 1);
-        vb[it] = P[(int64_t)qb * lda + kc];
-      }
-    }
-    if (k < kPad) {
-#pragma unroll
-      for (int it = 0; it < 16; it++) {
-        const int r = wave + 4 * it;
-        As[r * LD + k] = (k < nb && task.rowTile + r < pd.rowsBelow) ? va[it] : T(0);
-      }
-      if (!diagTile) {
-#pragma unroll
-        for (int it = 0; it < 16; it++) {
-          const int r = wave + 4 * it;
-          Bs[r * LD + k] = (k < nb && task.colTile + r < segEnd) ? vb[it] : T(0);
-        }
-      }
-    }
-  }
   // per-row / per-column target addressing of this tile
   if (tid < kTile) {
     const int q = task.rowTile + tid;
@@ -566,8 +529,6 @@ __global__ __launch_bounds__(256) void updateTile(const PanelDesc* panels, const
     if (q < segEnd) off = sd.kind == kSegIntra ? q : rowColOff[pd.lumpRowBase + (q - pd.nRest)];
     colOff[cidx] = off;
   }
-  __syncthreads();
-
   const T* Bt = diagTile ? As : Bs;
   const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
   const int li = lane & 15, lk = lane >> 4;
@@ -575,17 +536,61 @@ __global__ __launch_bounds__(256) void updateTile(const PanelDesc* panels, const
   Acc acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
   // a diagonal tile only needs sub-tiles on or below the diagonal
   const bool skipUpper = diagTile && wr < wc;
-  if (!skipUpper) {
-    for (int k0 = 0; k0 < kPad; k0 += 4) {
-      const T a0 = As[(wr + li) * LD + k0 + lk];
-      const T a1 = As[(wr + 16 + li) * LD + k0 + lk];
-      const T b0 = Bt[(wc + li) * LD + k0 + lk];
-      const T b1 = Bt[(wc + 16 + li) * LD + k0 + lk];
-      acc00 = Mfma<T>::run(a0, b0, acc00);
-      acc01 = Mfma<T>::run(a0, b1, acc01);
-      acc10 = Mfma<T>::run(a1, b0, acc10);
-      acc11 = Mfma<T>::run(a1, b1, acc11);
+
+  // K loop in chunks of up to 64 source columns: stage (lane = k, wave w takes rows w, w+4, ...;
+  // all loads of a chunk are issued before the first LDS write), then 2x2 MFMA tiles per wave.
+  for (int kBase = 0; kBase < K; kBase += kPanelWidth) {
+    const int kc = min(kPanelWidth, K - kBase);
+    const int kPad = (kc + 3) & ~3;
+    {
+      const int k = lane;
+      const int kcl = kBase + min(k, kc - 1);
+      T va[16], vb[16];
+#pragma unroll
+      for (int it = 0; it < 16; it++) {
+        const int r = wave + 4 * it;
+        const int qa = min(task.rowTile + r, pd.rowsBelow - 1);
+        va[it] = P[(int64_t)qa * lda + kcl];
+      }
+      if (!diagTile) {
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+          const int r = wave + 4 * it;
+          const int qb = min(task.colTile + r, segEnd - 1);
+          vb[it] = P[(int64_t)qb * lda + kcl];
+        }
+      }
+      if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
+      if (k < kPad) {
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+          const int r = wave + 4 * it;
+          As[r * LD + k] = (k < kc && task.rowTile + r < pd.rowsBelow) ? va[it] : T(0);
+        }
+        if (!diagTile) {
+#pragma unroll
+          for (int it = 0; it < 16; it++) {
+            const int r = wave + 4 * it;
+            Bs[r * LD + k] = (k < kc && task.colTile + r < segEnd) ? vb[it] : T(0);
+          }
+        }
+      }
     }
+    __syncthreads();
+    if (!skipUpper) {
+      for (int k0 = 0; k0 < kPad; k0 += 4) {
+        const T a0 = As[(wr + li) * LD + k0 + lk];
+        const T a1 = As[(wr + 16 + li) * LD + k0 + lk];
+        const T b0 = Bt[(wc + li) * LD + k0 + lk];
+        const T b1 = Bt[(wc + 16 + li) * LD + k0 + lk];
+        acc00 = Mfma<T>::run(a0, b0, acc00);
+        acc01 = Mfma<T>::run(a0, b1, acc01);
+        acc10 = Mfma<T>::run(a1, b0, acc10);
+        acc11 = Mfma<T>::run(a1, b1, acc11);
+      }
+    }
+  }
+  if (!skipUpper) {
     // Scatter.  Non-atomic targets: gather all 16 old values first (independent loads in
     // flight together), then subtract and store -- a read-modify-write per element would
     // serialise 16 memory round trips.

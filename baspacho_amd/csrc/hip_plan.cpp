@@ -172,41 +172,79 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
   // per-panel segment ranges (segments of one panel are contiguous in plan.segs)
   vector<int64_t> panelSegBegin, panelSegEnd;
 
-  // ---- helper: cut a lump into panels; returns number of panels
+  // ---- helper: cut a lump into outer blocks and panels; returns number of panels.
+  // Segments of a panel: the remaining columns of its outer block (source = the panel, K = nb);
+  // the last panel of an outer block also carries the segments of the block-wide source
+  // (K = block width): rest of the lump and, if requested, every board of the lump column.
   auto addPanels = [&](int64_t l, const LumpCols& g, int32_t lumpRowBase, bool withBoards,
                        const vector<SegDesc>& boardSegTemplates) {
     int32_t count = 0;
-    for (int64_t c0 = 0; c0 < g.width; c0 += kPanelWidth, count++) {
-      const int32_t nb = (int32_t)std::min<int64_t>(kPanelWidth, g.width - c0);
-      PanelDesc pd;
-      pd.diagOff = g.diagOff + c0 * g.width + c0;
-      pd.lda = (int32_t)g.width;
-      pd.nb = nb;
-      pd.nRest = (int32_t)(g.width - c0 - nb);
-      pd.rowsBelow = (int32_t)(pd.nRest + g.rowsBelow);
-      pd.lumpRowBase = lumpRowBase;
-      pd.lump = (int32_t)l;
-      const int32_t pIdx = (int32_t)plan.panels.size();
-      plan.panels.push_back(pd);
-      panelSegBegin.push_back((int64_t)plan.segs.size());
-      if (pd.nRest > 0) {
-        SegDesc s{};
-        s.panel = pIdx;
-        s.kind = kSegIntra;
-        s.q0 = 0;
-        s.m = pd.nRest;
-        s.tgtBase = g.diagOff + (c0 + nb) * g.width + (c0 + nb);
-        s.tgtStride = (int32_t)g.width;
-        plan.segs.push_back(s);
-      }
-      if (withBoards) {
-        for (SegDesc s : boardSegTemplates) {
-          s.panel = pIdx;
-          s.q0 += pd.nRest;
+    const int64_t n = g.width;
+    for (int64_t blockStart = 0; blockStart < n; blockStart += kOuterWidth) {
+      const int64_t blockEnd = std::min<int64_t>(n, blockStart + kOuterWidth);
+      for (int64_t c0 = blockStart; c0 < blockEnd; c0 += kPanelWidth, count++) {
+        const int32_t nb = (int32_t)std::min<int64_t>(kPanelWidth, blockEnd - c0);
+        PanelDesc pd;
+        pd.diagOff = g.diagOff + c0 * n + c0;
+        pd.lda = (int32_t)n;
+        pd.nb = nb;
+        pd.nRest = (int32_t)(n - c0 - nb);
+        pd.rowsBelow = (int32_t)(pd.nRest + g.rowsBelow);
+        pd.lumpRowBase = lumpRowBase;
+        pd.lump = (int32_t)l;
+        plan.panels.push_back(pd);
+        panelSegBegin.push_back((int64_t)plan.segs.size());
+        const int64_t innerCols = blockEnd - c0 - nb;
+        if (innerCols > 0) {
+          SrcDesc sr{};
+          sr.off = pd.diagOff + (int64_t)nb * n;
+          sr.lda = (int32_t)n;
+          sr.K = nb;
+          sr.rowsBelow = pd.rowsBelow;
+          sr.nRest = pd.nRest;
+          sr.lumpRowBase = lumpRowBase;
+          plan.srcs.push_back(sr);
+          SegDesc s{};
+          s.src = (int32_t)plan.srcs.size() - 1;
+          s.kind = kSegIntra;
+          s.q0 = 0;
+          s.m = (int32_t)innerCols;
+          s.tgtBase = g.diagOff + (c0 + nb) * n + (c0 + nb);
+          s.tgtStride = (int32_t)n;
           plan.segs.push_back(s);
         }
+        if (c0 + nb == blockEnd) {  // the outer block is complete
+          SrcDesc sr{};
+          sr.off = g.diagOff + blockEnd * n + blockStart;
+          sr.lda = (int32_t)n;
+          sr.K = (int32_t)(blockEnd - blockStart);
+          sr.nRest = (int32_t)(n - blockEnd);
+          sr.rowsBelow = (int32_t)(sr.nRest + g.rowsBelow);
+          sr.lumpRowBase = lumpRowBase;
+          if (sr.rowsBelow > 0) {
+            plan.srcs.push_back(sr);
+            const int32_t srcIdx = (int32_t)plan.srcs.size() - 1;
+            if (sr.nRest > 0) {
+              SegDesc s{};
+              s.src = srcIdx;
+              s.kind = kSegIntra;
+              s.q0 = 0;
+              s.m = sr.nRest;
+              s.tgtBase = g.diagOff + blockEnd * n + blockEnd;
+              s.tgtStride = (int32_t)n;
+              plan.segs.push_back(s);
+            }
+            if (withBoards) {
+              for (SegDesc s : boardSegTemplates) {
+                s.src = srcIdx;
+                s.q0 += sr.nRest;
+                plan.segs.push_back(s);
+              }
+            }
+          }
+        }
+        panelSegEnd.push_back((int64_t)plan.segs.size());
       }
-      panelSegEnd.push_back((int64_t)plan.segs.size());
     }
     return count;
   };
@@ -340,15 +378,16 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         for (int32_t r = 0; r < pd.rowsBelow; r += kTile) plan.trsmTasks.push_back({pb.panel, r});
         for (int64_t s = panelSegBegin[pb.panel]; s < panelSegEnd[pb.panel]; s++) {
           const SegDesc& sd = plan.segs[s];
+          const SrcDesc& sr = plan.srcs[sd.src];
           const int32_t atomic = sd.kind == kSegBoard && hits[sd.tgtBase] > 1 ? 1 : 0;
           for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += kTile) {
-            for (int32_t rT = cT; rT < pd.rowsBelow; rT += kTile) {
+            for (int32_t rT = cT; rT < sr.rowsBelow; rT += kTile) {
               plan.updTasks.push_back({(int32_t)s, rT, cT, atomic});
             }
           }
-          const double R = double(pd.rowsBelow - sd.q0), m = double(sd.m);
+          const double R = double(sr.rowsBelow - sd.q0), m = double(sd.m);
           plan.updElems += m * R - m * (m - 1) / 2;
-          plan.updFlops += 2.0 * pd.nb * (m * R - m * (m - 1) / 2);
+          plan.updFlops += 2.0 * sr.K * (m * R - m * (m - 1) / 2);
         }
       }
       lr.panelEnd = (int64_t)plan.levelPanels.size();

@@ -20,7 +20,9 @@
 
 namespace BaSpaCho {
 
-constexpr int kPanelWidth = 64;   // max panel width nb (K of the update GEMM)
+constexpr int kPanelWidth = 64;   // max panel width nb (potrf/trsm granularity)
+constexpr int kOuterWidth = 256;  // outer block: panels update only their own outer block right
+                                  // away; everything to its right gets ONE rank-256 update
 constexpr int kTile = 64;         // update tile (rows x cols) and trsm row tile
 constexpr int kElimSmallMax = 16; // widest lump handled by the small sparse-elim kernels
 
@@ -34,10 +36,21 @@ struct PanelDesc {
   int32_t lump;
 };
 
+// source of a rank-K update: K consecutive columns of a lump and all the rows below them
+struct SrcDesc {
+  int64_t off;         // data offset of (first row below the source columns, first source column)
+  int32_t lda;         // row stride (= lump width)
+  int32_t K;           // number of source columns (<= kOuterWidth)
+  int32_t rowsBelow;   // rows below the source columns: nRest + chain rows of the lump
+  int32_t nRest;       // of which still inside the lump's own diagonal block
+  int32_t lumpRowBase; // as in PanelDesc
+  int32_t pad;
+};
+
 enum SegKind : int32_t { kSegIntra = 0, kSegBoard = 1 };
 
 struct SegDesc {
-  int32_t panel;
+  int32_t src;
   int32_t kind;
   int32_t q0;            // first below-row index covered by the segment's columns
   int32_t m;             // number of columns
@@ -99,6 +112,7 @@ struct HipPlanHost {
   std::vector<uint32_t> elimPairOffJ, elimPairOffI;
 
   std::vector<PanelDesc> panels;
+  std::vector<SrcDesc> srcs;
   std::vector<SegDesc> segs;
   std::vector<int64_t> chainOffTab;
   std::vector<int32_t> rowChain, rowLocal, rowColOff;  // per chain row of every dense lump

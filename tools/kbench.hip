@@ -46,12 +46,15 @@ int main(int argc, char** argv) {
 
   const int nb = 64;
   PanelDesc pd{}; pd.diagOff = (int64_t)c0 * n + c0; pd.lda = n; pd.nb = nb; pd.nRest = n - c0 - nb; pd.rowsBelow = pd.nRest; pd.lumpRowBase = 0; pd.lump = 0;
-  SegDesc sd{}; sd.panel = 0; sd.kind = kSegIntra; sd.q0 = 0; sd.m = pd.nRest; sd.tgtBase = (int64_t)(c0 + nb) * n + (c0 + nb); sd.tgtStride = n;
+  int K = argc > 3 ? atoi(argv[3]) : 64;  // source width of the update
+  SrcDesc sr{}; sr.off = pd.diagOff + (int64_t)nb * n - (K - nb); sr.lda = n; sr.K = K; sr.rowsBelow = pd.rowsBelow; sr.nRest = pd.nRest; sr.lumpRowBase = 0;
+  SegDesc sd{}; sd.src = 0; sd.kind = kSegIntra; sd.q0 = 0; sd.m = pd.nRest; sd.tgtBase = (int64_t)(c0 + nb) * n + (c0 + nb); sd.tgtStride = n;
   std::vector<TrsmTask> tt; for (int r = 0; r < pd.rowsBelow; r += kTile) tt.push_back({0, r});
   std::vector<UpdTask> ut;
   for (int cT = 0; cT < sd.m; cT += kTile) for (int rT = cT; rT < pd.rowsBelow; rT += kTile) ut.push_back({0, rT, cT, 0});
   std::vector<UpdTask> utA = ut; for (auto& t : utA) t.atomic = 1;
   int32_t lp = 0;
+  SrcDesc* dsr; CK(hipMalloc(&dsr, sizeof sr)); CK(hipMemcpy(dsr, &sr, sizeof sr, hipMemcpyHostToDevice));
   PanelDesc* dpd; SegDesc* dsd; TrsmTask* dtt; UpdTask* dut; UpdTask* dutA; int32_t* dlp;
   CK(hipMalloc(&dpd, sizeof pd)); CK(hipMemcpy(dpd, &pd, sizeof pd, hipMemcpyHostToDevice));
   CK(hipMalloc(&dsd, sizeof sd)); CK(hipMemcpy(dsd, &sd, sizeof sd, hipMemcpyHostToDevice));
@@ -67,10 +70,10 @@ int main(int argc, char** argv) {
   printf("potrfPanel        : %8.1f us\n", us);
   us = timeIt([&] { hipk::trsmPanel<double><<<(unsigned)tt.size(), 256>>>(dpd, dtt, ref); }, 50);
   printf("trsmPanel         : %8.1f us  (%zu tasks)\n", us, tt.size());
-  double updFlops = 0; { double R = pd.rowsBelow, m = sd.m; updFlops = 2.0 * nb * (m * R - m * (m - 1) / 2); }
-  us = timeIt([&] { hipk::updateTile<double><<<(unsigned)ut.size(), 256>>>(dpd, dsd, dut, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
+  double updFlops = 0; { double R = pd.rowsBelow, m = sd.m; updFlops = 2.0 * K * (m * R - m * (m - 1) / 2); }
+  us = timeIt([&] { hipk::updateTile<double><<<(unsigned)ut.size(), 256>>>(dsr, dsd, dut, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
   printf("updateTile plain  : %8.1f us  -> %.2f TF/s\n", us, updFlops / us / 1e6);
-  us = timeIt([&] { hipk::updateTile<double><<<(unsigned)ut.size(), 256>>>(dpd, dsd, dutA, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
+  us = timeIt([&] { hipk::updateTile<double><<<(unsigned)ut.size(), 256>>>(dsr, dsd, dutA, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
   printf("updateTile atomic : %8.1f us  -> %.2f TF/s\n", us, updFlops / us / 1e6);
   CK(hipDeviceSynchronize());
   return 0;
