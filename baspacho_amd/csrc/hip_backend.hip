@@ -5,6 +5,7 @@
 // per-lump host->device table uploads.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -118,9 +119,14 @@ struct LaunchTimer {
 
 struct HipSymbolicCtx : SymbolicCtx {
   HipSymbolicCtx(const CoalescedBlockMatrixSkel& skel_, const vector<int64_t>& permutation_)
-      : skel(skel_), permutation(permutation_) {}
+      : skel(skel_), permutation(permutation_) {
+    if (const char* e = std::getenv("BSP_NO_LOOKAHEAD")) lookaheadEnabled = e[0] == '0';
+  }
 
-  virtual ~HipSymbolicCtx() override {}
+  virtual ~HipSymbolicCtx() override {
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    if (side) (void)hipStreamDestroy(side);
+  }
 
   virtual void setSparseElimRanges(const vector<int64_t>& ranges) override {
     sparseElimRanges = ranges;
@@ -196,11 +202,30 @@ struct HipSymbolicCtx : SymbolicCtx {
   virtual SolveCtxBase* createSolveCtxForType(std::type_index tIdx, int nRHS,
                                               int batchSize) override;
 
+  // side stream + event pool of the lookahead schedule (created on first use)
+  hipStream_t sideStream() {
+    if (!side) hipCHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    return side;
+  }
+  hipEvent_t eventFromPool() {
+    if (nextEvent == events.size()) {
+      hipEvent_t e;
+      hipCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      events.push_back(e);
+    }
+    return events[nextEvent++];
+  }
+  void resetEventPool() { nextEvent = 0; }
+
   const CoalescedBlockMatrixSkel& skel;
   vector<int64_t> permutation;
   vector<int64_t> sparseElimRanges;
   hipStream_t stream = nullptr;
   HipKernelProfile* profile = nullptr;
+  bool lookaheadEnabled = true;
+  hipStream_t side = nullptr;
+  vector<hipEvent_t> events;
+  size_t nextEvent = 0;
 
   bool skelUploaded = false;
   DevBuf dSpanStart, dSpanToLump, dLumpStart, dSpanOffsetInLump, dChainColPtr, dChainRowSpan,
@@ -217,13 +242,26 @@ struct HipNumericCtx : NumericCtx<T> {
   // single matrix: pointer by value; batch: the device-pointer array is uploaded once per call
   hipk::DataRef<BT> makeRef(T* data);
 
+  void launchUpdate(DevPlan& plan, int64_t begin, int64_t end, hipk::DataRef<BT> ref,
+                    hipStream_t stream) {
+    hipk::updateTile<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, 0, stream>>>(
+        plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(), plan.updTasks.as<UpdTask>() + begin,
+        plan.chainOffTab.as<int64_t>(), plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(),
+        plan.rowColOff.as<int32_t>(), ref);
+  }
+
+  // One level = potrf -> trsm -> update on the execution stream.  Deferred (lookahead) tiles go to
+  // the side stream after the level's trsm and are joined back by events where the plan says so.
   void launchLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::DataRef<BT> ref,
                     LaunchTimer& timer) {
     const dim3 gy(1, (unsigned)batchSize, 1);
-    for (const LevelRange& lr : levels) {
+    const bool lookahead = sym.profile == nullptr && sym.lookaheadEnabled;
+    vector<hipEvent_t> defDone(levels.size(), nullptr);
+    bool sideUsed = false;
+    for (size_t li = 0; li < levels.size(); li++) {
+      const LevelRange& lr = levels[li];
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
-      const unsigned nU = (unsigned)(lr.updEnd - lr.updBegin);
       if (nP) {
         timer.begin(kProfPotrf);
         hipk::potrfPanel<BT><<<dim3(nP, gy.y), 256, 0, sym.stream>>>(
@@ -236,15 +274,34 @@ struct HipNumericCtx : NumericCtx<T> {
             plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin, ref);
         timer.end();
       }
-      if (nU) {
+      if (lookahead && lr.defEnd > lr.defBegin) {
+        // the deferred tiles read the freshly solved panels: fork after the trsm
+        hipEvent_t fork = sym.eventFromPool();
+        hipCHECK(hipEventRecord(fork, sym.stream));
+        hipCHECK(hipStreamWaitEvent(sym.sideStream(), fork, 0));
+        launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.sideStream());
+        defDone[li] = sym.eventFromPool();
+        hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
+        sideUsed = true;
+      }
+      if (lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
+        hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
+      }
+      if (lr.updEnd > lr.updBegin) {
         timer.begin(kProfUpdate);
-        hipk::updateTile<BT><<<dim3(nU, gy.y), 256, 0, sym.stream>>>(
-            plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(),
-            plan.updTasks.as<UpdTask>() + lr.updBegin, plan.chainOffTab.as<int64_t>(),
-            plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(), plan.rowColOff.as<int32_t>(),
-            ref);
+        launchUpdate(plan, lr.updBegin, lr.updEnd, ref, sym.stream);
         timer.end();
       }
+      if (!lookahead && lr.defEnd > lr.defBegin) {
+        timer.begin(kProfUpdate);
+        launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.stream);
+        timer.end();
+      }
+    }
+    if (sideUsed) {  // join: everything on the side stream happens-before what follows
+      hipEvent_t join = sym.eventFromPool();
+      hipCHECK(hipEventRecord(join, sym.sideStream()));
+      hipCHECK(hipStreamWaitEvent(sym.stream, join, 0));
     }
   }
 
@@ -292,6 +349,7 @@ struct HipNumericCtx : NumericCtx<T> {
     DevPlan& plan = sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
     hipk::DataRef<BT> ref = makeRef(data);
     LaunchTimer timer(sym.stream, sym.profile);
+    sym.resetEventPool();
     for (const ElimRangePlan& er : plan.host.elimRanges) launchElim(plan, er, ref, timer);
     launchLevels(plan, plan.host.levels, ref, timer);
     hipCHECK(hipGetLastError());
@@ -307,6 +365,7 @@ struct HipNumericCtx : NumericCtx<T> {
     DevPlan& plan = sym.planFor({lumpsBegin, lumpsEnd}, lumpsBegin, lumpsEnd, /*tag=*/1);
     hipk::DataRef<BT> ref = makeRef(data);
     LaunchTimer timer(sym.stream, sym.profile);
+    sym.resetEventPool();
     for (const ElimRangePlan& er : plan.host.elimRanges) launchElim(plan, er, ref, timer);
     hipCHECK(hipGetLastError());
     timer.finish();

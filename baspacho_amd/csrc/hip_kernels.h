@@ -32,6 +32,24 @@ __device__ __forceinline__ void waveSync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// 1/sqrt(x): hardware estimate (v_rsq_f64 / v_rsq_f32) refined by Newton steps to full precision.
+// The library rsqrt() expands to a full-precision sqrt plus a division (hundreds of dependent
+// cycles), which sits on the serial critical path of the panel Cholesky.
+__device__ __forceinline__ double fastRsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const double r = fma(-0.5 * x * y, y, 0.5);  // 0.5 - 0.5 x y^2
+    y = fma(y, r, y);
+  }
+  return y;
+}
+__device__ __forceinline__ float fastRsqrt(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  const float r = fmaf(-0.5f * x * y, y, 0.5f);
+  return fmaf(y, r, y);
+}
+
 __device__ __forceinline__ void atomicSub(double* p, double v) { unsafeAtomicAdd(p, -v); }
 __device__ __forceinline__ void atomicSub(float* p, float v) { unsafeAtomicAdd(p, -v); }
 
@@ -187,50 +205,32 @@ __global__ __launch_bounds__(256) void elimUpdate(SkelDev sk, const int32_t* cha
 // straight from HBM/L2 (each is |s| x n contiguous values).  Replaces the per-pair atomics of
 // sparse_elim_straight_kernel (MatOpsCuda.cu:235-331) for ranges whose blocks fit a wave.
 // ------------------------------------------------------------------------------------------
-template <typename T, int N>
-__device__ __forceinline__ T dotRows(const T* __restrict__ a, const T* __restrict__ b, int n) {
-  T s = T(0);
-  if (N > 0) {
-#pragma unroll
-    for (int k = 0; k < N; k++) s += a[k] * b[k];
-  } else {
-    for (int k = 0; k < n; k++) s += a[k] * b[k];
-  }
-  return s;
-}
-
-template <typename T, int N, int SLOTS>
-__device__ __forceinline__ void gatherAccumulate(const T* data, const uint32_t* offJ,
-                                                 const uint32_t* offI, int pairBegin, int pairEnd,
-                                                 int n, int lane, const int (&rowK)[4],
-                                                 const int (&colK)[4], T (&acc)[4]) {
-  for (int base = pairBegin; base < pairEnd; base += 64) {
-    const int cnt = min(64, pairEnd - base);
-    const uint32_t myJ = lane < cnt ? offJ[base + lane] : 0u;
-    const uint32_t myI = lane < cnt ? offI[base + lane] : 0u;
-#pragma unroll 2
-    for (int t = 0; t < cnt; t++) {
-      const T* Bj = data + (uint32_t)__builtin_amdgcn_readlane((int)myJ, t);
-      const T* Bi = data + (uint32_t)__builtin_amdgcn_readlane((int)myI, t);
-#pragma unroll
-      for (int s = 0; s < SLOTS; s++) acc[s] += dotRows<T, N>(Bj + rowK[s], Bi + colK[s], n);
-    }
-  }
-}
+constexpr int kGatherStage = 1024;  // staged values per wave (8 KB fp64)
+constexpr int kGatherLoads = 16;    // global loads in flight per lane and batch
 
 template <typename T>
 __global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, const uint32_t* offJ,
                                                   const uint32_t* offI, DataRef<T> dref,
                                                   int numItems) {
+  // The source blocks of a batch of pairs are fetched with one coalesced load per 64 values
+  // (a pair's two blocks are |sj| x n and |si| x n contiguous values), parked in this wave's LDS
+  // slice and consumed from there; the next batch is already in flight in registers while the
+  // current one is multiplied (the 8-byte per-lane operand fetches straight from L1 were
+  // address-unit bound).
+  __shared__ T stageAll[4][kGatherStage];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int idx = blockIdx.x * 4 + wave;
   if (idx >= numItems) return;
   const ElimGatherItem it = items[idx];
   T* data = pickData(dref);
+  T* stage = stageAll[wave];
   const int rows = it.rows, cols = it.cols, n = it.n;
   const int total = rows * cols;
-  // per-lane output elements e = lane + 64*s  ->  (r, q); offsets of the operand rows
+  const int EJ = rows * n, E = (rows + cols) * n;  // values per pair: B_j then B_i
+  const int loadsPerPair = (E + 63) >> 6;
+  const int batch = max(1, min(kGatherLoads / loadsPerPair, kGatherStage / E));
+  // per-lane output elements e = lane + 64*s  ->  (r, q)
   int rowK[4], colK[4], tgt[4];
   bool ok[4];
 #pragma unroll
@@ -240,18 +240,81 @@ __global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, c
     const int ee = ok[s] ? e : 0;
     const int r = ee / cols, q = ee - r * cols;
     rowK[s] = r * n;
-    colK[s] = q * n;
+    colK[s] = EJ + q * n;
     tgt[s] = r * it.tgtStride + q;
     if ((it.flags & 2) && q > r) ok[s] = false;  // diagonal target block: lower triangle only
   }
-  T acc[4] = {T(0), T(0), T(0), T(0)};
   const int slots = (total + 63) >> 6;
-  if (n == 3 && slots <= 2) {
-    gatherAccumulate<T, 3, 2>(data, offJ, offI, it.pairBegin, it.pairEnd, n, lane, rowK, colK, acc);
-  } else if (slots <= 2) {
-    gatherAccumulate<T, 0, 2>(data, offJ, offI, it.pairBegin, it.pairEnd, n, lane, rowK, colK, acc);
-  } else {
-    gatherAccumulate<T, 0, 4>(data, offJ, offI, it.pairBegin, it.pairEnd, n, lane, rowK, colK, acc);
+  T acc[4] = {T(0), T(0), T(0), T(0)};
+
+  for (int base = it.pairBegin; base < it.pairEnd; base += 64) {
+    const int cnt = min(64, it.pairEnd - base);
+    const uint32_t myJ = lane < cnt ? offJ[base + lane] : 0u;
+    const uint32_t myI = lane < cnt ? offI[base + lane] : 0u;
+    T v[kGatherLoads];
+    auto fetch = [&](int t0) {  // issue the loads of pairs [t0, t0+batch) of this group of 64
+#pragma unroll
+      for (int u = 0; u < kGatherLoads; u++) {
+        const int t = t0 + u / loadsPerPair;
+        const int e = (u % loadsPerPair) * 64 + lane;
+        const bool live = u < batch * loadsPerPair && t < cnt && e < E;
+        const int tt = min(t, cnt - 1);
+        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)myJ, tt);
+        const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)myI, tt);
+        const uint32_t off = e < EJ ? oj + e : oi + (e - EJ);
+        v[u] = live ? data[off] : T(0);
+      }
+    };
+    auto park = [&]() {
+#pragma unroll
+      for (int u = 0; u < kGatherLoads; u++) {
+        const int e = (u % loadsPerPair) * 64 + lane;
+        if (u < batch * loadsPerPair && e < E) stage[(u / loadsPerPair) * E + e] = v[u];
+      }
+    };
+    fetch(0);
+    park();
+    waveSync();
+    for (int t0 = 0; t0 < cnt; t0 += batch) {
+      const bool more = t0 + batch < cnt;
+      if (more) fetch(t0 + batch);
+      const int nb = min(batch, cnt - t0);
+      for (int t = 0; t < nb; t++) {
+        const T* blk = stage + t * E;
+        if (n == 3) {
+#pragma unroll
+          for (int sl = 0; sl < 2; sl++) {
+            const T* a = blk + rowK[sl];
+            const T* b = blk + colK[sl];
+            acc[sl] += a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+          }
+          if (slots > 2) {
+#pragma unroll
+            for (int sl = 2; sl < 4; sl++) {
+              const T* a = blk + rowK[sl];
+              const T* b = blk + colK[sl];
+              acc[sl] += a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int sl = 0; sl < 4; sl++) {
+            if (sl < slots) {
+              const T* a = blk + rowK[sl];
+              const T* b = blk + colK[sl];
+              T d = T(0);
+              for (int k = 0; k < n; k++) d += a[k] * b[k];
+              acc[sl] += d;
+            }
+          }
+        }
+      }
+      waveSync();
+      if (more) {
+        park();
+        waveSync();
+      }
+    }
   }
   T* target = data + it.tgtOff;
 #pragma unroll
@@ -271,17 +334,29 @@ __global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, c
 // workgroup per panel, whole block in LDS.  Replaces cusolverDn?potrf / potrfBatched
 // (MatOpsCuda.cu:508-548, 727-755) on the panel granularity.
 // ------------------------------------------------------------------------------------------
+#ifdef BSP_KDEBUG
+#define BSP_STAMP(slot) if (threadIdx.x == 0 && blockIdx.x == 0) bspDebugStamps[slot] = clock64()
+__device__ long long bspDebugStamps[16];
+#else
+#define BSP_STAMP(slot)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
                                                   const int32_t* levelPanels, DataRef<T> dref) {
+  BSP_STAMP(0);
   // Thread (i,g) = (tid/4, tid%4) keeps the 16 entries k = 4*kk+g of row i in registers, so the
   // quad of row i holds column block J (columns 4J..4J+3) in its registers a[J].  One step per
-  // 4-column pivot block (16 steps, one barrier each): the block is published through LDS
-  // (double buffered); every thread factors the 4x4 pivot redundantly, solves its own row and the
-  // rows k it needs against it, and applies the rank-4 update to its registers.  Branch-free
-  // (selects) apart from wave-uniform conditions.  Strictly-upper entries are carried as finite
-  // mirror values and never written back; rows/columns beyond nb are padded with the identity.
-  __shared__ T blk[2][kPanelWidth][4];
+  // 4-column pivot block (16 steps, two barriers each):
+  //   (1) the raw block is in LDS (raw[i][0..3]); every thread factors the 4x4 pivot redundantly,
+  //       solves its own row against it and publishes the solved row (sol[i][0..3]);
+  //   (2) every thread applies the rank-4 update  a[kk] -= <sol[i], sol[k]>  to its registers and
+  //       publishes the next raw column block.
+  // Branch-free (selects) apart from wave-uniform conditions.  Strictly-upper entries are carried
+  // as finite mirror values and never written back; rows/columns beyond nb are padded with the
+  // identity.
+  __shared__ T raw[kPanelWidth][4];
+  __shared__ T sol[kPanelWidth][4];
   const PanelDesc pd = panels[levelPanels[blockIdx.x]];
   T* A = pickData(dref) + pd.diagOff;
   const int nb = pd.nb, lda = pd.lda, tid = threadIdx.x;
@@ -294,32 +369,31 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
     const T v = A[(int64_t)iLd * lda + min(k, iLd)];
     a[kk] = (i < nb && k <= i) ? v : ((i >= nb && k == i) ? T(1) : T(0));
   }
-  blk[0][i][g] = a[0];
+  raw[i][g] = a[0];
   __syncthreads();
+  BSP_STAMP(1);
   const int nSteps = (nb + 3) >> 2;
 #pragma unroll 1
   for (int J = 0; J < nSteps; J++) {
-    const T(*cur)[4] = blk[J & 1];
-    T(*nxt)[4] = blk[(J + 1) & 1];
     const int j0 = 4 * J;
     // 4x4 pivot block (lower part), factored redundantly by every thread
-    const T p00 = cur[j0][0];
-    const T p10 = cur[j0 + 1][0], p11 = cur[j0 + 1][1];
-    const T p20 = cur[j0 + 2][0], p21 = cur[j0 + 2][1], p22 = cur[j0 + 2][2];
-    const T p30 = cur[j0 + 3][0], p31 = cur[j0 + 3][1], p32 = cur[j0 + 3][2], p33 = cur[j0 + 3][3];
-    const T i0 = rsqrt(p00);
+    const T p00 = raw[j0][0];
+    const T p10 = raw[j0 + 1][0], p11 = raw[j0 + 1][1];
+    const T p20 = raw[j0 + 2][0], p21 = raw[j0 + 2][1], p22 = raw[j0 + 2][2];
+    const T p30 = raw[j0 + 3][0], p31 = raw[j0 + 3][1], p32 = raw[j0 + 3][2], p33 = raw[j0 + 3][3];
+    const T r0 = raw[i][0], r1 = raw[i][1], r2 = raw[i][2], r3 = raw[i][3];
+    const T i0 = fastRsqrt(p00);
     const T l00 = p00 * i0, l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
     const T q11 = p11 - l10 * l10;
-    const T i1 = rsqrt(q11);
+    const T i1 = fastRsqrt(q11);
     const T l11 = q11 * i1, l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
     const T q22 = p22 - l20 * l20 - l21 * l21;
-    const T i2 = rsqrt(q22);
+    const T i2 = fastRsqrt(q22);
     const T l22 = q22 * i2, l32 = (p32 - l30 * l20 - l31 * l21) * i2;
     const T q33 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
-    const T i3 = rsqrt(q33);
+    const T i3 = fastRsqrt(q33);
     const T l33 = q33 * i3;
     // own row against the pivot
-    const T r0 = cur[i][0], r1 = cur[i][1], r2 = cur[i][2], r3 = cur[i][3];
     T c0 = r0 * i0;
     T c1 = (r1 - c0 * l10) * i1;
     T c2 = (r2 - c0 * l20 - c1 * l21) * i2;
@@ -338,28 +412,30 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
       for (int kk = 0; kk < 16; kk++) {
         if (kk == J) a[kk] = below ? solved : ((pivRow && g <= di) ? inPiv : a[kk]);
       }
+      // publish the solved row (zero for rows that take no further part)
+      sol[i][g] = below ? solved : T(0);
     }
     if (!below) c0 = c1 = c2 = c3 = T(0);
+    __syncthreads();
+    // straight-line on purpose (selects, no branches): all 32 LDS reads are issued up front
+    T nextRaw = T(0);
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-      if (kk > J) {  // wave-uniform
-        const int k = 4 * kk + g;
-        const T s0 = cur[k][0], s1 = cur[k][1], s2 = cur[k][2], s3 = cur[k][3];
-        const T d0 = s0 * i0;
-        const T d1 = (s1 - d0 * l10) * i1;
-        const T d2 = (s2 - d0 * l20 - d1 * l21) * i2;
-        const T d3 = (s3 - d0 * l30 - d1 * l31 - d2 * l32) * i3;
-        a[kk] -= c0 * d0 + c1 * d1 + c2 * d2 + c3 * d3;
-        if (kk == J + 1) nxt[i][g] = a[kk];  // publish the next column block
-      }
+    for (int kk = 1; kk < 16; kk++) {
+      const int k = 4 * kk + g;
+      const T upd = a[kk] - (c0 * sol[k][0] + c1 * sol[k][1] + c2 * sol[k][2] + c3 * sol[k][3]);
+      a[kk] = kk > J ? upd : a[kk];
+      nextRaw = kk == J + 1 ? a[kk] : nextRaw;
     }
+    raw[i][g] = nextRaw;  // publish the next raw column block
     __syncthreads();
   }
+  BSP_STAMP(2);
 #pragma unroll
   for (int kk = 0; kk < 16; kk++) {
     const int k = 4 * kk + g;
     if (i < nb && k <= i) A[(int64_t)i * lda + k] = a[kk];
   }
+  BSP_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -368,6 +444,30 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
 // that both the coalesced fill and the per-lane column walk are bank-conflict free).
 // Replaces cublas?trsm LEFT/UPPER/OP_C (MatOpsCuda.cu:550-566, 757-781).
 // ------------------------------------------------------------------------------------------
+// broadcast the value held by lane G of every quad (lanes 4q..4q+3) to the whole quad: one DPP
+// move per 32-bit half (quad_perm [G,G,G,G]) instead of a ds_bpermute round trip through LDS
+template <int G>
+__device__ __forceinline__ double quadBcast(double v) {
+  constexpr int ctrl = G | (G << 2) | (G << 4) | (G << 6);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int G>
+__device__ __forceinline__ float quadBcast(float v) {
+  constexpr int ctrl = G | (G << 2) | (G << 4) | (G << 6);
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true));
+}
+template <typename T>
+__device__ __forceinline__ T quadBcastSel(T v, int g) {  // g is a compile-time value after unrolling
+  switch (g) {
+    case 0: return quadBcast<0>(v);
+    case 1: return quadBcast<1>(v);
+    case 2: return quadBcast<2>(v);
+    default: return quadBcast<3>(v);
+  }
+}
+
 // body for panels of width <= NB (NB in {8,16,32,64}); thread (r,g) = (tid/4, tid%4) owns the
 // entries k = 8*m + 2*g + h (m < NB/8, h < 2) of row r in registers; the pivot value x_j is
 // broadcast inside the quad with a shuffle, L(k,j) comes from LDS.  Ls is zero above the diagonal
@@ -393,7 +493,7 @@ __device__ __forceinline__ void trsmRows(const T* __restrict__ Ls, const T* __re
   for (int j = 0; j < NB; j++) {
     const int mj = j >> 3, gj = (j >> 1) & 3, hj = j & 1;
     T xj = x[mj][hj] * invDiag[j];
-    xj = __shfl(xj, gj, 4);
+    xj = quadBcastSel(xj, gj);
 #pragma unroll
     for (int m = mj; m < M; m++) {
 #pragma unroll

@@ -228,6 +228,8 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
               SegDesc s{};
               s.src = srcIdx;
               s.kind = kSegIntra;
+              s.outer = 1;
+              s.lump = (int32_t)l;
               s.q0 = 0;
               s.m = sr.nRest;
               s.tgtBase = g.diagOff + blockEnd * n + blockEnd;
@@ -360,11 +362,15 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
 
   // ---- emit task lists level by level
   auto emitLevels = [&](const vector<vector<PanelBuild>>& buckets, vector<LevelRange>& out) {
+    std::map<int32_t, int64_t> lastDeferredLevel;  // lump -> level index that deferred tiles
     for (const auto& bucket : buckets) {
       LevelRange lr;
       lr.panelBegin = (int64_t)plan.levelPanels.size();
       lr.trsmBegin = (int64_t)plan.trsmTasks.size();
       lr.updBegin = (int64_t)plan.updTasks.size();
+      lr.waitDefLevel = -1;
+      const int64_t levelIdx = (int64_t)out.size();
+      vector<UpdTask> deferred;
       // how many panels of this level hit each target lump
       std::map<int64_t, int> hits;
       for (const auto& pb : bucket) {
@@ -380,11 +386,25 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           const SegDesc& sd = plan.segs[s];
           const SrcDesc& sr = plan.srcs[sd.src];
           const int32_t atomic = sd.kind == kSegBoard && hits[sd.tgtBase] > 1 ? 1 : 0;
+          if (sd.outer) {
+            // this block-wide update touches columns that the previous block's deferred tiles
+            // of the same lump also touch: they must have completed
+            auto it = lastDeferredLevel.find(sd.lump);
+            if (it != lastDeferredLevel.end()) lr.waitDefLevel = std::max(lr.waitDefLevel, it->second);
+          }
+          bool anyDeferred = false;
           for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += kTile) {
+            const bool defer = sd.outer && cT - sd.q0 >= kOuterWidth;
             for (int32_t rT = cT; rT < sr.rowsBelow; rT += kTile) {
-              plan.updTasks.push_back({(int32_t)s, rT, cT, atomic});
+              if (defer) {
+                deferred.push_back({(int32_t)s, rT, cT, atomic});
+                anyDeferred = true;
+              } else {
+                plan.updTasks.push_back({(int32_t)s, rT, cT, atomic});
+              }
             }
           }
+          if (anyDeferred) lastDeferredLevel[sd.lump] = levelIdx;
           const double R = double(sr.rowsBelow - sd.q0), m = double(sd.m);
           plan.updElems += m * R - m * (m - 1) / 2;
           plan.updFlops += 2.0 * sr.K * (m * R - m * (m - 1) / 2);
@@ -393,8 +413,31 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       lr.panelEnd = (int64_t)plan.levelPanels.size();
       lr.trsmEnd = (int64_t)plan.trsmTasks.size();
       lr.updEnd = (int64_t)plan.updTasks.size();
+      lr.defBegin = lr.updEnd;
+      plan.updTasks.insert(plan.updTasks.end(), deferred.begin(), deferred.end());
+      lr.defEnd = (int64_t)plan.updTasks.size();
+      // XCD-aware order: workgroup b lands on XCD b % 8 (observed dispatch; each XCD has its own
+      // L2), so hand every XCD a CONTIGUOUS run of the tile list (neighbouring tiles share
+      // operand rows) instead of every 8th tile.  Pure permutation: speed only.
+      auto xcdOrder = [&](int64_t begin, int64_t end) {
+        const int64_t cnt = end - begin;
+        if (cnt < 64) return;
+        vector<UpdTask> tmp(plan.updTasks.begin() + begin, plan.updTasks.begin() + end);
+        const int64_t base = cnt / 8, extra = cnt % 8;
+        int64_t chunkStart[9];
+        chunkStart[0] = 0;
+        for (int x = 0; x < 8; x++) chunkStart[x + 1] = chunkStart[x] + base + (x < extra ? 1 : 0);
+        for (int64_t p = 0; p < cnt; p++) {
+          const int64_t x = p % 8, k = p / 8;
+          // positions p with p%8 == x receive chunk x in order (chunk sizes match by construction)
+          plan.updTasks[begin + p] = tmp[chunkStart[x] + k];
+        }
+      };
+      xcdOrder(lr.updBegin, lr.updEnd);
+      xcdOrder(lr.defBegin, lr.defEnd);
       plan.maxPanelsInLevel = std::max<int64_t>(plan.maxPanelsInLevel, lr.panelEnd - lr.panelBegin);
-      plan.numLaunches += 1 + (lr.trsmEnd > lr.trsmBegin) + (lr.updEnd > lr.updBegin);
+      plan.numLaunches += 1 + (lr.trsmEnd > lr.trsmBegin) + (lr.updEnd > lr.updBegin) +
+                          (lr.defEnd > lr.defBegin);
       out.push_back(lr);
     }
   };

@@ -58,6 +58,8 @@ struct SegDesc {
   int32_t tgtStride;     // row stride of the target lump
   int32_t firstChainOrd; // board: below-diagonal chain ordinal of the segment's first chain
   int64_t chainTabPtr;   // board: index into chainOffTab of that chain's entry
+  int32_t outer;         // 1: source is a complete outer block (rank-kOuterWidth update)
+  int32_t lump;          // lump owning the source columns
 };
 
 struct UpdTask {
@@ -75,7 +77,14 @@ struct TrsmTask {
 struct LevelRange {
   int64_t panelBegin, panelEnd;  // into levelPanels
   int64_t trsmBegin, trsmEnd;    // into trsmTasks
-  int64_t updBegin, updEnd;      // into updTasks
+  int64_t updBegin, updEnd;      // into updTasks: tiles that must run before the next level
+  // LOOKAHEAD.  Tiles of a block-wide (rank-256) intra-lump update whose target columns lie
+  // beyond the NEXT outer block are not needed by the next 4 panels: they form the deferred list
+  // and may run on a second stream concurrently with the following levels.  They must be complete
+  // before the update launch of level `waitDefLevel`-consumers (see below).
+  int64_t defBegin, defEnd;      // into updTasks (deferred tiles of this level)
+  int64_t waitDefLevel;          // index (within the same level list) of the level whose deferred
+                                 // tiles must be complete before this level's update launch; -1
 };
 
 // One work item of the gather-form sparse-elimination update: a target block (sj,si) of the

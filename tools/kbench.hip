@@ -4,7 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#define BSP_KDEBUG 1
 #include "hip_kernels.h"
+__global__ void emptyKernel() {}
 using namespace BaSpaCho;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -68,6 +70,10 @@ int main(int argc, char** argv) {
   float us;
   us = timeIt([&] { hipk::potrfPanel<double><<<1, 256>>>(dpd, dlp, ref); }, 50);
   printf("potrfPanel        : %8.1f us\n", us);
+  { long long st[16]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(hipk::bspDebugStamps), sizeof st));
+    printf("   potrf cycles: load %lld, loop %lld, store %lld (total %lld = %.1f us @2.4GHz)\n", st[1]-st[0], st[2]-st[1], st[3]-st[2], st[3]-st[0], (st[3]-st[0])/2400.0); }
+  us = timeIt([&] { emptyKernel<<<1, 256>>>(); }, 200);
+  printf("empty kernel      : %8.1f us\n", us);
   us = timeIt([&] { hipk::trsmPanel<double><<<(unsigned)tt.size(), 256>>>(dpd, dtt, ref); }, 50);
   printf("trsmPanel         : %8.1f us  (%zu tasks)\n", us, tt.size());
   double updFlops = 0; { double R = pd.rowsBelow, m = sd.m; updFlops = 2.0 * K * (m * R - m * (m - 1) / 2); }
