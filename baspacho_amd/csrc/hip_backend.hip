@@ -11,6 +11,7 @@
 
 #include "hip_backend.h"
 #include "hip_kernels.h"
+#include "hip_solve_kernels.h"
 #include "mat_ops.h"
 
 namespace BaSpaCho {
@@ -60,7 +61,7 @@ struct DevBuf {
 struct DevPlan {
   HipPlanHost host;
   DevBuf panels, srcs, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
-      updTasks, elimChainLump, elimItems, elimPairOffJ, elimPairOffI;
+      updTasks, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal;
   void upload() {
     panels.upload(host.panels);
     srcs.upload(host.srcs);
@@ -69,6 +70,7 @@ struct DevPlan {
     rowChain.upload(host.rowChain);
     rowLocal.upload(host.rowLocal);
     rowColOff.upload(host.rowColOff);
+    rowGlobal.upload(host.rowGlobal);
     levelPanels.upload(host.levelPanels);
     trsmTasks.upload(host.trsmTasks);
     updTasks.upload(host.updTasks);
@@ -426,8 +428,103 @@ NumericCtxBase* HipSymbolicCtx::createNumericCtxForType(std::type_index tIdx, in
   return nullptr;
 }
 
-SolveCtxBase* HipSymbolicCtx::createSolveCtxForType(std::type_index, int, int) {
-  throw std::runtime_error("HIP backend: solve is not available yet in this build");
+// Triangular solves on the device, fused over a lump range (SolveCtx extension of mat_ops.h).
+template <typename T>
+struct HipSolveCtx : SolveCtx<T> {
+  HipSolveCtx(HipSymbolicCtx& sym_, int nRHS_) : sym(sym_), nRHS(nRHS_) {}
+
+  virtual bool hasFusedSolve() const override { return true; }
+
+  template <bool BACKWARD>
+  void elimRange(DevPlan& plan, const ElimRangePlan& er, const T* data, T* C, int64_t ldc) {
+    hipk::SkelDev sk = sym.skelDev();
+    const int64_t nLumps = er.lumpEnd - er.lumpBegin;
+    if (nLumps <= 0) return;
+    auto small = [&] {
+      hipk::solveElimSmall<T, BACKWARD><<<dim3((unsigned)((nLumps + 255) / 256), (unsigned)nRHS),
+                                         256, 0, sym.stream>>>(sk, data, C, ldc, er.lumpBegin,
+                                                               er.lumpEnd);
+    };
+    // lumps of a range are mutually independent: the order small/wide does not matter
+    if (!BACKWARD) {
+      small();
+      denseLevels<false>(plan, er.bigLevels, data, C, ldc);
+    } else {
+      denseLevels<true>(plan, er.bigLevels, data, C, ldc);
+      small();
+    }
+  }
+
+  template <bool BACKWARD>
+  void denseLevels(DevPlan& plan, const vector<LevelRange>& levels, const T* data, T* C,
+                   int64_t ldc) {
+    const int64_t nL = (int64_t)levels.size();
+    for (int64_t k = 0; k < nL; k++) {
+      const LevelRange& lr = levels[BACKWARD ? nL - 1 - k : k];
+      const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
+      const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
+      if (!nP) continue;
+      const dim3 gP(nP, (unsigned)nRHS), gT(nT, (unsigned)nRHS);
+      if (!BACKWARD) {
+        hipk::solveTriPanel<T, false><<<gP, 64, 0, sym.stream>>>(
+            plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, data, C, ldc);
+        if (nT) {
+          hipk::solveGemvL<T><<<gT, 256, 0, sym.stream>>>(
+              plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin,
+              plan.rowGlobal.as<int32_t>(), data, C, ldc);
+        }
+      } else {
+        if (nT) {
+          hipk::solveGemvLt<T><<<gT, 256, 0, sym.stream>>>(
+              plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin,
+              plan.rowGlobal.as<int32_t>(), data, C, ldc);
+        }
+        hipk::solveTriPanel<T, true><<<gP, 64, 0, sym.stream>>>(
+            plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, data, C, ldc);
+      }
+    }
+  }
+
+  virtual void solveLRange(const T* data, int64_t startLump, int64_t upToLump, T* C,
+                           int64_t ldc) override {
+    DevPlan& plan = sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
+    for (const ElimRangePlan& er : plan.host.elimRanges) elimRange<false>(plan, er, data, C, ldc);
+    denseLevels<false>(plan, plan.host.levels, data, C, ldc);
+    hipCHECK(hipGetLastError());
+  }
+
+  virtual void solveLtRange(const T* data, int64_t startLump, int64_t upToLump, T* C,
+                            int64_t ldc) override {
+    DevPlan& plan = sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
+    denseLevels<true>(plan, plan.host.levels, data, C, ldc);
+    for (auto it = plan.host.elimRanges.rbegin(); it != plan.host.elimRanges.rend(); ++it) {
+      elimRange<true>(plan, *it, data, C, ldc);
+    }
+    hipCHECK(hipGetLastError());
+  }
+
+  [[noreturn]] static void perOp(const char* what) {
+    throw std::runtime_error(std::string("HIP backend: per-op ") + what +
+                             " is not exposed; use solve()/solveL()/solveLt() (fused path)");
+  }
+  virtual void sparseElimSolveL(const SymElimCtx&, const T*, int64_t, int64_t, T*, int64_t) override { perOp("sparseElimSolveL"); }
+  virtual void sparseElimSolveLt(const SymElimCtx&, const T*, int64_t, int64_t, T*, int64_t) override { perOp("sparseElimSolveLt"); }
+  virtual void symm(const T*, int64_t, int64_t, const T*, int64_t, int64_t, T*, int64_t, BaseType<T>) override { perOp("symm"); }
+  virtual void solveL(const T*, int64_t, int64_t, T*, int64_t, int64_t) override { perOp("solveL"); }
+  virtual void gemv(const T*, int64_t, int64_t, int64_t, const T*, int64_t, int64_t, BaseType<T>) override { perOp("gemv"); }
+  virtual void assembleVec(int64_t, int64_t, T*, int64_t) override { perOp("assembleVec"); }
+  virtual void solveLt(const T*, int64_t, int64_t, T*, int64_t, int64_t) override { perOp("solveLt"); }
+  virtual void gemvT(const T*, int64_t, int64_t, int64_t, T*, int64_t, int64_t, BaseType<T>) override { perOp("gemvT"); }
+  virtual void assembleVecT(const T*, int64_t, int64_t, int64_t) override { perOp("assembleVecT"); }
+
+  HipSymbolicCtx& sym;
+  int nRHS;
+};
+
+SolveCtxBase* HipSymbolicCtx::createSolveCtxForType(std::type_index tIdx, int nRHS, int) {
+  if (tIdx == std::type_index(typeid(double))) return new HipSolveCtx<double>(*this, nRHS);
+  if (tIdx == std::type_index(typeid(float))) return new HipSolveCtx<float>(*this, nRHS);
+  throw std::runtime_error("HIP backend: batched solve is not available yet");
 }
 
 struct HipOps : Ops {

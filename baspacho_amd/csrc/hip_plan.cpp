@@ -192,6 +192,8 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         pd.rowsBelow = (int32_t)(pd.nRest + g.rowsBelow);
         pd.lumpRowBase = lumpRowBase;
         pd.lump = (int32_t)l;
+        pd.vecOff = (int32_t)(sk.lumpStart[l] + c0);
+        pd.pad = 0;
         plan.panels.push_back(pd);
         panelSegBegin.push_back((int64_t)plan.segs.size());
         const int64_t innerCols = blockEnd - c0 - nb;
@@ -251,6 +253,22 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     return count;
   };
 
+  // ---- helper: per-row lookup arrays of the below-diagonal rows of a lump
+  auto appendLumpRows = [&](int64_t, const LumpCols& g) {
+    const int64_t belowChain0 = g.chain0 + g.diagChains;
+    for (int64_t c = belowChain0; c < g.chain0 + g.nChains; c++) {
+      const int64_t span = sk.chainRowSpan[c];
+      const int64_t rows = sk.spanStart[span + 1] - sk.spanStart[span];
+      for (int64_t i = 0; i < rows; i++) {
+        plan.rowChain.push_back((int32_t)(c - belowChain0));
+        plan.rowLocal.push_back((int32_t)i);
+        plan.rowColOff.push_back((int32_t)(sk.spanOffsetInLump[span] + i));
+        plan.rowGlobal.push_back((int32_t)(sk.spanStart[span] + i));
+      }
+    }
+    BASPACHO_CHECK_LT((int64_t)plan.rowChain.size(), (int64_t)INT32_MAX);
+  };
+
   // ---- sparse-elimination ranges inside [startLump, upToLump)
   vector<vector<vector<PanelBuild>>> elimBigBuckets;
   for (size_t r = 0; r + 1 < elimRangesIn.size(); r++) {
@@ -288,7 +306,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                     double(g.rowsBelow) * g.rowsBelow * g.width;
       if (g.width > kElimSmallMax) {
         const int32_t first = (int32_t)plan.panels.size();
-        int32_t n = addPanels(l, g, 0, /*withBoards=*/false, {});
+        const int32_t rowBase = (int32_t)plan.rowChain.size();
+        appendLumpRows(l, g);
+        int32_t n = addPanels(l, g, rowBase, /*withBoards=*/false, {});
         for (int32_t j = 0; j < n; j++) bucketAt(big, j).push_back({first + j, j});
       }
     }
@@ -309,16 +329,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     // per-row lookup arrays of the below-diagonal rows
     const int32_t lumpRowBase = (int32_t)plan.rowChain.size();
     const int64_t belowChain0 = g.chain0 + g.diagChains;
-    for (int64_t c = belowChain0; c < g.chain0 + g.nChains; c++) {
-      const int64_t span = sk.chainRowSpan[c];
-      const int64_t rows = sk.spanStart[span + 1] - sk.spanStart[span];
-      for (int64_t i = 0; i < rows; i++) {
-        plan.rowChain.push_back((int32_t)(c - belowChain0));
-        plan.rowLocal.push_back((int32_t)i);
-        plan.rowColOff.push_back((int32_t)(sk.spanOffsetInLump[span] + i));
-      }
-    }
-    BASPACHO_CHECK_LT((int64_t)plan.rowChain.size(), (int64_t)INT32_MAX);
+    appendLumpRows(l, g);
 
     // one segment template per off-diagonal board (q0 relative to the first chain row)
     vector<SegDesc> boardSegs;

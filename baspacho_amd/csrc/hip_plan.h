@@ -34,6 +34,8 @@ struct PanelDesc {
   int32_t nRest;       // rows that still belong to the lump's own diagonal block
   int32_t lumpRowBase; // index of the lump's first chain row in the rowChain/rowLocal/rowColOff arrays
   int32_t lump;
+  int32_t vecOff;      // row index (in the full matrix) of the panel's first column
+  int32_t pad;
 };
 
 // source of a rank-K update: K consecutive columns of a lump and all the rows below them
@@ -125,6 +127,7 @@ struct HipPlanHost {
   std::vector<SegDesc> segs;
   std::vector<int64_t> chainOffTab;
   std::vector<int32_t> rowChain, rowLocal, rowColOff;  // per chain row of every dense lump
+  std::vector<int32_t> rowGlobal;                      // ... and its row index in the full matrix
 
   std::vector<int32_t> levelPanels;
   std::vector<TrsmTask> trsmTasks;
