@@ -287,6 +287,12 @@ class Solver:
             _check(getattr(self._lib, "bsp_factor_" + _suffix(data))(
                 self._h, ctypes.c_void_p(_ptr_of(data))))
 
+    def factorPerOp(self, data):
+        """TESTING: factor() through the per-op NumericCtx boundary in the reference's call order"""
+        self._check_data(data)
+        _check(getattr(self._lib, "bsp_factor_per_op_" + _suffix(data))(
+            self._h, ctypes.c_void_p(_ptr_of(data))))
+
     def factorUpTo(self, data, span_index):
         self._check_data(data)
         _check(getattr(self._lib, "bsp_factor_up_to_" + _suffix(data))(

@@ -217,6 +217,29 @@ int bsp_factor_from_f32(bsp_solver* s, float* d, int64_t span) {
 }
 
 template <typename T>
+static void factorPerOp(bsp_solver* s, T* d) {
+  SymbolicCtx& sym = s->solver->internalSymbolicContext();
+  hipBackendForcePerOp(sym, true);
+  try {
+    s->solver->factor(d);
+  } catch (...) {
+    hipBackendForcePerOp(sym, false);
+    throw;
+  }
+  hipBackendForcePerOp(sym, false);
+}
+int bsp_factor_per_op_f64(bsp_solver* s, double* d) {
+  BSP_TRY
+  factorPerOp(s, d);
+  BSP_CATCH
+}
+int bsp_factor_per_op_f32(bsp_solver* s, float* d) {
+  BSP_TRY
+  factorPerOp(s, d);
+  BSP_CATCH
+}
+
+template <typename T>
 static void doElim(bsp_solver* s, T* d, int64_t idx) {
   const auto& ranges = s->solver->sparseEliminationRanges();
   BASPACHO_CHECK(idx >= 0 && idx + 1 < (int64_t)ranges.size());

@@ -33,6 +33,10 @@ struct HipPlanStats {
 // the execution stream and accumulated per kernel class (factor calls then synchronise)
 void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof);
 
+// TESTING: make factor() take the reference-style per-op loop (potrf/trsm/saveSyrkGemm/
+// prepareAssemble/assemble/doElimination virtuals) instead of the fused path
+void hipBackendForcePerOp(SymbolicCtx& sym, bool on);
+
 HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t upToLump);
 
 }  // namespace BaSpaCho

@@ -225,6 +225,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   hipStream_t stream = nullptr;
   HipKernelProfile* profile = nullptr;
   bool lookaheadEnabled = true;
+  bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
   hipStream_t side = nullptr;
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
@@ -239,17 +240,18 @@ template <typename T>
 struct HipNumericCtx : NumericCtx<T> {
   using BT = BaseType<T>;
 
-  HipNumericCtx(HipSymbolicCtx& sym_, int batchSize_) : sym(sym_), batchSize(batchSize_) {}
+  HipNumericCtx(HipSymbolicCtx& sym_, int batchSize_, int64_t tempBufSize_)
+      : sym(sym_), batchSize(batchSize_), tempBufSize(std::max<int64_t>(tempBufSize_, 1)) {}
 
   // single matrix: pointer by value; batch: the device-pointer array is uploaded once per call
   hipk::DataRef<BT> makeRef(T* data);
 
   void launchUpdate(DevPlan& plan, int64_t begin, int64_t end, hipk::DataRef<BT> ref,
-                    hipStream_t stream) {
+                    hipStream_t stream, BT* altTarget = nullptr, int64_t altStride = 0) {
     hipk::updateTile<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, 0, stream>>>(
         plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(), plan.updTasks.as<UpdTask>() + begin,
         plan.chainOffTab.as<int64_t>(), plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(),
-        plan.rowColOff.as<int32_t>(), ref);
+        plan.rowColOff.as<int32_t>(), ref, altTarget, altStride);
   }
 
   // One level = potrf -> trsm -> update on the execution stream.  Deferred (lookahead) tiles go to
@@ -345,7 +347,7 @@ struct HipNumericCtx : NumericCtx<T> {
     }
   }
 
-  virtual bool hasFusedFactor() const override { return true; }
+  virtual bool hasFusedFactor() const override { return !sym.forcePerOp; }
 
   virtual void factorRange(T* data, int64_t startLump, int64_t upToLump) override {
     DevPlan& plan = sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
@@ -373,26 +375,100 @@ struct HipNumericCtx : NumericCtx<T> {
     timer.finish();
   }
 
-  // The per-op entry points of the boundary are served by the fused path in this backend.
-  [[noreturn]] static void perOpUnsupported(const char* what) {
-    throw std::runtime_error(std::string("HIP backend: per-op ") + what +
-                             " is not exposed; use factor()/factorUpTo()/factorFrom() (fused "
-                             "level-scheduled path) or doElimination()");
+  // ---- per-op boundary (MatOps.h:113-136).  factor() never goes through these (fused path); they
+  // exist so that a driver written against the reference's NumericCtx -- e.g. the per-op loop of
+  // Solver.cpp:198-218, kept in solver.cpp -- runs on this backend op by op.  Each call builds a
+  // one-off device plan: correct, not fast.
+  DevPlan& adoptPlan(HipPlanHost&& host) {
+    opPlans.emplace_back(new DevPlan);
+    opPlans.back()->host = std::move(host);
+    opPlans.back()->upload();
+    return *opPlans.back();
   }
-  virtual void pseudoFactorSpans(T*, int64_t, int64_t) override { perOpUnsupported("pseudoFactorSpans"); }
-  virtual void potrf(int64_t, T*, int64_t) override { perOpUnsupported("potrf"); }
-  virtual void trsm(int64_t, int64_t, T*, int64_t, int64_t) override { perOpUnsupported("trsm"); }
-  virtual void saveSyrkGemm(int64_t, int64_t, int64_t, const T*, int64_t) override {
-    perOpUnsupported("saveSyrkGemm");
+
+  virtual void potrf(int64_t n, T* data, int64_t offA) override {
+    sym.potrfBiggestN = std::max(sym.potrfBiggestN, n);
+    DevPlan& plan = adoptPlan(buildDenseOpPlan(n, 0, offA, /*potrfOnly=*/true));
+    LaunchTimer timer(sym.stream, nullptr);
+    const bool la = sym.lookaheadEnabled;
+    sym.lookaheadEnabled = false;
+    launchLevels(plan, plan.host.levels, makeRef(data), timer);
+    sym.lookaheadEnabled = la;
+    hipCHECK(hipGetLastError());
   }
-  virtual void prepareAssemble(int64_t) override { perOpUnsupported("prepareAssemble"); }
-  virtual void assemble(T*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t) override {
-    perOpUnsupported("assemble");
+
+  virtual void trsm(int64_t n, int64_t k, T* data, int64_t offA, int64_t offB) override {
+    // every caller on the factor path passes the rows that directly follow the diagonal block
+    // (Solver.cpp:43-64); the blocked solve relies on that contiguity
+    BASPACHO_CHECK_EQ(offB, offA + n * n);
+    DevPlan& plan = adoptPlan(buildDenseOpPlan(n, k, offA, /*potrfOnly=*/false));
+    LaunchTimer timer(sym.stream, nullptr);
+    const bool la = sym.lookaheadEnabled;
+    sym.lookaheadEnabled = false;
+    launchLevels(plan, plan.host.levels, makeRef(data), timer);
+    sym.lookaheadEnabled = la;
+    hipCHECK(hipGetLastError());
+  }
+
+  virtual void saveSyrkGemm(int64_t m, int64_t n, int64_t k, const T* data, int64_t offset) override {
+    BASPACHO_CHECK_LE(m * n, tempBufSize);
+    temp.resize((size_t)(tempBufSize * batchSize) * sizeof(BT));
+    hipCHECK(hipMemsetAsync(temp.ptr, 0, (size_t)(tempBufSize * batchSize) * sizeof(BT), sym.stream));
+    HipPlanHost host;
+    SrcDesc sr{};
+    sr.off = offset;
+    sr.lda = (int32_t)k;
+    sr.K = (int32_t)k;
+    sr.rowsBelow = (int32_t)n;
+    sr.nRest = (int32_t)n;
+    host.srcs.push_back(sr);
+    SegDesc sd{};
+    sd.src = 0;
+    sd.kind = kSegIntra;
+    sd.q0 = 0;
+    sd.m = (int32_t)m;
+    sd.tgtBase = 0;
+    sd.tgtStride = (int32_t)m;
+    host.segs.push_back(sd);
+    for (int32_t cT = 0; cT < m; cT += kTile) {
+      for (int32_t rT = cT; rT < n; rT += kTile) host.updTasks.push_back({0, rT, cT, 0});
+    }
+    DevPlan& plan = adoptPlan(std::move(host));
+    sym.gemmCalls++;
+    // temp := -(P P^T) on the lower trapezoid (the strictly upper part of the leading m x m block
+    // "doesn't matter", MatOps.h:129); assemble() adds it
+    launchUpdate(plan, 0, (int64_t)plan.host.updTasks.size(), makeRef(const_cast<T*>(data)),
+                 sym.stream, temp.as<BT>() ? const_cast<BT*>(temp.as<BT>()) : nullptr, tempBufSize);
+    hipCHECK(hipGetLastError());
+  }
+
+  virtual void prepareAssemble(int64_t targetLump) override {
+    hipk::SkelDev sk = sym.skelDev();
+    spanToChainOffset.resize((size_t)(sym.skel.numSpans() + 1) * sizeof(int64_t));
+    const int64_t n = sym.skel.chainColPtr[targetLump + 1] - sym.skel.chainColPtr[targetLump];
+    hipk::prepareAssembleKernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, sym.stream>>>(
+        sk, reinterpret_cast<int64_t*>(spanToChainOffset.ptr), targetLump);
+  }
+
+  virtual void assemble(T* data, int64_t rectRowBegin, int64_t dstStride, int64_t srcColDataOffset,
+                        int64_t srcRectWidth, int64_t numBlockRows, int64_t numBlockCols) override {
+    hipk::SkelDev sk = sym.skelDev();
+    hipk::assembleKernel<BT><<<dim3((unsigned)numBlockRows, (unsigned)batchSize), 256, 0, sym.stream>>>(
+        sk, spanToChainOffset.as<int64_t>(), temp.as<BT>(), tempBufSize, makeRef(data),
+        rectRowBegin, dstStride, srcColDataOffset, srcRectWidth, numBlockRows, numBlockCols);
+    hipCHECK(hipGetLastError());
+  }
+
+  virtual void pseudoFactorSpans(T*, int64_t, int64_t) override {
+    throw std::runtime_error("HIP backend: pseudoFactorSpans is not on the factor() path and is "
+                             "not available (SURVEY.md section 8f)");
   }
 
   HipSymbolicCtx& sym;
   int batchSize;
-  DevBuf devPtrs;
+  int64_t tempBufSize = 0;
+  DevBuf devPtrs, temp, spanToChainOffset;
+  vector<std::unique_ptr<DevPlan>> opPlans;
 };
 
 template <>
@@ -416,14 +492,15 @@ hipk::DataRef<float> HipNumericCtx<vector<float*>>::makeRef(vector<float*>* data
   return {nullptr, devPtrs.as<float*>()};
 }
 
-NumericCtxBase* HipSymbolicCtx::createNumericCtxForType(std::type_index tIdx, int64_t, int batch) {
-  if (tIdx == std::type_index(typeid(double))) return new HipNumericCtx<double>(*this, 1);
-  if (tIdx == std::type_index(typeid(float))) return new HipNumericCtx<float>(*this, 1);
+NumericCtxBase* HipSymbolicCtx::createNumericCtxForType(std::type_index tIdx, int64_t tempSize,
+                                                        int batch) {
+  if (tIdx == std::type_index(typeid(double))) return new HipNumericCtx<double>(*this, 1, tempSize);
+  if (tIdx == std::type_index(typeid(float))) return new HipNumericCtx<float>(*this, 1, tempSize);
   if (tIdx == std::type_index(typeid(vector<double*>))) {
-    return new HipNumericCtx<vector<double*>>(*this, batch);
+    return new HipNumericCtx<vector<double*>>(*this, batch, tempSize);
   }
   if (tIdx == std::type_index(typeid(vector<float*>))) {
-    return new HipNumericCtx<vector<float*>>(*this, batch);
+    return new HipNumericCtx<vector<float*>>(*this, batch, tempSize);
   }
   return nullptr;
 }
@@ -537,6 +614,12 @@ struct HipOps : Ops {
 }  // namespace
 
 OpsPtr hipOps() { return OpsPtr(new HipOps); }
+
+void hipBackendForcePerOp(SymbolicCtx& sym, bool on) {
+  HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
+  BASPACHO_CHECK_NOTNULL(h);
+  h->forcePerOp = on;
+}
 
 void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof) {
   HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);

@@ -591,7 +591,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const SegDesc* segs,
                                                   const UpdTask* tasks, const int64_t* chainOffTab,
                                                   const int32_t* rowChain, const int32_t* rowLocal,
-                                                  const int32_t* rowColOff, DataRef<T> dref) {
+                                                  const int32_t* rowColOff, DataRef<T> dref,
+                                                  T* altTarget = nullptr, int64_t altStride = 0) {
+  // altTarget: write the (negated) product into a separate buffer instead of `data`
+  // (per-op saveSyrkGemm: the frontal temp buffer, one slice per batch entry)
   constexpr int LD = kPanelWidth + 2;
   __shared__ T As[kTile * LD];
   __shared__ T Bs[kTile * LD];
@@ -695,6 +698,7 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
     // flight together), then subtract and store -- a read-modify-write per element would
     // serialise 16 memory round trips.
     const Acc* accs[4] = {&acc00, &acc01, &acc10, &acc11};
+    T* tbase = altTarget ? altTarget + (int64_t)blockIdx.y * altStride : data;
     T* ptr[16];
     bool ok[16];
 #pragma unroll
@@ -707,8 +711,8 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
       for (int reg = 0; reg < 4; reg++) {
         const int rIn = r0 + Mfma<T>::row(lane, reg);
         const int qr = task.rowTile + rIn;
-        ok[t * 4 + reg] = qc < segEnd && qr < pd.rowsBelow && qr >= qc;
-        ptr[t * 4 + reg] = data + rowBase[rIn] + co;
+        ok[t * 4 + reg] = qc < segEnd && qr < pd.rowsBelow && qr >= qc && qr >= sd.rowMin;
+        ptr[t * 4 + reg] = tbase + rowBase[rIn] + co;
       }
     }
     if (task.atomic) {
@@ -731,6 +735,46 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
         }
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-op boundary (NumericCtx::prepareAssemble / assemble, MatOps.h:132-135).  The fused path never
+// uses these; they let the reference's own driver loop (Solver.cpp:198-218) run on this backend.
+// ------------------------------------------------------------------------------------------
+__global__ void prepareAssembleKernel(SkelDev sk, int64_t* spanToChainOffset, int64_t targetLump) {
+  const int64_t i = sk.chainColPtr[targetLump] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < sk.chainColPtr[targetLump + 1]) spanToChainOffset[sk.chainRowSpan[i]] = sk.chainData[i];
+}
+
+// target column -= frontal product; `negTemp` holds MINUS the product (see saveSyrkGemm), hence +=.
+// One workgroup per block row r; block columns c <= r (MatOpsRef.cpp:144-175).
+template <typename T>
+__global__ __launch_bounds__(256) void assembleKernel(SkelDev sk, const int64_t* spanToChainOffset,
+                                                      const T* negTemp, int64_t tempStride,
+                                                      DataRef<T> dref, int64_t rectRowBegin,
+                                                      int64_t dstStride, int64_t srcColDataOffset,
+                                                      int64_t srcRectWidth, int64_t numBlockRows,
+                                                      int64_t numBlockCols) {
+  const int64_t r = blockIdx.x;
+  T* data = pickData(dref);
+  const T* temp = negTemp + (int64_t)blockIdx.y * tempStride;
+  const int64_t* cre = sk.chainRowsTillEnd + srcColDataOffset;
+  const int64_t* toSpan = sk.chainRowSpan + srcColDataOffset;
+  const int64_t rBegin = cre[r - 1] - rectRowBegin;
+  const int64_t rSize = cre[r] - rBegin - rectRowBegin;
+  const int64_t rOffset = spanToChainOffset[toSpan[r]];
+  const int64_t cEnd = numBlockCols < r + 1 ? numBlockCols : r + 1;
+  // all block columns 0..cEnd-1 are contiguous columns [0, colsTotal) of the frontal rectangle
+  const int64_t colsTotal = cre[cEnd - 1] - rectRowBegin;
+  for (int64_t e = threadIdx.x; e < rSize * colsTotal; e += blockDim.x) {
+    const int64_t j = e / colsTotal, col = e - j * colsTotal;
+    // block column of `col`
+    int64_t c = 0;
+    while (cre[c] - rectRowBegin <= col) c++;
+    const int64_t cStart = cre[c - 1] - rectRowBegin;
+    T* dst = data + rOffset + sk.spanOffsetInLump[toSpan[c]] + j * dstStride + (col - cStart);
+    *dst += temp[(rBegin + j) * srcRectWidth + col];
   }
 }
 

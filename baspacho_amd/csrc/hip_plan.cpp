@@ -466,4 +466,75 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
   return plan;
 }
 
+HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly) {
+  HipPlanHost plan;
+  BASPACHO_CHECK_LT(n + k, (int64_t)INT32_MAX);
+  const int64_t rowsB = potrfOnly ? 0 : k;
+  for (int64_t blockStart = 0; blockStart < n; blockStart += kOuterWidth) {
+    const int64_t blockEnd = std::min<int64_t>(n, blockStart + kOuterWidth);
+    for (int64_t c0 = blockStart; c0 < blockEnd; c0 += kPanelWidth) {
+      const int32_t nb = (int32_t)std::min<int64_t>(kPanelWidth, blockEnd - c0);
+      LevelRange lr{};
+      lr.waitDefLevel = -1;
+      PanelDesc pd{};
+      pd.diagOff = offA + c0 * n + c0;
+      pd.lda = (int32_t)n;
+      pd.nb = nb;
+      pd.nRest = (int32_t)(n - c0 - nb);
+      pd.rowsBelow = (int32_t)(pd.nRest + rowsB);
+      const int32_t pIdx = (int32_t)plan.panels.size();
+      plan.panels.push_back(pd);
+      const int32_t rowMin = potrfOnly ? 0 : pd.nRest;  // trsm: only the k rows are touched
+      lr.panelBegin = (int64_t)plan.levelPanels.size();
+      if (potrfOnly) plan.levelPanels.push_back(pIdx);
+      lr.panelEnd = (int64_t)plan.levelPanels.size();
+      lr.trsmBegin = (int64_t)plan.trsmTasks.size();
+      for (int32_t r = rowMin; r < pd.rowsBelow; r += kTile) plan.trsmTasks.push_back({pIdx, r});
+      lr.trsmEnd = (int64_t)plan.trsmTasks.size();
+      lr.updBegin = (int64_t)plan.updTasks.size();
+      auto addSeg = [&](const SrcDesc& sr, int64_t cols, int64_t tgtBase) {
+        plan.srcs.push_back(sr);
+        SegDesc sd{};
+        sd.src = (int32_t)plan.srcs.size() - 1;
+        sd.kind = kSegIntra;
+        sd.q0 = 0;
+        sd.m = (int32_t)cols;
+        sd.tgtBase = tgtBase;
+        sd.tgtStride = (int32_t)n;
+        sd.rowMin = potrfOnly ? 0 : sr.nRest;
+        plan.segs.push_back(sd);
+        const int32_t s = (int32_t)plan.segs.size() - 1;
+        for (int32_t cT = 0; cT < sd.m; cT += kTile) {
+          for (int32_t rT = cT; rT < sr.rowsBelow; rT += kTile) {
+            if (rT + kTile > sd.rowMin) plan.updTasks.push_back({s, rT, cT, 0});
+          }
+        }
+      };
+      const int64_t innerCols = blockEnd - c0 - nb;
+      if (innerCols > 0 && pd.rowsBelow > 0) {
+        SrcDesc sr{};
+        sr.off = pd.diagOff + (int64_t)nb * n;
+        sr.lda = (int32_t)n;
+        sr.K = nb;
+        sr.rowsBelow = pd.rowsBelow;
+        sr.nRest = pd.nRest;
+        addSeg(sr, innerCols, offA + (c0 + nb) * n + (c0 + nb));
+      }
+      if (c0 + nb == blockEnd && n - blockEnd > 0) {
+        SrcDesc sr{};
+        sr.off = offA + blockEnd * n + blockStart;
+        sr.lda = (int32_t)n;
+        sr.K = (int32_t)(blockEnd - blockStart);
+        sr.nRest = (int32_t)(n - blockEnd);
+        sr.rowsBelow = (int32_t)(sr.nRest + rowsB);
+        addSeg(sr, n - blockEnd, offA + blockEnd * n + blockEnd);
+      }
+      lr.updEnd = (int64_t)plan.updTasks.size();
+      lr.defBegin = lr.defEnd = lr.updEnd;
+      plan.levels.push_back(lr);
+    }
+  }
+  return plan;
+}
+
 }  // namespace BaSpaCho

@@ -62,6 +62,8 @@ struct SegDesc {
   int64_t chainTabPtr;   // board: index into chainOffTab of that chain's entry
   int32_t outer;         // 1: source is a complete outer block (rank-kOuterWidth update)
   int32_t lump;          // lump owning the source columns
+  int32_t rowMin;        // rows (below-row index) smaller than this are left untouched
+  int32_t pad;
 };
 
 struct UpdTask {
@@ -150,5 +152,11 @@ struct HipPlanHost {
 HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& skel,
                          const std::vector<int64_t>& sparseElimRanges, int64_t startLump,
                          int64_t upToLump);
+
+// Plan of ONE dense operation of the per-op boundary (NumericCtx::potrf / trsm, MatOps.h:124-127)
+// on a row-major n x n block at offA followed (contiguously, as in Solver::factorLump,
+// Solver.cpp:42-64) by k rows: potrfOnly -> Cholesky of the block, rows below untouched;
+// otherwise -> the k rows are solved against the already factored block.
+HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly);
 
 }  // namespace BaSpaCho

@@ -125,6 +125,11 @@ int bsp_factor_up_to_f64(bsp_solver* s, double* dev_data, int64_t span_index);
 int bsp_factor_from_f64(bsp_solver* s, double* dev_data, int64_t span_index);
 int bsp_factor_up_to_f32(bsp_solver* s, float* dev_data, int64_t span_index);
 int bsp_factor_from_f32(bsp_solver* s, float* dev_data, int64_t span_index);
+/* TESTING: Solver::factor driven op by op through the reference's NumericCtx boundary
+   (potrf / trsm / saveSyrkGemm / prepareAssemble / assemble / doElimination, MatOps.h:113-136)
+   in the reference's call order (Solver.cpp:164-219) instead of the fused path */
+int bsp_factor_per_op_f64(bsp_solver* s, double* dev_data);
+int bsp_factor_per_op_f32(bsp_solver* s, float* dev_data);
 /* TESTING hook of the reference: numCtx->doElimination(solver.internalGetElimCtx(i), ...)
    (Solver.h:139-145, tests/FactorTest.cpp:158-160) */
 int bsp_do_elimination_f64(bsp_solver* s, double* dev_data, int64_t elim_range_index);

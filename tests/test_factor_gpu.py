@@ -238,3 +238,41 @@ def test_errors_are_loud():
         sol.factor(torch.zeros(sol.dataSize(), dtype=torch.float64))  # host memory
     with pytest.raises(RuntimeError):
         B.create_solver(B.Settings(backend=B.BackendFast), ps, ss)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_per_op_boundary_drives_reference_loop(dtype):
+    """the reference's driver loop (Solver.cpp:164-219: doElimination, then per target lump
+    prepareAssemble / saveSyrkGemm+assemble per board / potrf / trsm) executed op by op through
+    the NumericCtx boundary of the HIP backend; must equal the dense Cholesky and the fused path"""
+    for i in range(6):
+        ranges = [0, 60] if i % 2 else ()
+        sol, _, _ = solver_random(57 + i, fill=0.03, elim=(0, 60), ranges=ranges,
+                                  model="openblas" if i < 4 else "hip")
+        data = spd_data(sol, 9 + i, dtype=dtype)
+        L, _ = dense_lower_chol(sol, data)
+        d = to_dev(data)
+        sol.factorPerOp(d)
+        got = d.cpu().numpy()
+        err = np.linalg.norm(lower_of(sol, got) - L)
+        assert err < EPS[dtype][1], (i, err)
+        fused = _gpu_factor(sol, data)
+        mask = sol.lowerMask()
+        rel = np.linalg.norm((got - fused)[mask].astype(np.float64)) / np.linalg.norm(fused[mask])
+        assert rel < (1e-13 if dtype == np.float64 else 2e-6), (i, rel)
+
+
+def test_per_op_wide_lump():
+    """per-op potrf/trsm on a multi-panel (two-level blocked) lump with rows below"""
+    n = 300
+    cols = [set(range(i, n)) for i in range(n)]
+    cols += [set([n + j]) | set() for j in range(40)]
+    for j in range(40):
+        cols[(7 * j) % n].add(n + j)   # a few rows below the wide dense part
+    ss = T.columns_to_structure(cols)
+    sol = B.create_solver(B.Settings(), np.ones(n + 40, dtype=np.int64), ss)
+    data = spd_data(sol, 33, beta_factor=1.2)
+    L, _ = dense_lower_chol(sol, data)
+    d = to_dev(data)
+    sol.factorPerOp(d)
+    assert np.linalg.norm(lower_of(sol, d.cpu().numpy()) - L) < 1e-8
