@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="bal871")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="total number of identical-structure matrices (sharded over the GPUs); "
+                         "0 = one matrix per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -104,13 +107,26 @@ def main():
         sol = broadcast_solver(sol, src=0, device=device)
     sol.setStream(torch.cuda.current_stream(device))
 
-    # ---- numeric data: one matrix per rank, K+W pristine copies resident in HBM -------------
+    # ---- numeric data: K+W pristine copies of this rank's matrices resident in HBM ------------
     order, flops = sol.order(), sol.factorFlops()
-    host = T.random_data(sol.dataSize(), -1.0, 1.0, 37 + rank)
-    sol.damp(host, 0.0, order * 1.2)
-    A_dev = torch.from_numpy(host).to(device)
+    from baspacho_amd.distributed import shard_batch
+    total_batch = args.batch if args.batch > 0 else world
+    q0, q1 = shard_batch(total_batch, world, rank)
+    n_local = q1 - q0
+    # seeds / damping as the reference's batched bench (Bench.cpp:227-233): seed 37+q
+    hosts = []
+    for q in range(q0, q1):
+        h = T.random_data(sol.dataSize(), -1.0, 1.0, 37 + q)
+        sol.damp(h, 0.0, order * (1.2 if args.batch == 0 else 1.3))
+        hosts.append(h)
+    host = hosts[0]
+    A_devs = [torch.from_numpy(h).to(device) for h in hosts]
+    A_dev = A_devs[0]
     n_buf = args.steps + args.warmup
-    bufs = [A_dev.clone() for _ in range(n_buf)]
+    if args.batch == 0:
+        bufs = [A_dev.clone() for _ in range(n_buf)]
+    else:
+        bufs = [[a.clone() for a in A_devs] for _ in range(n_buf)]   # batched factor() per step
     torch.cuda.synchronize(device)
 
     for i in range(args.warmup):
@@ -133,7 +149,7 @@ def main():
         elapsed = float(tmax.item())
 
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * flops * args.steps / elapsed / 1e9
+    value = total_batch * flops * args.steps / elapsed / 1e9
 
     out = {
         "metric": "factor_gflops_fp64_bal871_schur" if args.workload == "bal871"
@@ -142,14 +158,16 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "description": desc, "order": order,
-                   "data_MB": round(sol.dataSize() * 8 / 1e6, 1), "matrices_per_gpu": 1,
+                   "data_MB": round(sol.dataSize() * 8 / 1e6, 1), "matrices_per_gpu": n_local,
+                   "batch": total_batch,
                    "factor_GF_per_matrix": round(flops / 1e9, 3),
                    "parallelism": "batch-shard x%d (plan broadcast over RCCL)" % world},
     }
 
     if rank == 0:
         # ---- parity at full size: residual probe of the last timed factor -------------------
-        out["residual_probe"] = residual_probe(sol, host, bufs[-1])
+        last = bufs[-1] if args.batch == 0 else bufs[-1][0]
+        out["residual_probe"] = residual_probe(sol, host, last)
         st = sol.planStats()
         out["plan"] = {k: st[k] for k in ("num_launches", "num_levels", "num_panels",
                                           "num_upd_tasks", "num_atomic_upd_tasks")}

@@ -104,3 +104,20 @@ def test_solve_bal_like_residual():
     # here we check A x = b with A applied by the dense matrix of this mid-size problem
     A = sol.densify(data, fill_upper_half=True)
     assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-12
+
+
+def test_mixed_precision_refinement():
+    """BASELINE config 5 in small: fp32 factor + fp64 iterative refinement reaches ||r||/||b|| <
+    1e-10 on a bundle-adjustment shaped problem (stand-in for BAL-1723)"""
+    import torch
+    from baspacho_amd.refine import solve_refined
+    sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=80, num_pts=8000, band=10, seed=7)
+    sol = B.create_solver(B.Settings(), sizes, ss, [0, 8000])
+    data = spd_data(sol, 13, beta_factor=1.2)
+    b = T.random_data(sol.order(), -1, 1, 4)
+    x, iters, hist = solve_refined(sol, to_dev(data), to_dev(b), tol=1e-10)
+    assert hist[-1] < 1e-10, hist
+    assert iters <= 6, hist
+    assert hist[0] < 1e-4  # the fp32 solve alone is already a decent solution
+    A = sol.densify(data, fill_upper_half=True)
+    assert np.linalg.norm(A @ x.cpu().numpy() - b) / np.linalg.norm(b) < 1e-10
