@@ -393,6 +393,13 @@ class Solver:
         return data
 
 
+def probe_mfma_f64_tflops():
+    """sustained fp64 MFMA rate of the current GPU (register-only probe kernel), TFLOP/s"""
+    out = ctypes.c_double(0)
+    _check(_lib.load().bsp_probe_mfma_f64(ctypes.byref(out)))
+    return out.value
+
+
 def create_solver(settings: Optional[Settings], param_sizes, ss: SparseStructure,
                   sparse_elim_ranges=(), elim_last_ids=()) -> Solver:
     """createSolver (Solver.h:235-237): symbolic analysis on the host; never touches the GPU."""

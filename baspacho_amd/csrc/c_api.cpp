@@ -312,6 +312,12 @@ int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out) {
   BSP_CATCH
 }
 
+int bsp_probe_mfma_f64(double* tflops) {
+  BSP_TRY
+  *tflops = hipBackendMfmaF64ProbeTflops();
+  BSP_CATCH
+}
+
 int bsp_factor_profiled_f64(bsp_solver* s, double* d, double ms[5], int64_t launches[5]) {
   BSP_TRY
   HipKernelProfile prof;

@@ -33,6 +33,9 @@ struct HipPlanStats {
 // the execution stream and accumulated per kernel class (factor calls then synchronise)
 void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof);
 
+// sustained fp64 MFMA rate of this GPU measured with a register-only probe kernel (TFLOP/s)
+double hipBackendMfmaF64ProbeTflops();
+
 // TESTING: make factor() take the reference-style per-op loop (potrf/trsm/saveSyrkGemm/
 // prepareAssemble/assemble/doElimination virtuals) instead of the fused path
 void hipBackendForcePerOp(SymbolicCtx& sym, bool on);

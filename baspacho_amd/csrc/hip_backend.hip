@@ -276,6 +276,14 @@ struct HipNumericCtx : NumericCtx<T> {
         plan.rowColOff.as<int32_t>(), ref, altTarget, altStride);
   }
 
+  void launchUpdateBig(DevPlan& plan, int64_t begin, int64_t end, hipk::DataRef<BT> ref,
+                       hipStream_t stream) {
+    hipk::updateTileBig<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, 0, stream>>>(
+        plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(), plan.updTasks.as<UpdTask>() + begin,
+        plan.chainOffTab.as<int64_t>(), plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(),
+        plan.rowColOff.as<int32_t>(), ref);
+  }
+
   // One level = potrf -> trsm -> update on the execution stream.  Deferred (lookahead) tiles go to
   // the side stream after the level's trsm and are joined back by events where the plan says so.
   void launchLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::DataRef<BT> ref,
@@ -300,12 +308,16 @@ struct HipNumericCtx : NumericCtx<T> {
             plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin, ref);
         timer.end();
       }
-      if (lookahead && lr.defEnd > lr.defBegin) {
+      const bool anyDef = lr.defEnd > lr.defBegin || lr.bigDefEnd > lr.bigDefBegin;
+      if (lookahead && anyDef) {
         // the deferred tiles read the freshly solved panels: fork after the trsm
         hipEvent_t fork = sym.eventFromPool();
         hipCHECK(hipEventRecord(fork, sym.stream));
         hipCHECK(hipStreamWaitEvent(sym.sideStream(), fork, 0));
-        launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.sideStream());
+        if (lr.bigDefEnd > lr.bigDefBegin) {
+          launchUpdateBig(plan, lr.bigDefBegin, lr.bigDefEnd, ref, sym.sideStream());
+        }
+        if (lr.defEnd > lr.defBegin) launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.sideStream());
         defDone[li] = sym.eventFromPool();
         hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
         sideUsed = true;
@@ -313,9 +325,19 @@ struct HipNumericCtx : NumericCtx<T> {
       if (lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
         hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
       }
+      if (lr.bigEnd > lr.bigBegin) {
+        timer.begin(kProfUpdate);
+        launchUpdateBig(plan, lr.bigBegin, lr.bigEnd, ref, sym.stream);
+        timer.end();
+      }
       if (lr.updEnd > lr.updBegin) {
         timer.begin(kProfUpdate);
         launchUpdate(plan, lr.updBegin, lr.updEnd, ref, sym.stream);
+        timer.end();
+      }
+      if (!lookahead && lr.bigDefEnd > lr.bigDefBegin) {
+        timer.begin(kProfUpdate);
+        launchUpdateBig(plan, lr.bigDefBegin, lr.bigDefEnd, ref, sym.stream);
         timer.end();
       }
       if (!lookahead && lr.defEnd > lr.defBegin) {
@@ -636,6 +658,26 @@ struct HipOps : Ops {
 }  // namespace
 
 OpsPtr hipOps() { return OpsPtr(new HipOps); }
+
+double hipBackendMfmaF64ProbeTflops() {
+  const int blocks = 1024, iters = 4000;
+  double* out = nullptr;
+  hipCHECK(hipMalloc(&out, sizeof(double) * 256 * blocks));
+  hipEvent_t a, b;
+  hipCHECK(hipEventCreate(&a));
+  hipCHECK(hipEventCreate(&b));
+  hipk::mfmaF64Probe<<<blocks, 256>>>(out, iters);  // warm-up
+  hipCHECK(hipEventRecord(a, nullptr));
+  hipk::mfmaF64Probe<<<blocks, 256>>>(out, iters);
+  hipCHECK(hipEventRecord(b, nullptr));
+  hipCHECK(hipEventSynchronize(b));
+  float ms = 0;
+  hipCHECK(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipFree(out);
+  return double(blocks) * 4 * iters * 4 * 2048.0 / (ms * 1e-3) / 1e12;
+}
 
 void hipBackendForcePerOp(SymbolicCtx& sym, bool on) {
   HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);

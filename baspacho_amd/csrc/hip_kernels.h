@@ -565,6 +565,7 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
 //   * fp64: v_mfma_f64_16x16x4_f64, C layout col = lane&15, row = (lane>>4) + 4*reg
 //   * fp32: v_mfma_f32_16x16x4_f32, C layout col = lane&15, row = 4*(lane>>4) + reg
 // ------------------------------------------------------------------------------------------
+constexpr int kUpdChunk = 32;  // K chunk of updateTile: 2 x 64 x 34 doubles = 35 KB LDS -> 4 WG/CU
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
                                                   T* altTarget = nullptr, int64_t altStride = 0) {
   // altTarget: write the (negated) product into a separate buffer instead of `data`
   // (per-op saveSyrkGemm: the frontal temp buffer, one slice per batch entry)
-  constexpr int LD = kPanelWidth + 2;
+  constexpr int KC = kUpdChunk, LD = KC + 2;
   __shared__ T As[kTile * LD];
   __shared__ T Bs[kTile * LD];
   __shared__ int64_t rowBase[kTile];
@@ -640,42 +641,40 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
   // a diagonal tile only needs sub-tiles on or below the diagonal
   const bool skipUpper = diagTile && wr < wc;
 
-  // K loop in chunks of up to 64 source columns: stage (lane = k, wave w takes rows w, w+4, ...;
-  // all loads of a chunk are issued before the first LDS write), then 2x2 MFMA tiles per wave.
-  for (int kBase = 0; kBase < K; kBase += kPanelWidth) {
-    const int kc = min(kPanelWidth, K - kBase);
+  // K loop in chunks of KC source columns.  Staging map: k = tid % KC, rows (tid / KC) + (256/KC)*it;
+  // all loads of a chunk are issued before the first LDS write (memory-level parallelism), then
+  // every wave runs its 2x2 MFMA tiles over the chunk.
+  constexpr int RSTEP = 256 / KC, NIT = kTile / RSTEP;
+  const int sk = tid % KC, sr = tid / KC;
+  for (int kBase = 0; kBase < K; kBase += KC) {
+    const int kc = min(KC, K - kBase);
     const int kPad = (kc + 3) & ~3;
     {
-      const int k = lane;
-      const int kcl = kBase + min(k, kc - 1);
-      T va[16], vb[16];
+      const int kcl = kBase + min(sk, kc - 1);
+      T va[NIT], vb[NIT];
 #pragma unroll
-      for (int it = 0; it < 16; it++) {
-        const int r = wave + 4 * it;
-        const int qa = min(task.rowTile + r, pd.rowsBelow - 1);
+      for (int it = 0; it < NIT; it++) {
+        const int qa = min(task.rowTile + sr + RSTEP * it, pd.rowsBelow - 1);
         va[it] = P[(int64_t)qa * lda + kcl];
       }
       if (!diagTile) {
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-          const int r = wave + 4 * it;
-          const int qb = min(task.colTile + r, segEnd - 1);
+        for (int it = 0; it < NIT; it++) {
+          const int qb = min(task.colTile + sr + RSTEP * it, segEnd - 1);
           vb[it] = P[(int64_t)qb * lda + kcl];
         }
       }
       if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
-      if (k < kPad) {
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-          const int r = wave + 4 * it;
-          As[r * LD + k] = (k < kc && task.rowTile + r < pd.rowsBelow) ? va[it] : T(0);
-        }
-        if (!diagTile) {
+      for (int it = 0; it < NIT; it++) {
+        const int r = sr + RSTEP * it;
+        As[r * LD + sk] = (sk < kc && task.rowTile + r < pd.rowsBelow) ? va[it] : T(0);
+      }
+      if (!diagTile) {
 #pragma unroll
-          for (int it = 0; it < 16; it++) {
-            const int r = wave + 4 * it;
-            Bs[r * LD + k] = (k < kc && task.colTile + r < segEnd) ? vb[it] : T(0);
-          }
+        for (int it = 0; it < NIT; it++) {
+          const int r = sr + RSTEP * it;
+          Bs[r * LD + sk] = (sk < kc && task.colTile + r < segEnd) ? vb[it] : T(0);
         }
       }
     }
@@ -736,6 +735,190 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5b  the same rank-K update on a 128x128 tile, for the large segments (bulk of the flops).
+//   * 256 threads = 4 waves, each wave a 64x64 sub-tile = 4x4 MFMA 16x16 tiles (16 accumulators,
+//     64 fp64 accumulator values per lane): 4x the MFMA work per byte staged and per scatter
+//   * K loop in chunks of 32 columns; the NEXT chunk is fetched into registers (32 values per
+//     lane) while the current one is multiplied out of LDS, so global latency hides behind MFMA
+//   * one LDS buffer of 2 x 128 x 34 doubles (row stride 34 == 2 mod 4 doubles: conflict-free
+//     operand fetch); 70 KB per workgroup leaves room for the panel kernels of the critical path
+// ------------------------------------------------------------------------------------------
+constexpr int kBigTile = 128;
+constexpr int kBigChunk = 32;
+
+template <typename T>
+__global__ __launch_bounds__(256) void updateTileBig(const SrcDesc* srcs, const SegDesc* segs,
+                                                     const UpdTask* tasks,
+                                                     const int64_t* chainOffTab,
+                                                     const int32_t* rowChain,
+                                                     const int32_t* rowLocal,
+                                                     const int32_t* rowColOff, DataRef<T> dref) {
+  constexpr int LD = kBigChunk + 2;
+  __shared__ T As[kBigTile * LD];
+  __shared__ T Bs[kBigTile * LD];
+  __shared__ int64_t rowBase[kBigTile];
+  __shared__ int32_t colOff[kBigTile];
+
+  const UpdTask task = tasks[blockIdx.x];
+  const SegDesc sd = segs[task.seg];
+  const SrcDesc pd = srcs[sd.src];
+  T* data = pickData(dref);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = pd.K, lda = pd.lda;
+  const T* P = data + pd.off;
+  const bool diagTile = task.rowTile == task.colTile;
+  const int segEnd = sd.q0 + sd.m;
+
+  if (tid < kBigTile) {
+    const int q = task.rowTile + tid;
+    int64_t base = 0;
+    if (q < pd.rowsBelow) {
+      if (sd.kind == kSegIntra) {
+        base = sd.tgtBase + (int64_t)q * sd.tgtStride;
+      } else {
+        const int rr = pd.lumpRowBase + (q - pd.nRest);
+        base = chainOffTab[sd.chainTabPtr + (rowChain[rr] - sd.firstChainOrd)] +
+               (int64_t)rowLocal[rr] * sd.tgtStride;
+      }
+    }
+    rowBase[tid] = base;
+  } else {
+    const int cidx = tid - kBigTile;
+    const int q = task.colTile + cidx;
+    int32_t off = 0;
+    if (q < segEnd) off = sd.kind == kSegIntra ? q : rowColOff[pd.lumpRowBase + (q - pd.nRest)];
+    colOff[cidx] = off;
+  }
+
+  const T* Bt = diagTile ? As : Bs;
+  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  const int li = lane & 15, lk = lane >> 4;
+  using Acc = typename Mfma<T>::Acc;
+  Acc acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = Acc{0, 0, 0, 0};
+  }
+  const bool skipUpper = diagTile && wr < wc;
+
+  // staging map: lane quarter k = tid & 31 (column inside the chunk), rows (tid >> 5) + 8*it
+  const int sk = tid & 31, sr = tid >> 5;
+  T va[16], vb[16];
+  auto fetch = [&](int kBase) {
+    const int kc = min(kBigChunk, K - kBase);
+    const int kcl = kBase + min(sk, kc - 1);
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int qa = min(task.rowTile + sr + 8 * it, pd.rowsBelow - 1);
+      va[it] = P[(int64_t)qa * lda + kcl];
+    }
+    if (!diagTile) {
+#pragma unroll
+      for (int it = 0; it < 16; it++) {
+        const int qb = min(task.colTile + sr + 8 * it, segEnd - 1);
+        vb[it] = P[(int64_t)qb * lda + kcl];
+      }
+    }
+  };
+  auto park = [&](int kBase) {
+    const int kc = min(kBigChunk, K - kBase);
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int r = sr + 8 * it;
+      As[r * LD + sk] = (sk < kc && task.rowTile + r < pd.rowsBelow) ? va[it] : T(0);
+    }
+    if (!diagTile) {
+#pragma unroll
+      for (int it = 0; it < 16; it++) {
+        const int r = sr + 8 * it;
+        Bs[r * LD + sk] = (sk < kc && task.colTile + r < segEnd) ? vb[it] : T(0);
+      }
+    }
+  };
+
+  fetch(0);
+  for (int kBase = 0; kBase < K; kBase += kBigChunk) {
+    if (kBase > 0) __syncthreads();  // everyone is done reading the previous chunk
+    park(kBase);
+    __syncthreads();
+    if (kBase + kBigChunk < K) fetch(kBase + kBigChunk);  // in flight during the MFMAs below
+    if (!skipUpper) {
+      const int kPad = (min(kBigChunk, K - kBase) + 3) & ~3;
+      for (int k0 = 0; k0 < kPad; k0 += 4) {
+        T a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = As[(wr + 16 * i + li) * LD + k0 + lk];
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[j] = Bt[(wc + 16 * j + li) * LD + k0 + lk];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+        }
+      }
+    }
+  }
+  if (skipUpper) return;
+
+  // scatter: 16 MFMA tiles x 4 values per lane, in groups of 16 (gather old values, then store)
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    T* ptr[16];
+    bool ok[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int cIn = wc + 16 * j + li;
+      const int qc = task.colTile + cIn;
+      const int32_t co = colOff[cIn];
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int rIn = wr + 16 * i + Mfma<T>::row(lane, reg);
+        const int qr = task.rowTile + rIn;
+        ok[j * 4 + reg] = qc < segEnd && qr < pd.rowsBelow && qr >= qc && qr >= sd.rowMin;
+        ptr[j * 4 + reg] = data + rowBase[rIn] + co;
+      }
+    }
+    if (task.atomic) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          if (ok[j * 4 + reg]) atomicSub(ptr[j * 4 + reg], acc[i][j][reg]);
+        }
+      }
+    } else {
+      T old[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) old[e] = *ptr[e];  // masked-off entries point at valid memory
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          if (ok[j * 4 + reg]) *ptr[j * 4 + reg] = old[j * 4 + reg] - acc[i][j][reg];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Measurement helper: sustained rate of back-to-back independent v_mfma_f64_16x16x4_f64 (4
+// accumulators per wave).  bench.py reports it next to the datasheet peak.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mfmaF64Probe(double* out, int iters) {
+  double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+  const double a = threadIdx.x * 1e-3, b = threadIdx.x * 2e-3;
+  for (int i = 0; i < iters; i++) {
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
 }
 
 // ------------------------------------------------------------------------------------------

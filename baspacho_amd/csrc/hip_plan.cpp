@@ -381,7 +381,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       lr.updBegin = (int64_t)plan.updTasks.size();
       lr.waitDefLevel = -1;
       const int64_t levelIdx = (int64_t)out.size();
-      vector<UpdTask> deferred;
+      vector<UpdTask> deferred, big, bigDeferred;
       // how many panels of this level hit each target lump
       std::map<int64_t, int> hits;
       for (const auto& pb : bucket) {
@@ -404,14 +404,20 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             if (it != lastDeferredLevel.end()) lr.waitDefLevel = std::max(lr.waitDefLevel, it->second);
           }
           bool anyDeferred = false;
-          for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += kTile) {
+          // large segments go to the 128x128-tile kernel, the rest to the 64x64 one
+          const bool useBig = sd.m >= kBigTileMin && sr.rowsBelow - sd.q0 >= kBigTileMin;
+          const int32_t step = useBig ? 2 * kTile : kTile;
+          for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += step) {
             const bool defer = sd.outer && cT - sd.q0 >= kOuterWidth;
-            for (int32_t rT = cT; rT < sr.rowsBelow; rT += kTile) {
+            for (int32_t rT = cT; rT < sr.rowsBelow; rT += step) {
+              const UpdTask t{(int32_t)s, rT, cT, atomic};
               if (defer) {
-                deferred.push_back({(int32_t)s, rT, cT, atomic});
+                (useBig ? bigDeferred : deferred).push_back(t);
                 anyDeferred = true;
+              } else if (useBig) {
+                big.push_back(t);
               } else {
-                plan.updTasks.push_back({(int32_t)s, rT, cT, atomic});
+                plan.updTasks.push_back(t);
               }
             }
           }
@@ -444,6 +450,12 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           plan.updTasks[begin + p] = tmp[chunkStart[x] + k];
         }
       };
+      lr.bigBegin = (int64_t)plan.updTasks.size();
+      plan.updTasks.insert(plan.updTasks.end(), big.begin(), big.end());
+      lr.bigEnd = lr.bigDefBegin = (int64_t)plan.updTasks.size();
+      plan.updTasks.insert(plan.updTasks.end(), bigDeferred.begin(), bigDeferred.end());
+      lr.bigDefEnd = (int64_t)plan.updTasks.size();
+      plan.numLaunches += (lr.bigEnd > lr.bigBegin) + (lr.bigDefEnd > lr.bigDefBegin);
       xcdOrder(lr.updBegin, lr.updEnd);
       xcdOrder(lr.defBegin, lr.defEnd);
       plan.maxPanelsInLevel = std::max<int64_t>(plan.maxPanelsInLevel, lr.panelEnd - lr.panelBegin);
@@ -531,6 +543,7 @@ HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly)
       }
       lr.updEnd = (int64_t)plan.updTasks.size();
       lr.defBegin = lr.defEnd = lr.updEnd;
+      lr.bigBegin = lr.bigEnd = lr.bigDefBegin = lr.bigDefEnd = lr.updEnd;
       plan.levels.push_back(lr);
     }
   }

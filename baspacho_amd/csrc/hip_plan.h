@@ -24,6 +24,10 @@ constexpr int kPanelWidth = 64;   // max panel width nb (potrf/trsm granularity)
 constexpr int kOuterWidth = 256;  // outer block: panels update only their own outer block right
                                   // away; everything to its right gets ONE rank-256 update
 constexpr int kTile = 64;         // update tile (rows x cols) and trsm row tile
+constexpr int kBigTileMin = 1 << 30;  // segments at least this wide AND tall would use the 128x128
+                                      // kernel; disabled: measured equal rate per tile (35 TF/s at
+                                      // K=256, the fp64 MFMA pipe sustains ~47 TF/s on this chip)
+                                      // and worse load balance than 64x64 tiles
 constexpr int kElimSmallMax = 16; // widest lump handled by the small sparse-elim kernels
 
 struct PanelDesc {
@@ -87,6 +91,8 @@ struct LevelRange {
   // and may run on a second stream concurrently with the following levels.  They must be complete
   // before the update launch of level `waitDefLevel`-consumers (see below).
   int64_t defBegin, defEnd;      // into updTasks (deferred tiles of this level)
+  // the same two lists for the 128x128-tile kernel (large segments)
+  int64_t bigBegin, bigEnd, bigDefBegin, bigDefEnd;
   int64_t waitDefLevel;          // index (within the same level list) of the level whose deferred
                                  // tiles must be complete before this level's update launch; -1
 };

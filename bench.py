@@ -205,6 +205,11 @@ def main():
                                    "avg_launch_ms": round(ms / max(launches, 1), 5),
                                    "algorithmic_bytes_per_launch": byt / max(launches, 1),
                                    "share_of_factor": round(ms / tot, 3)}
+            if out["roofline"]["bound"] == "mfma":
+                # what back-to-back fp64 MFMAs sustain on this very GPU (register-only probe)
+                probe = B.probe_mfma_f64_tflops()
+                out["roofline"]["measured_mfma_probe"] = round(probe, 2)
+                out["roofline"]["frac_of_probe"] = round(out["roofline"]["achieved"] / probe, 4)
             # secondary kernels, for the record
             sec = {}
             if prof["update"][0] > 0:

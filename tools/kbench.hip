@@ -18,6 +18,29 @@ __global__ void clockProbe(long long* out, int iters) {
   if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (long long)x; }
 }
 
+__global__ __launch_bounds__(256) void mfmaPeak(double* out, int iters) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+  double a = threadIdx.x * 1e-3, b = threadIdx.x * 2e-3;
+  for (int i = 0; i < iters; i++) {
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+__global__ __launch_bounds__(256) void fmaPeak(double* out, int iters) {
+  double c[8]; for (int j = 0; j < 8; j++) c[j] = j;
+  double a = threadIdx.x * 1e-3, b = 1.0000001;
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) c[j] = __builtin_fma(c[j], b, a);
+  }
+  double s = 0; for (int j = 0; j < 8; j++) s += c[j];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <typename F>
 float timeIt(F&& f, int reps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -46,6 +69,18 @@ int main(int argc, char** argv) {
     printf("clockProbe blocks=%d: shader cycles %lld, wall ticks(100MHz) %lld -> %.2f GHz\n", blocks, hc[0], hc[1], hc[0] / (hc[1] * 10.0));
   }
 
+  {
+    double* dout; CK(hipMalloc(&dout, 8 * 256 * 2048));
+    for (int blocks : {256, 512, 1024}) {
+      int iters = 20000;
+      float us2 = timeIt([&] { mfmaPeak<<<blocks, 256>>>(dout, iters); }, 3);
+      double fl = (double)blocks * 4 * iters * 4 * 2048.0;
+      printf("mfma f64 16x16x4 peak probe, %d blocks x 4 waves: %.1f TF/s\n", blocks, fl / us2 / 1e6);
+      us2 = timeIt([&] { fmaPeak<<<blocks, 256>>>(dout, iters); }, 3);
+      fl = (double)blocks * 256 * iters * 8 * 2.0;
+      printf("v_fma_f64 peak probe, %d blocks: %.1f TF/s\n", blocks, fl / us2 / 1e6);
+    }
+  }
   const int nb = 64;
   PanelDesc pd{}; pd.diagOff = (int64_t)c0 * n + c0; pd.lda = n; pd.nb = nb; pd.nRest = n - c0 - nb; pd.rowsBelow = pd.nRest; pd.lumpRowBase = 0; pd.lump = 0;
   int K = argc > 3 ? atoi(argv[3]) : 64;  // source width of the update
@@ -81,6 +116,13 @@ int main(int argc, char** argv) {
   printf("updateTile plain  : %8.1f us  -> %.2f TF/s\n", us, updFlops / us / 1e6);
   us = timeIt([&] { hipk::updateTile<double><<<(unsigned)ut.size(), 256>>>(dsr, dsd, dutA, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
   printf("updateTile atomic : %8.1f us  -> %.2f TF/s\n", us, updFlops / us / 1e6);
+  {
+    std::vector<UpdTask> ub;
+    for (int cT = 0; cT < sd.m; cT += 128) for (int rT = cT; rT < pd.rowsBelow; rT += 128) ub.push_back({0, rT, cT, 0});
+    UpdTask* dub; CK(hipMalloc(&dub, ub.size() * sizeof(UpdTask))); CK(hipMemcpy(dub, ub.data(), ub.size() * sizeof(UpdTask), hipMemcpyHostToDevice));
+    us = timeIt([&] { hipk::updateTileBig<double><<<(unsigned)ub.size(), 256>>>(dsr, dsd, dub, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
+    printf("updateTileBig     : %8.1f us  -> %.2f TF/s  (%zu tiles)\n", us, updFlops / us / 1e6, ub.size());
+  }
   CK(hipDeviceSynchronize());
   return 0;
 }
