@@ -123,11 +123,14 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipSymbolicCtx(const CoalescedBlockMatrixSkel& skel_, const vector<int64_t>& permutation_)
       : skel(skel_), permutation(permutation_) {
     if (const char* e = std::getenv("BSP_NO_LOOKAHEAD")) lookaheadEnabled = e[0] == '0';
+    if (const char* e = std::getenv("BSP_NO_CRIT_STREAM")) critEnabled = e[0] == '0';
+    if (const char* e = std::getenv("BSP_BULK_EXTRA_LDS")) bulkExtraLds = (unsigned)atoi(e);
   }
 
   virtual ~HipSymbolicCtx() override {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
+    if (crit) (void)hipStreamDestroy(crit);
   }
 
   virtual void setSparseElimRanges(const vector<int64_t>& ranges) override {
@@ -231,6 +234,15 @@ struct HipSymbolicCtx : SymbolicCtx {
     }
     return side;
   }
+  // high-priority stream for the latency-critical chain while a bulk update runs beside it
+  hipStream_t critStream() {
+    if (!crit) {
+      int least = 0, greatest = 0;
+      hipCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      hipCHECK(hipStreamCreateWithPriority(&crit, hipStreamNonBlocking, greatest));
+    }
+    return crit;
+  }
   hipEvent_t eventFromPool() {
     if (nextEvent == events.size()) {
       hipEvent_t e;
@@ -247,8 +259,10 @@ struct HipSymbolicCtx : SymbolicCtx {
   hipStream_t stream = nullptr;
   HipKernelProfile* profile = nullptr;
   bool lookaheadEnabled = true;
+  unsigned bulkExtraLds = 6 * 1024;
+  bool critEnabled = false;  // measured: no gain from stream priorities on MI355X
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr, crit = nullptr;
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
 
@@ -268,9 +282,14 @@ struct HipNumericCtx : NumericCtx<T> {
   // single matrix: pointer by value; batch: the device-pointer array is uploaded once per call
   hipk::DataRef<BT> makeRef(T* data);
 
+  // extraLds: dynamic LDS requested on top of the kernel's static 35 KB.  Bulk (deferred) launches
+  // ask for 6 KB so that only THREE of their workgroups fit on a CU (3 x 41 KB), leaving 37 KB for
+  // a workgroup of the critical-path kernels (trsm needs 33.5 KB); with four resident bulk
+  // workgroups the trsm of the next panel was starved for the whole bulk update (273 us vs 17 us).
   void launchUpdate(DevPlan& plan, int64_t begin, int64_t end, hipk::DataRef<BT> ref,
-                    hipStream_t stream, BT* altTarget = nullptr, int64_t altStride = 0) {
-    hipk::updateTile<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, 0, stream>>>(
+                    hipStream_t stream, BT* altTarget = nullptr, int64_t altStride = 0,
+                    unsigned extraLds = 0) {
+    hipk::updateTile<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, extraLds, stream>>>(
         plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(), plan.updTasks.as<UpdTask>() + begin,
         plan.chainOffTab.as<int64_t>(), plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(),
         plan.rowColOff.as<int32_t>(), ref, altTarget, altStride);
@@ -308,20 +327,6 @@ struct HipNumericCtx : NumericCtx<T> {
             plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin, ref);
         timer.end();
       }
-      const bool anyDef = lr.defEnd > lr.defBegin || lr.bigDefEnd > lr.bigDefBegin;
-      if (lookahead && anyDef) {
-        // the deferred tiles read the freshly solved panels: fork after the trsm
-        hipEvent_t fork = sym.eventFromPool();
-        hipCHECK(hipEventRecord(fork, sym.stream));
-        hipCHECK(hipStreamWaitEvent(sym.sideStream(), fork, 0));
-        if (lr.bigDefEnd > lr.bigDefBegin) {
-          launchUpdateBig(plan, lr.bigDefBegin, lr.bigDefEnd, ref, sym.sideStream());
-        }
-        if (lr.defEnd > lr.defBegin) launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.sideStream());
-        defDone[li] = sym.eventFromPool();
-        hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
-        sideUsed = true;
-      }
       if (lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
         hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
       }
@@ -334,6 +339,23 @@ struct HipNumericCtx : NumericCtx<T> {
         timer.begin(kProfUpdate);
         launchUpdate(plan, lr.updBegin, lr.updEnd, ref, sym.stream);
         timer.end();
+      }
+      const bool anyDef = lr.defEnd > lr.defBegin || lr.bigDefEnd > lr.bigDefBegin;
+      if (lookahead && anyDef) {
+        // Fork AFTER the level's own update launch: those "now" tiles (the next outer block's
+        // columns) are on the critical path and run 3x faster alone than beside the bulk tiles.
+        hipEvent_t fork = sym.eventFromPool();
+        hipCHECK(hipEventRecord(fork, sym.stream));
+        hipCHECK(hipStreamWaitEvent(sym.sideStream(), fork, 0));
+        if (lr.bigDefEnd > lr.bigDefBegin) {
+          launchUpdateBig(plan, lr.bigDefBegin, lr.bigDefEnd, ref, sym.sideStream());
+        }
+        if (lr.defEnd > lr.defBegin) {
+          launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+        }
+        defDone[li] = sym.eventFromPool();
+        hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
+        sideUsed = true;
       }
       if (!lookahead && lr.bigDefEnd > lr.bigDefBegin) {
         timer.begin(kProfUpdate);
@@ -398,9 +420,32 @@ struct HipNumericCtx : NumericCtx<T> {
     hipk::DataRef<BT> ref = makeRef(data);
     LaunchTimer timer(sym.stream, sym.profile);
     sym.resetEventPool();
-    for (const ElimRangePlan& er : plan.host.elimRanges) launchElim(plan, er, ref, timer);
-    launchLevels(plan, plan.host.levels, ref, timer);
-    hipCHECK(hipGetLastError());
+    // With lookahead the whole call runs on an internal high-priority stream (forked from / joined
+    // to the caller's stream by events) so that the critical chain wins dispatch slots against the
+    // low-priority bulk tiles.
+    const bool useCrit = sym.profile == nullptr && sym.lookaheadEnabled && sym.critEnabled &&
+                         plan.host.hasDeferred;
+    hipStream_t userStream = sym.stream;
+    if (useCrit) {
+      hipEvent_t fork = sym.eventFromPool();
+      hipCHECK(hipEventRecord(fork, userStream));
+      hipCHECK(hipStreamWaitEvent(sym.critStream(), fork, 0));
+      sym.stream = sym.critStream();
+    }
+    try {
+      for (const ElimRangePlan& er : plan.host.elimRanges) launchElim(plan, er, ref, timer);
+      launchLevels(plan, plan.host.levels, ref, timer);
+      hipCHECK(hipGetLastError());
+    } catch (...) {
+      sym.stream = userStream;
+      throw;
+    }
+    if (useCrit) {
+      hipEvent_t join = sym.eventFromPool();
+      hipCHECK(hipEventRecord(join, sym.stream));
+      sym.stream = userStream;
+      hipCHECK(hipStreamWaitEvent(userStream, join, 0));
+    }
     timer.finish();
   }
 

@@ -456,6 +456,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       plan.updTasks.insert(plan.updTasks.end(), bigDeferred.begin(), bigDeferred.end());
       lr.bigDefEnd = (int64_t)plan.updTasks.size();
       plan.numLaunches += (lr.bigEnd > lr.bigBegin) + (lr.bigDefEnd > lr.bigDefBegin);
+      if (lr.defEnd > lr.defBegin || lr.bigDefEnd > lr.bigDefBegin) plan.hasDeferred = true;
       xcdOrder(lr.updBegin, lr.updEnd);
       xcdOrder(lr.defBegin, lr.defEnd);
       plan.maxPanelsInLevel = std::max<int64_t>(plan.maxPanelsInLevel, lr.panelEnd - lr.panelBegin);

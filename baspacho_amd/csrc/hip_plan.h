@@ -151,6 +151,7 @@ struct HipPlanHost {
   double elimColElems = 0;   // numeric elements of the sparse-eliminated columns
   int64_t numLaunches = 0;
   int64_t maxPanelsInLevel = 0;
+  bool hasDeferred = false;  // some level carries lookahead (deferred) tiles
 };
 
 // Build the plan for factoring lumps [startLump, upToLump) (sparse-elimination ranges fully
