@@ -101,6 +101,8 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   plan.elimPairOffJ.reserve(plan.elimPairOffJ.size() + (size_t)nPairs);
   plan.elimPairOffI.reserve(plan.elimPairOffI.size() + (size_t)nPairs);
   er.itemBegin = (int64_t)plan.elimItems.size();
+  vector<int64_t> itemRowTag;  // target chain of every emitted item
+  vector<int32_t> itemChunk;   // source-data chunk of every emitted item
   for (int64_t c = 0; c < nChainsTot; c++) {
     const int64_t b = bucketPtr[c], e = bucketPtr[c + 1];
     if (b == e) continue;
@@ -119,7 +121,11 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
       int64_t u = q;
       while (u < q1) {  // split by source width and by length
         int64_t u1 = u;
-        while (u1 < q1 && sorted[u1].width == sorted[u].width && u1 - u < kGatherMaxPairs) u1++;
+        const uint32_t chunkOfU = sorted[u].offJ / kGatherChunkElems;
+        while (u1 < q1 && sorted[u1].width == sorted[u].width && u1 - u < kGatherMaxPairs &&
+               sorted[u1].offJ / kGatherChunkElems == chunkOfU) {
+          u1++;
+        }
         ElimGatherItem it{};
         it.tgtOff = sk.chainData[c] + sk.spanOffsetInLump[si];
         it.pairBegin = (int32_t)plan.elimPairOffJ.size();
@@ -134,6 +140,8 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
         it.n = (int16_t)sorted[u].width;
         it.flags = (int16_t)(sj == si ? 2 : 0);
         plan.elimItems.push_back(it);
+        itemRowTag.push_back(c);
+        itemChunk.push_back((int32_t)chunkOfU);
         u = u1;
       }
       if (plan.elimItems.size() - firstItem > 1) {
@@ -144,6 +152,57 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   }
   er.itemEnd = (int64_t)plan.elimItems.size();
   er.useGather = true;
+  // XCD-aware order (speed only).  A workgroup takes 4 consecutive items and workgroup b runs on
+  // XCD b % 8, each XCD with its own 4 MB L2.  All items of one target ROW (same sj) read the same
+  // B_j source blocks, so a row is handed to ONE XCD (row r -> XCD r % 8, rows balance the load
+  // statistically) instead of being sprayed over all eight L2s (measured L2 hit rate 26 %).
+  {
+    const int64_t nItems = er.itemEnd - er.itemBegin;
+    if (nItems >= 512) {
+      vector<ElimGatherItem> tmp(plan.elimItems.begin() + er.itemBegin, plan.elimItems.end());
+      int32_t nChunks = 0;
+      for (int32_t ch : itemChunk) nChunks = std::max(nChunks, ch + 1);
+      int64_t out = er.itemBegin;
+      // Chunk-major: the source columns are visited in slices of kGatherChunkElems values, so that
+      // a slice (re-read ~11x by the pairs that use it) stays resident in the 256 MB Infinity
+      // Cache instead of streaming the whole elimination range from HBM for every target row.
+      for (int32_t ch = 0; ch < nChunks; ch++) {
+        vector<vector<int64_t>> perXcd(8);
+        int64_t row = -1, rowKey = -1;
+        for (int64_t k = 0; k < nItems; k++) {
+          if (itemChunk[k] != ch) continue;
+          if (itemRowTag[k] != rowKey) {
+            rowKey = itemRowTag[k];
+            row++;
+          }
+          perXcd[row % 8].push_back(k);
+        }
+        size_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t remaining = 0;
+        for (auto& v : perXcd) remaining += (int64_t)v.size();
+        while (remaining > 0) {
+          for (int x = 0; x < 8 && remaining > 0; x++) {
+            int src = x;
+            if (cursor[src] >= perXcd[src].size()) {  // this XCD's list is exhausted: steal
+              size_t best = 0;
+              for (int y = 0; y < 8; y++) {
+                const size_t left = perXcd[y].size() - cursor[y];
+                if (left > best) {
+                  best = left;
+                  src = y;
+                }
+              }
+            }
+            for (int q = 0; q < 4 && cursor[src] < perXcd[src].size(); q++) {
+              plan.elimItems[out++] = tmp[perXcd[src][cursor[src]++]];
+              remaining--;
+            }
+          }
+        }
+      }
+      BASPACHO_CHECK_EQ(out, er.itemEnd);
+    }
+  }
   lap("sort + emit items");
 }
 

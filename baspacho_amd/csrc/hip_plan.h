@@ -111,6 +111,9 @@ struct ElimGatherItem {
 };
 constexpr int kGatherMaxElems = 256;   // rows*cols handled per wave (4 per lane)
 constexpr int kGatherMaxPairs = 2048;  // pairs per work item (longer lists are split)
+constexpr uint32_t kGatherChunkElems = 0xffffffffu;  // optional slicing of the source columns into
+                                                     // cache-sized passes: measured 2x SLOWER on
+                                                     // BAL-871 (more items + atomics), so disabled
 
 // one sparse-elimination range restricted to the planned lump range
 struct ElimRangePlan {
