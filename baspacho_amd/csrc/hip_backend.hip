@@ -125,12 +125,14 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_NO_LOOKAHEAD")) lookaheadEnabled = e[0] == '0';
     if (const char* e = std::getenv("BSP_NO_CRIT_STREAM")) critEnabled = e[0] == '0';
     if (const char* e = std::getenv("BSP_BULK_EXTRA_LDS")) bulkExtraLds = (unsigned)atoi(e);
+    if (const char* e = std::getenv("BSP_NO_EARLY_POTRF")) earlyPotrf = e[0] == '0';
   }
 
   virtual ~HipSymbolicCtx() override {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
     if (crit) (void)hipStreamDestroy(crit);
+    if (third) (void)hipStreamDestroy(third);
   }
 
   virtual void setSparseElimRanges(const vector<int64_t>& ranges) override {
@@ -234,6 +236,10 @@ struct HipSymbolicCtx : SymbolicCtx {
     }
     return side;
   }
+  hipStream_t thirdStream() {
+    if (!third) hipCHECK(hipStreamCreateWithFlags(&third, hipStreamNonBlocking));
+    return third;
+  }
   // high-priority stream for the latency-critical chain while a bulk update runs beside it
   hipStream_t critStream() {
     if (!crit) {
@@ -262,7 +268,8 @@ struct HipSymbolicCtx : SymbolicCtx {
   unsigned bulkExtraLds = 6 * 1024;
   bool critEnabled = false;  // measured: no gain from stream priorities on MI355X
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
-  hipStream_t side = nullptr, crit = nullptr;
+  hipStream_t side = nullptr, crit = nullptr, third = nullptr;
+  bool earlyPotrf = false;  // measured SLOWER (15.2 vs 13.1 ms): cross-stream events per panel cost more than the overlap saves
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
 
@@ -310,12 +317,18 @@ struct HipNumericCtx : NumericCtx<T> {
     const dim3 gy(1, (unsigned)batchSize, 1);
     const bool lookahead = sym.profile == nullptr && sym.lookaheadEnabled;
     vector<hipEvent_t> defDone(levels.size(), nullptr);
+    hipEvent_t potrfDone = nullptr;
     bool sideUsed = false;
     for (size_t li = 0; li < levels.size(); li++) {
       const LevelRange& lr = levels[li];
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
-      if (nP) {
+      const bool early = lookahead && sym.earlyPotrf;
+      if (nP && early && lr.potrfIssuedEarly && potrfDone) {
+        // this level's potrf already ran on the third stream: just order after it
+        hipCHECK(hipStreamWaitEvent(sym.stream, potrfDone, 0));
+        potrfDone = nullptr;
+      } else if (nP) {
         timer.begin(kProfPotrf);
         hipk::potrfPanel<BT><<<dim3(nP, gy.y), 256, 0, sym.stream>>>(
             plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, ref);
@@ -335,9 +348,25 @@ struct HipNumericCtx : NumericCtx<T> {
         launchUpdateBig(plan, lr.bigBegin, lr.bigEnd, ref, sym.stream);
         timer.end();
       }
-      if (lr.updEnd > lr.updBegin) {
+      int64_t updBegin = lr.updBegin;
+      if (early && lr.urgentCount > 0 && li + 1 < levels.size()) {
+        // the tile that completes the next panel's diagonal block goes first; the next level's
+        // potrf then runs on the third stream beside the rest of this level's update
+        launchUpdate(plan, updBegin, updBegin + lr.urgentCount, ref, sym.stream);
+        updBegin += lr.urgentCount;
+        hipEvent_t urgentDone = sym.eventFromPool();
+        hipCHECK(hipEventRecord(urgentDone, sym.stream));
+        hipCHECK(hipStreamWaitEvent(sym.thirdStream(), urgentDone, 0));
+        const LevelRange& nx = levels[li + 1];
+        hipk::potrfPanel<BT><<<dim3((unsigned)(nx.panelEnd - nx.panelBegin), gy.y), 256, 0,
+                               sym.thirdStream()>>>(
+            plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + nx.panelBegin, ref);
+        potrfDone = sym.eventFromPool();
+        hipCHECK(hipEventRecord(potrfDone, sym.thirdStream()));
+      }
+      if (lr.updEnd > updBegin) {
         timer.begin(kProfUpdate);
-        launchUpdate(plan, lr.updBegin, lr.updEnd, ref, sym.stream);
+        launchUpdate(plan, updBegin, lr.updEnd, ref, sym.stream);
         timer.end();
       }
       const bool anyDef = lr.defEnd > lr.defBegin || lr.bigDefEnd > lr.bigDefBegin;

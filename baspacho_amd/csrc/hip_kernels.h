@@ -334,6 +334,29 @@ __global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, c
 // workgroup per panel, whole block in LDS.  Replaces cusolverDn?potrf / potrfBatched
 // (MatOpsCuda.cu:508-548, 727-755) on the panel granularity.
 // ------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<double> {
+  using Acc = double4_t;
+  static __device__ __forceinline__ Acc run(double a, double b, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <>
+struct Mfma<float> {
+  using Acc = float4_t;
+  static __device__ __forceinline__ Acc run(float a, float b, Acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+
 #ifdef BSP_KDEBUG
 #define BSP_STAMP(slot) if (threadIdx.x == 0 && blockIdx.x == 0) bspDebugStamps[slot] = clock64()
 __device__ long long bspDebugStamps[16];
@@ -344,96 +367,120 @@ __device__ long long bspDebugStamps[16];
 template <typename T>
 __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
                                                   const int32_t* levelPanels, DataRef<T> dref) {
-  BSP_STAMP(0);
-  // Thread (i,g) = (tid/4, tid%4) keeps the 16 entries k = 4*kk+g of row i in registers, so the
-  // quad of row i holds column block J (columns 4J..4J+3) in its registers a[J].  One step per
-  // 4-column pivot block (16 steps, two barriers each):
-  //   (1) the raw block is in LDS (raw[i][0..3]); every thread factors the 4x4 pivot redundantly,
-  //       solves its own row against it and publishes the solved row (sol[i][0..3]);
-  //   (2) every thread applies the rank-4 update  a[kk] -= <sol[i], sol[k]>  to its registers and
-  //       publishes the next raw column block.
-  // Branch-free (selects) apart from wave-uniform conditions.  Strictly-upper entries are carried
-  // as finite mirror values and never written back; rows/columns beyond nb are padded with the
-  // identity.
+  // The 64x64 block lives in MFMA accumulator layout: wave w owns tile row w (16x16 tiles
+  // (w,0..w)); lane l / register r of tile (ti,tj) hold row 16ti + Mfma::row(l,r), column
+  // 16tj + (l&15).  One step per 4-column pivot block (16 steps, two barriers each):
+  //   (1) the lanes that hold columns 4J..4J+3 publish them (raw[row][0..3]);
+  //   (2) thread (i,g) = (tid/4, tid%4) factors the 4x4 pivot redundantly (hardware rsq + Newton),
+  //       solves row i against it and publishes sol[i][g] (zero for rows that are done) and the
+  //       final entry fin[i][g] = L(i, 4J+g);
+  //   (3) every tile gets the rank-4 update  D -= sol_rows * sol_cols^T  as ONE v_mfma 16x16x4
+  //       (operands: one LDS read each) -- the register/LDS formulation of this update was LDS
+  //       bandwidth bound -- and the holder lanes install the final column block.
+  // Finished columns are protected by the zeros in sol, so full-tile updates need no masks.
+  // Strictly-upper entries are carried as finite mirror values and never written back; rows and
+  // columns beyond nb are padded with the identity.
   __shared__ T raw[kPanelWidth][4];
   __shared__ T sol[kPanelWidth][4];
+  __shared__ T fin[kPanelWidth][4];
+  BSP_STAMP(0);
   const PanelDesc pd = panels[levelPanels[blockIdx.x]];
   T* A = pickData(dref) + pd.diagOff;
   const int nb = pd.nb, lda = pd.lda, tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
   const int i = tid >> 2, g = tid & 3;
-  const int iLd = min(i, nb - 1);
-  T a[16];
+  using Acc = typename Mfma<T>::Acc;
+  Acc acc[4];
 #pragma unroll
-  for (int kk = 0; kk < 16; kk++) {
-    const int k = 4 * kk + g;
-    const T v = A[(int64_t)iLd * lda + min(k, iLd)];
-    a[kk] = (i < nb && k <= i) ? v : ((i >= nb && k == i) ? T(1) : T(0));
+  for (int tj = 0; tj < 4; tj++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * w + Mfma<T>::row(lane, r), col = 16 * tj + li;
+      const int rl = min(row, nb - 1);
+      const T v = A[(int64_t)rl * lda + min(col, rl)];
+      acc[tj][r] = (row < nb && col <= row) ? v : ((row >= nb && col == row) ? T(1) : T(0));
+    }
   }
-  raw[i][g] = a[0];
-  __syncthreads();
   BSP_STAMP(1);
   const int nSteps = (nb + 3) >> 2;
 #pragma unroll 1
   for (int J = 0; J < nSteps; J++) {
-    const int j0 = 4 * J;
-    // 4x4 pivot block (lower part), factored redundantly by every thread
-    const T p00 = raw[j0][0];
-    const T p10 = raw[j0 + 1][0], p11 = raw[j0 + 1][1];
-    const T p20 = raw[j0 + 2][0], p21 = raw[j0 + 2][1], p22 = raw[j0 + 2][2];
-    const T p30 = raw[j0 + 3][0], p31 = raw[j0 + 3][1], p32 = raw[j0 + 3][2], p33 = raw[j0 + 3][3];
-    const T r0 = raw[i][0], r1 = raw[i][1], r2 = raw[i][2], r3 = raw[i][3];
-    const T i0 = fastRsqrt(p00);
-    const T l00 = p00 * i0, l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
-    const T q11 = p11 - l10 * l10;
-    const T i1 = fastRsqrt(q11);
-    const T l11 = q11 * i1, l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
-    const T q22 = p22 - l20 * l20 - l21 * l21;
-    const T i2 = fastRsqrt(q22);
-    const T l22 = q22 * i2, l32 = (p32 - l30 * l20 - l31 * l21) * i2;
-    const T q33 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
-    const T i3 = fastRsqrt(q33);
-    const T l33 = q33 * i3;
-    // own row against the pivot
-    T c0 = r0 * i0;
-    T c1 = (r1 - c0 * l10) * i1;
-    T c2 = (r2 - c0 * l20 - c1 * l21) * i2;
-    T c3 = (r3 - c0 * l30 - c1 * l31 - c2 * l32) * i3;
-    const bool below = i >= j0 + 4;
-    // final values of column block J for this row
+    const int j0 = 4 * J, tjJ = J >> 2, cbase = 4 * (J & 3);
+    const bool holder = w >= tjJ && li >= cbase && li < cbase + 4;
+    // (1) publish the raw column block
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++) {
+      if (tj == tjJ && holder) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) raw[16 * w + Mfma<T>::row(lane, r)][li - cbase] = acc[tj][r];
+      }
+    }
+    __syncthreads();
+    // (2) pivot block + own row
     {
+      const T p00 = raw[j0][0];
+      const T p10 = raw[j0 + 1][0], p11 = raw[j0 + 1][1];
+      const T p20 = raw[j0 + 2][0], p21 = raw[j0 + 2][1], p22 = raw[j0 + 2][2];
+      const T p30 = raw[j0 + 3][0], p31 = raw[j0 + 3][1], p32 = raw[j0 + 3][2],
+              p33 = raw[j0 + 3][3];
+      const T r0 = raw[i][0], r1 = raw[i][1], r2 = raw[i][2], r3 = raw[i][3];
+      const T i0 = fastRsqrt(p00);
+      const T l00 = p00 * i0, l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+      const T q11 = p11 - l10 * l10;
+      const T i1 = fastRsqrt(q11);
+      const T l11 = q11 * i1, l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+      const T q22 = p22 - l20 * l20 - l21 * l21;
+      const T i2 = fastRsqrt(q22);
+      const T l22 = q22 * i2, l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+      const T q33 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
+      const T i3 = fastRsqrt(q33);
+      const T l33 = q33 * i3;
+      const T c0 = r0 * i0;
+      const T c1 = (r1 - c0 * l10) * i1;
+      const T c2 = (r2 - c0 * l20 - c1 * l21) * i2;
+      const T c3 = (r3 - c0 * l30 - c1 * l31 - c2 * l32) * i3;
+      const bool below = i >= j0 + 4;
       const int di = i - j0;  // row inside the pivot block when 0..3
       const T lrow0 = di == 0 ? l00 : di == 1 ? l10 : di == 2 ? l20 : l30;
       const T lrow1 = di == 1 ? l11 : di == 2 ? l21 : l31;
       const T lrow2 = di == 2 ? l22 : l32;
       const T inPiv = g == 0 ? lrow0 : g == 1 ? lrow1 : g == 2 ? lrow2 : l33;
       const T solved = g == 0 ? c0 : g == 1 ? c1 : g == 2 ? c2 : c3;
-      const bool pivRow = di >= 0 && di < 4;
-#pragma unroll
-      for (int kk = 0; kk < 16; kk++) {
-        if (kk == J) a[kk] = below ? solved : ((pivRow && g <= di) ? inPiv : a[kk]);
-      }
-      // publish the solved row (zero for rows that take no further part)
       sol[i][g] = below ? solved : T(0);
+      fin[i][g] = below ? solved : ((di >= 0 && g <= di) ? inPiv : T(0));
     }
-    if (!below) c0 = c1 = c2 = c3 = T(0);
     __syncthreads();
-    // straight-line on purpose (selects, no branches): all 32 LDS reads are issued up front
-    T nextRaw = T(0);
+    // (3) rank-4 update of every owned tile + install the final column block
+    {
+      const T sa = -sol[16 * w + li][lk];
 #pragma unroll
-    for (int kk = 1; kk < 16; kk++) {
-      const int k = 4 * kk + g;
-      const T upd = a[kk] - (c0 * sol[k][0] + c1 * sol[k][1] + c2 * sol[k][2] + c3 * sol[k][3]);
-      a[kk] = kk > J ? upd : a[kk];
-      nextRaw = kk == J + 1 ? a[kk] : nextRaw;
+      for (int tj = 0; tj < 4; tj++) {
+        if (tj <= w) {  // wave-uniform
+          const T sb = sol[16 * tj + li][lk];
+          acc[tj] = Mfma<T>::run(sa, sb, acc[tj]);
+        }
+      }
+#pragma unroll
+      for (int tj = 0; tj < 4; tj++) {
+        if (tj == tjJ && holder) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = 16 * w + Mfma<T>::row(lane, r);
+            const T f = fin[row][li - cbase];
+            acc[tj][r] = row >= j0 ? f : acc[tj][r];
+          }
+        }
+      }
     }
-    raw[i][g] = nextRaw;  // publish the next raw column block
-    __syncthreads();
   }
   BSP_STAMP(2);
 #pragma unroll
-  for (int kk = 0; kk < 16; kk++) {
-    const int k = 4 * kk + g;
-    if (i < nb && k <= i) A[(int64_t)i * lda + k] = a[kk];
+  for (int tj = 0; tj < 4; tj++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * w + Mfma<T>::row(lane, r), col = 16 * tj + li;
+      if (row < nb && col <= row) A[(int64_t)row * lda + col] = acc[tj][r];
+    }
   }
   BSP_STAMP(3);
 }
@@ -566,28 +613,6 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
 //   * fp32: v_mfma_f32_16x16x4_f32, C layout col = lane&15, row = 4*(lane>>4) + reg
 // ------------------------------------------------------------------------------------------
 constexpr int kUpdChunk = 32;  // K chunk of updateTile: 2 x 64 x 34 doubles = 35 KB LDS -> 4 WG/CU
-typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef float float4_t __attribute__((ext_vector_type(4)));
-
-template <typename T>
-struct Mfma;
-template <>
-struct Mfma<double> {
-  using Acc = double4_t;
-  static __device__ __forceinline__ Acc run(double a, double b, Acc c) {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
-};
-template <>
-struct Mfma<float> {
-  using Acc = float4_t;
-  static __device__ __forceinline__ Acc run(float a, float b, Acc c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
-};
-
 template <typename T>
 __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const SegDesc* segs,
                                                   const UpdTask* tasks, const int64_t* chainOffTab,

@@ -439,7 +439,15 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       lr.trsmBegin = (int64_t)plan.trsmTasks.size();
       lr.updBegin = (int64_t)plan.updTasks.size();
       lr.waitDefLevel = -1;
+      lr.urgentCount = 0;
+      lr.potrfIssuedEarly = 0;
       const int64_t levelIdx = (int64_t)out.size();
+      // single-panel level followed by a single-panel level of the same lump?
+      const size_t bi = (size_t)(&bucket - &buckets[0]);
+      const bool chain = bucket.size() == 1 && bi + 1 < buckets.size() &&
+                         buckets[bi + 1].size() == 1 &&
+                         plan.panels[buckets[bi + 1][0].panel].lump == plan.panels[bucket[0].panel].lump;
+      if (bi > 0 && !out.empty() && out.back().urgentCount > 0) lr.potrfIssuedEarly = 1;
       vector<UpdTask> deferred, big, bigDeferred;
       // how many panels of this level hit each target lump
       std::map<int64_t, int> hits;
@@ -475,6 +483,11 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                 anyDeferred = true;
               } else if (useBig) {
                 big.push_back(t);
+              } else if (chain && sd.kind == kSegIntra && sd.q0 == 0 && cT == 0 && rT == 0 &&
+                         s == panelSegBegin[pb.panel]) {
+                // tile (0,0) of the panel's first intra-lump segment = next panel's diagonal block
+                plan.updTasks.insert(plan.updTasks.begin() + lr.updBegin, t);
+                lr.urgentCount = 1;
               } else {
                 plan.updTasks.push_back(t);
               }
@@ -516,7 +529,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       lr.bigDefEnd = (int64_t)plan.updTasks.size();
       plan.numLaunches += (lr.bigEnd > lr.bigBegin) + (lr.bigDefEnd > lr.bigDefBegin);
       if (lr.defEnd > lr.defBegin || lr.bigDefEnd > lr.bigDefBegin) plan.hasDeferred = true;
-      xcdOrder(lr.updBegin, lr.updEnd);
+      xcdOrder(lr.updBegin + lr.urgentCount, lr.updEnd);
       xcdOrder(lr.defBegin, lr.defEnd);
       plan.maxPanelsInLevel = std::max<int64_t>(plan.maxPanelsInLevel, lr.panelEnd - lr.panelBegin);
       plan.numLaunches += 1 + (lr.trsmEnd > lr.trsmBegin) + (lr.updEnd > lr.updBegin) +
@@ -604,6 +617,8 @@ HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly)
       lr.updEnd = (int64_t)plan.updTasks.size();
       lr.defBegin = lr.defEnd = lr.updEnd;
       lr.bigBegin = lr.bigEnd = lr.bigDefBegin = lr.bigDefEnd = lr.updEnd;
+      lr.urgentCount = 0;
+      lr.potrfIssuedEarly = 0;
       plan.levels.push_back(lr);
     }
   }

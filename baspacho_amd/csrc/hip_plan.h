@@ -93,6 +93,12 @@ struct LevelRange {
   int64_t defBegin, defEnd;      // into updTasks (deferred tiles of this level)
   // the same two lists for the 128x128-tile kernel (large segments)
   int64_t bigBegin, bigEnd, bigDefBegin, bigDefEnd;
+  // EARLY POTRF.  When this level and the next one each hold a single panel of the same lump,
+  // the first `urgentCount` tiles of [updBegin, updEnd) are the ones that complete the next
+  // panel's diagonal block: they are launched first and the next level's potrf may start right
+  // after them, concurrently with the remaining tiles (the next level then skips its potrf).
+  int64_t urgentCount;
+  int32_t potrfIssuedEarly;  // this level's potrf was already launched by the previous level
   int64_t waitDefLevel;          // index (within the same level list) of the level whose deferred
                                  // tiles must be complete before this level's update launch; -1
 };
