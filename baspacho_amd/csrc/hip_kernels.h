@@ -567,6 +567,7 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
   constexpr int LDL = kPanelWidth + 1;
   __shared__ T Ls[kPanelWidth * LDL];
   __shared__ T invDiag[kPanelWidth];
+  BSP_STAMP(4);
   const TrsmTask task = tasks[blockIdx.x];
   const PanelDesc pd = panels[task.panel];
   T* data = pickData(dref);
@@ -576,19 +577,25 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
   const int rows = min(kTile, pd.rowsBelow - task.rowTile);
   const int nbPad = nb <= 8 ? 8 : nb <= 16 ? 16 : nb <= 32 ? 32 : 64;
 
-  // lane = column, one row per wave per pass; zero above the diagonal and in the padding
+  // lane = column, wave w takes rows w, w+4, ...; all loads are issued before the first LDS write
+  // (addresses clamped, values masked): zero above the diagonal and in the padding
   {
-    const int j = tid & 63;
-    for (int i = tid >> 6; i < nbPad; i += 4) {
-      if (j < nbPad) {
-        T v = T(0);
-        if (i < nb && j <= i) v = A[(int64_t)i * lda + j];
-        Ls[i * LDL + j] = v;
-      }
+    const int j = tid & 63, w = tid >> 6;
+    T v[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int i = min(w + 4 * it, nb - 1);
+      v[it] = A[(int64_t)i * lda + min(j, i)];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int i = w + 4 * it;
+      if (i < nbPad && j < nbPad) Ls[i * LDL + j] = (i < nb && j <= i) ? v[it] : T(0);
     }
   }
   if (tid < kPanelWidth) invDiag[tid] = tid < nb ? T(1) / A[(int64_t)tid * lda + tid] : T(0);
   __syncthreads();
+  BSP_STAMP(5);
   if (nb <= 8) {
     trsmRows<T, 8>(Ls, invDiag, P, lda, nb, rows, tid);
   } else if (nb <= 16) {
@@ -598,6 +605,7 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
   } else {
     trsmRows<T, 64>(Ls, invDiag, P, lda, nb, rows, tid);
   }
+  BSP_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------

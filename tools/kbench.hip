@@ -111,6 +111,8 @@ int main(int argc, char** argv) {
   printf("empty kernel      : %8.1f us\n", us);
   us = timeIt([&] { hipk::trsmPanel<double><<<(unsigned)tt.size(), 256>>>(dpd, dtt, ref); }, 50);
   printf("trsmPanel         : %8.1f us  (%zu tasks)\n", us, tt.size());
+  { long long st[16]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(hipk::bspDebugStamps), sizeof st));
+    printf("   trsm cycles (block 0): stage L %lld, rows %lld (total %.1f us)\n", st[5]-st[4], st[6]-st[5], (st[6]-st[4])/2400.0); }
   double updFlops = 0; { double R = pd.rowsBelow, m = sd.m; updFlops = 2.0 * K * (m * R - m * (m - 1) / 2); }
   us = timeIt([&] { hipk::updateTile<double><<<(unsigned)ut.size(), 256>>>(dsr, dsd, dut, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
   printf("updateTile plain  : %8.1f us  -> %.2f TF/s\n", us, updFlops / us / 1e6);
