@@ -434,6 +434,14 @@ struct HipNumericCtx : NumericCtx<T> {
             plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems);
         timer.end();
       }
+      const int64_t nTiny = er.tinyEnd - er.tinyBegin;
+      if (nTiny > 0) {
+        timer.begin(kProfElimUpdate);
+        hipk::elimGatherTiny<BT><<<dim3((unsigned)((nTiny + 15) / 16), gy), 256, 0, sym.stream>>>(
+            plan.elimItems.as<ElimGatherItem>() + er.tinyBegin, plan.elimPairOffJ.as<uint32_t>(),
+            plan.elimPairOffI.as<uint32_t>(), ref, (int)nTiny);
+        timer.end();
+      }
     } else if (nChains > 0) {
       timer.begin(kProfElimUpdate);
       hipk::elimUpdate<BT><<<dim3((unsigned)((nChains + 3) / 4), gy), 256, 0, sym.stream>>>(

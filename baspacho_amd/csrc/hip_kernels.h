@@ -329,6 +329,40 @@ __global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, c
   }
 }
 
+// K2t  the same gather for TINY target blocks (<= 16 elements, e.g. the 3x3 blocks of automatically
+// detected elimination ranges): four items per wave, 16 lanes each, operands straight from
+// global memory (a pair's blocks are a few dozen bytes).
+template <typename T>
+__global__ __launch_bounds__(256) void elimGatherTiny(const ElimGatherItem* items,
+                                                      const uint32_t* offJ, const uint32_t* offI,
+                                                      DataRef<T> dref, int numItems) {
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const int idx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  if (idx >= numItems) return;
+  const ElimGatherItem it = items[idx];
+  T* data = pickData(dref);
+  const int cols = it.cols, n = it.n, total = int(it.rows) * cols;
+  const bool live = sub < total;
+  const int e = live ? sub : 0;
+  const int r = e / cols, q = e - r * cols;
+  T acc = T(0);
+  for (int p = it.pairBegin; p < it.pairEnd; p++) {
+    const T* Bj = data + offJ[p] + r * n;
+    const T* Bi = data + offI[p] + q * n;
+    T d = T(0);
+    for (int k = 0; k < n; k++) d += Bj[k] * Bi[k];
+    acc += d;
+  }
+  if (live && !((it.flags & 2) && q > r)) {
+    T* target = data + it.tgtOff + (int64_t)r * it.tgtStride + q;
+    if (it.flags & 1) {
+      atomicSub(target, acc);
+    } else {
+      *target -= acc;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K3  panel potrf: in-place Cholesky of the nb x nb (nb <= 64) diagonal block of a panel, one
 // workgroup per panel, whole block in LDS.  Replaces cusolverDn?potrf / potrfBatched

@@ -152,6 +152,24 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   }
   er.itemEnd = (int64_t)plan.elimItems.size();
   er.useGather = true;
+  // items whose target block has at most 16 elements (e.g. 3x3 blocks of automatically detected
+  // ranges) go to the kernel that packs four items per wave: move them behind the others
+  {
+    vector<ElimGatherItem> large, tiny;
+    vector<int64_t> tagL, tagT;
+    for (int64_t k = er.itemBegin; k < er.itemEnd; k++) {
+      const ElimGatherItem& it = plan.elimItems[k];
+      const bool isTiny = int(it.rows) * int(it.cols) <= 16;
+      (isTiny ? tiny : large).push_back(it);
+      (isTiny ? tagT : tagL).push_back(itemRowTag[k - er.itemBegin]);
+    }
+    std::copy(large.begin(), large.end(), plan.elimItems.begin() + er.itemBegin);
+    std::copy(tiny.begin(), tiny.end(), plan.elimItems.begin() + er.itemBegin + (int64_t)large.size());
+    itemRowTag = tagL;
+    er.itemEnd = er.itemBegin + (int64_t)large.size();
+    er.tinyBegin = er.itemEnd;
+    er.tinyEnd = er.tinyBegin + (int64_t)tiny.size();
+  }
   // XCD-aware order (speed only).  A workgroup takes 4 consecutive items and workgroup b runs on
   // XCD b % 8, each XCD with its own 4 MB L2.  All items of one target ROW (same sj) read the same
   // B_j source blocks, so a row is handed to ONE XCD (row r -> XCD r % 8, rows balance the load

@@ -129,7 +129,8 @@ struct ElimRangePlan {
   int32_t maxWidth;              // widest lump of the range
   std::vector<LevelRange> bigLevels;  // lumps wider than kElimSmallMax go through panels
   bool useGather = false;             // pair updates in gather form (atomic-free) ...
-  int64_t itemBegin = 0, itemEnd = 0; // ... over these ElimGatherItems
+  int64_t itemBegin = 0, itemEnd = 0; // ... over these ElimGatherItems (one wave per item)
+  int64_t tinyBegin = 0, tinyEnd = 0; // items with <= 16 target elements: 4 items per wave
 };
 
 struct HipPlanHost {
