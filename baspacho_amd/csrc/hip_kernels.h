@@ -398,41 +398,44 @@ __device__ long long bspDebugStamps[16];
 #define BSP_STAMP(slot)
 #endif
 
-template <typename T>
-__global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
-                                                  const int32_t* levelPanels, DataRef<T> dref) {
-  // The 64x64 block lives in MFMA accumulator layout: wave w owns tile row w (16x16 tiles
-  // (w,0..w)); lane l / register r of tile (ti,tj) hold row 16ti + Mfma::row(l,r), column
-  // 16tj + (l&15).  One step per 4-column pivot block (16 steps, two barriers each):
+// NT = tiles per dimension (NT = 4: 64x64 block, 256 threads).  A 256x256 single-workgroup variant
+// (NT = 16 / paired tile rows, 512 threads) and a fused 256-column trsm were built and measured:
+// 184 us + 77 us per outer block against ~165 us for the four 64-wide panel steps they would
+// replace -- the serial dependent-latency per 4-column step dominates either way -- so the
+// 64-wide panel chain stays.
+template <typename T, int NT>
+__device__ __forceinline__ void potrfTiles(T* A, int nb, int lda, T (*raw)[4], T (*sol)[4],
+                                           T (*fin)[4]) {
+  // The block lives in MFMA accumulator layout: wave w owns tile row w (16x16 tiles (w,0..w));
+  // lane l / register r of tile (ti,tj) hold row 16ti + Mfma::row(l,r), column 16tj + (l&15).
+  // One step per 4-column pivot block (two barriers each):
   //   (1) the lanes that hold columns 4J..4J+3 publish them (raw[row][0..3]);
   //   (2) thread (i,g) = (tid/4, tid%4) factors the 4x4 pivot redundantly (hardware rsq + Newton),
   //       solves row i against it and publishes sol[i][g] (zero for rows that are done) and the
   //       final entry fin[i][g] = L(i, 4J+g);
-  //   (3) every tile gets the rank-4 update  D -= sol_rows * sol_cols^T  as ONE v_mfma 16x16x4
-  //       (operands: one LDS read each) -- the register/LDS formulation of this update was LDS
-  //       bandwidth bound -- and the holder lanes install the final column block.
+  //   (3) every live tile gets the rank-4 update  D -= sol_rows * sol_cols^T  as ONE v_mfma
+  //       16x16x4 (operands: one LDS read each) and the holder lanes install the final column
+  //       block.
   // Finished columns are protected by the zeros in sol, so full-tile updates need no masks.
   // Strictly-upper entries are carried as finite mirror values and never written back; rows and
   // columns beyond nb are padded with the identity.
-  __shared__ T raw[kPanelWidth][4];
-  __shared__ T sol[kPanelWidth][4];
-  __shared__ T fin[kPanelWidth][4];
-  BSP_STAMP(0);
-  const PanelDesc pd = panels[levelPanels[blockIdx.x]];
-  T* A = pickData(dref) + pd.diagOff;
-  const int nb = pd.nb, lda = pd.lda, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
   const int i = tid >> 2, g = tid & 3;
   using Acc = typename Mfma<T>::Acc;
-  Acc acc[4];
+  Acc acc[NT];
 #pragma unroll
-  for (int tj = 0; tj < 4; tj++) {
+  for (int tj = 0; tj < NT; tj++) {
+    if (tj <= w) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = 16 * w + Mfma<T>::row(lane, r), col = 16 * tj + li;
-      const int rl = min(row, nb - 1);
-      const T v = A[(int64_t)rl * lda + min(col, rl)];
-      acc[tj][r] = (row < nb && col <= row) ? v : ((row >= nb && col == row) ? T(1) : T(0));
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * w + Mfma<T>::row(lane, r), col = 16 * tj + li;
+        const int rl = min(row, nb - 1);
+        const T v = A[(int64_t)rl * lda + min(col, rl)];
+        acc[tj][r] = (row < nb && col <= row) ? v : ((row >= nb && col == row) ? T(1) : T(0));
+      }
+    } else {
+      acc[tj] = Acc{0, 0, 0, 0};
     }
   }
   BSP_STAMP(1);
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
     const bool holder = w >= tjJ && li >= cbase && li < cbase + 4;
     // (1) publish the raw column block
 #pragma unroll
-    for (int tj = 0; tj < 4; tj++) {
+    for (int tj = 0; tj < NT; tj++) {
       if (tj == tjJ && holder) {
 #pragma unroll
         for (int r = 0; r < 4; r++) raw[16 * w + Mfma<T>::row(lane, r)][li - cbase] = acc[tj][r];
@@ -484,18 +487,18 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
       fin[i][g] = below ? solved : ((di >= 0 && g <= di) ? inPiv : T(0));
     }
     __syncthreads();
-    // (3) rank-4 update of every owned tile + install the final column block
+    // (3) rank-4 update of every live tile + install the final column block
     {
       const T sa = -sol[16 * w + li][lk];
 #pragma unroll
-      for (int tj = 0; tj < 4; tj++) {
-        if (tj <= w) {  // wave-uniform
+      for (int tj = 0; tj < NT; tj++) {
+        if (tj <= w && tj >= tjJ) {  // wave-uniform; tile columns left of the pivot are final
           const T sb = sol[16 * tj + li][lk];
           acc[tj] = Mfma<T>::run(sa, sb, acc[tj]);
         }
       }
 #pragma unroll
-      for (int tj = 0; tj < 4; tj++) {
+      for (int tj = 0; tj < NT; tj++) {
         if (tj == tjJ && holder) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
@@ -509,13 +512,26 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
   }
   BSP_STAMP(2);
 #pragma unroll
-  for (int tj = 0; tj < 4; tj++) {
+  for (int tj = 0; tj < NT; tj++) {
+    if (tj <= w) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = 16 * w + Mfma<T>::row(lane, r), col = 16 * tj + li;
-      if (row < nb && col <= row) A[(int64_t)row * lda + col] = acc[tj][r];
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * w + Mfma<T>::row(lane, r), col = 16 * tj + li;
+        if (row < nb && col <= row) A[(int64_t)row * lda + col] = acc[tj][r];
+      }
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
+                                                  const int32_t* levelPanels, DataRef<T> dref) {
+  __shared__ T raw[kPanelWidth][4];
+  __shared__ T sol[kPanelWidth][4];
+  __shared__ T fin[kPanelWidth][4];
+  BSP_STAMP(0);
+  const PanelDesc pd = panels[levelPanels[blockIdx.x]];
+  potrfTiles<T, 4>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, raw, sol, fin);
   BSP_STAMP(3);
 }
 

@@ -222,6 +222,21 @@ def main():
                                                (prof["elim_factor"][0] * 1e-3) / 1e9, 1)
             out["kernel_rates"] = sec
 
+        # ---- device solve() on the last factor (not part of the metric; BENCHMARK_RESULTS.md of the
+        #      reference reports solve-1 timings separately too)
+        try:
+            rhs = torch.from_numpy(T.random_data(order, -1, 1, 38)).to(device)
+            work = rhs.clone()
+            sol.solve(last, work, order, 1)  # warm-up
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            work.copy_(rhs)
+            sol.solve(last, work, order, 1)
+            torch.cuda.synchronize(device)
+            out["solve1_ms"] = round(1e3 * (time.perf_counter() - t0), 3)
+        except Exception as e:
+            out["solve1_ms"] = "error: %s" % e
+
         # ---- CPU baseline: the BackendFast restatement (oracle/blas_factor.c) on host cores --
         if world == 1 and not args.no_cpu_baseline:
             try:
