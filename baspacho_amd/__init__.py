@@ -400,6 +400,15 @@ def probe_mfma_f64_tflops():
     return out.value
 
 
+def debug_read_trace(max_records=8192):
+    """in-situ kernel clock records (library built with BSP_KTRACE=1), array [n, 4]"""
+    out = np.zeros((max_records, 4), dtype=np.int64)
+    n = ctypes.c_int(0)
+    _check(_lib.load().bsp_debug_read_trace(out.ctypes.data_as(ctypes.c_void_p), max_records,
+                                            ctypes.byref(n)))
+    return out[:n.value]
+
+
 def create_solver(settings: Optional[Settings], param_sizes, ss: SparseStructure,
                   sparse_elim_ranges=(), elim_last_ids=()) -> Solver:
     """createSolver (Solver.h:235-237): symbolic analysis on the host; never touches the GPU."""

@@ -318,6 +318,12 @@ int bsp_probe_mfma_f64(double* tflops) {
   BSP_CATCH
 }
 
+int bsp_debug_read_trace(long long* out, int max_records, int* n_records) {
+  BSP_TRY
+  *n_records = hipBackendReadTrace(out, max_records);
+  BSP_CATCH
+}
+
 int bsp_factor_profiled_f64(bsp_solver* s, double* d, double ms[5], int64_t launches[5]) {
   BSP_TRY
   HipKernelProfile prof;

@@ -35,6 +35,8 @@ void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof);
 
 // sustained fp64 MFMA rate of this GPU measured with a register-only probe kernel (TFLOP/s)
 double hipBackendMfmaF64ProbeTflops();
+// in-situ kernel trace (BSP_KTRACE builds only; returns 0 records otherwise)
+int hipBackendReadTrace(long long* out, int maxRecords);
 
 // TESTING: make factor() take the reference-style per-op loop (potrf/trsm/saveSyrkGemm/
 // prepareAssemble/assemble/doElimination virtuals) instead of the fused path

@@ -62,6 +62,18 @@ struct DevPlan {
   HipPlanHost host;
   DevBuf panels, srcs, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
       updTasks, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal;
+  // forward-solve gather lists, built on the first solve that needs them
+  bool solveGatherReady = false;
+  SolveGatherPlan solveGather;
+  DevBuf solveEntries, solveItems;
+  void ensureSolveGather(const CoalescedBlockMatrixSkel& skel) {
+    if (solveGatherReady) return;
+    solveGather = buildSolveGather(skel, host);
+    solveEntries.upload(solveGather.entries);
+    solveItems.upload(solveGather.items);
+    vector<SolveGatherEntry>().swap(solveGather.entries);
+    solveGatherReady = true;
+  }
   void upload() {
     panels.upload(host.panels);
     srcs.upload(host.srcs);
@@ -126,6 +138,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_NO_CRIT_STREAM")) critEnabled = e[0] == '0';
     if (const char* e = std::getenv("BSP_BULK_EXTRA_LDS")) bulkExtraLds = (unsigned)atoi(e);
     if (const char* e = std::getenv("BSP_NO_EARLY_POTRF")) earlyPotrf = e[0] == '0';
+    if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -210,23 +223,31 @@ struct HipSymbolicCtx : SymbolicCtx {
                                               int batchSize) override;
 
   // side stream + event pool of the lookahead schedule (created on first use)
+  // CU mask with every k-th CU set (invert = false) or cleared (invert = true)
+  static std::vector<uint32_t> everyKthCuMask(int k, bool invert) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    hipCHECK(hipGetDevice(&dev));
+    hipCHECK(hipGetDeviceProperties(&prop, dev));
+    const int nCu = prop.multiProcessorCount;
+    std::vector<uint32_t> mask((nCu + 31) / 32, 0u);
+    for (int cu = 0; cu < nCu; cu++) {
+      const bool kth = cu % k == k - 1;
+      if (kth != invert) mask[cu / 32] |= 1u << (cu % 32);
+    }
+    return mask;
+  }
+  static int reserveEvery() {
+    const char* e = std::getenv("BSP_RESERVE_EVERY");
+    return e ? atoi(e) : 0;
+  }
   hipStream_t sideStream() {
     if (!side) {
       // Optional experiment (BSP_RESERVE_EVERY=k): keep every k-th CU free of bulk work with a CU
-      // mask.  Measured on MI355X: a CU-masked side stream makes the whole factor 45-70 % SLOWER
-      // (20-23 ms vs 13.6 ms), so the default is a plain lowest-priority stream.
-      int reserveEvery = 0;
-      if (const char* e = std::getenv("BSP_RESERVE_EVERY")) reserveEvery = atoi(e);
-      hipDeviceProp_t prop;
-      int dev = 0;
-      hipCHECK(hipGetDevice(&dev));
-      hipCHECK(hipGetDeviceProperties(&prop, dev));
-      const int nCu = prop.multiProcessorCount;
-      if (reserveEvery >= 2 && nCu >= 64) {
-        std::vector<uint32_t> mask((nCu + 31) / 32, 0u);
-        for (int cu = 0; cu < nCu; cu++) {
-          if (cu % reserveEvery != reserveEvery - 1) mask[cu / 32] |= 1u << (cu % 32);
-        }
+      // mask (and pin the critical chain to those CUs, see critStream).
+      const int k = reserveEvery();
+      if (k >= 2) {
+        std::vector<uint32_t> mask = everyKthCuMask(k, /*invert=*/true);
         hipCHECK(hipExtStreamCreateWithCUMask(&side, (uint32_t)mask.size(), mask.data()));
       } else {
         int least = 0, greatest = 0;
@@ -242,6 +263,10 @@ struct HipSymbolicCtx : SymbolicCtx {
   }
   // high-priority stream for the latency-critical chain while a bulk update runs beside it
   hipStream_t critStream() {
+    if (!crit && reserveEvery() >= 2 && std::getenv("BSP_PIN_CHAIN")) {
+      std::vector<uint32_t> mask = everyKthCuMask(reserveEvery(), /*invert=*/false);
+      hipCHECK(hipExtStreamCreateWithCUMask(&crit, (uint32_t)mask.size(), mask.data()));
+    }
     if (!crit) {
       int least = 0, greatest = 0;
       hipCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -270,6 +295,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
   hipStream_t side = nullptr, crit = nullptr, third = nullptr;
   bool earlyPotrf = false;  // measured SLOWER (15.2 vs 13.1 ms): cross-stream events per panel cost more than the overlap saves
+  bool directChain = true;  // descriptor-by-value kernels on one-panel levels (BSP_DIRECT_CHAIN=0 disables)
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
 
@@ -324,20 +350,31 @@ struct HipNumericCtx : NumericCtx<T> {
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
       const bool early = lookahead && sym.earlyPotrf;
+      const bool direct = sym.directChain && lr.directPanel >= 0;
       if (nP && early && lr.potrfIssuedEarly && potrfDone) {
         // this level's potrf already ran on the third stream: just order after it
         hipCHECK(hipStreamWaitEvent(sym.stream, potrfDone, 0));
         potrfDone = nullptr;
       } else if (nP) {
         timer.begin(kProfPotrf);
-        hipk::potrfPanel<BT><<<dim3(nP, gy.y), 256, 0, sym.stream>>>(
-            plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, ref);
+        if (direct) {
+          hipk::potrfPanelDirect<BT><<<dim3(1, gy.y), 256, 0, sym.stream>>>(
+              plan.host.panels[lr.directPanel], ref);
+        } else {
+          hipk::potrfPanel<BT><<<dim3(nP, gy.y), 256, 0, sym.stream>>>(
+              plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, ref);
+        }
         timer.end();
       }
       if (nT) {
         timer.begin(kProfTrsm);
-        hipk::trsmPanel<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
-            plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin, ref);
+        if (direct) {
+          hipk::trsmPanelDirect<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
+              plan.host.panels[lr.directPanel], ref);
+        } else {
+          hipk::trsmPanel<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
+              plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin, ref);
+        }
         timer.end();
       }
       if (lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
@@ -366,7 +403,14 @@ struct HipNumericCtx : NumericCtx<T> {
       }
       if (lr.updEnd > updBegin) {
         timer.begin(kProfUpdate);
-        launchUpdate(plan, updBegin, lr.updEnd, ref, sym.stream);
+        if (direct && lr.directSeg >= 0 && updBegin == lr.updBegin) {
+          const SegDesc& sd = plan.host.segs[lr.directSeg];
+          hipk::updateTileDirect<BT><<<dim3((unsigned)(lr.updEnd - updBegin), gy.y), 256, 0,
+                                     sym.stream>>>(plan.host.srcs[sd.src], sd,
+                                                   (int)(lr.updEnd - updBegin), ref);
+        } else {
+          launchUpdate(plan, updBegin, lr.updEnd, ref, sym.stream);
+        }
         timer.end();
       }
       const bool anyDef = lr.defEnd > lr.defBegin || lr.bigDefEnd > lr.bigDefBegin;
@@ -644,9 +688,22 @@ struct HipSolveCtx : SolveCtx<T> {
     const int64_t nLumps = er.lumpEnd - er.lumpBegin;
     if (nLumps <= 0) return;
     auto small = [&] {
-      hipk::solveElimSmall<T, BACKWARD><<<dim3((unsigned)((nLumps + 255) / 256), (unsigned)nRHS),
-                                         256, 0, sym.stream>>>(sk, data, C, ldc, er.lumpBegin,
-                                                               er.lumpEnd);
+      const dim3 gL((unsigned)((nLumps + 255) / 256), (unsigned)nRHS);
+      if (BACKWARD) {
+        hipk::solveElimSmall<T, true><<<gL, 256, 0, sym.stream>>>(sk, data, C, ldc, er.lumpBegin,
+                                                                  er.lumpEnd);
+        return;
+      }
+      plan.ensureSolveGather(sym.skel);
+      const auto items = plan.solveGather.rangeItems[&er - plan.host.elimRanges.data()];
+      hipk::solveElimDiagL<T><<<gL, 256, 0, sym.stream>>>(sk, data, C, ldc, er.lumpBegin,
+                                                          er.lumpEnd);
+      if (items.second > items.first) {
+        hipk::solveElimGatherL<T><<<dim3((unsigned)(items.second - items.first), (unsigned)nRHS),
+                                    256, 0, sym.stream>>>(
+            plan.solveItems.as<SolveGatherItem>() + items.first,
+            plan.solveEntries.as<SolveGatherEntry>(), data, C, ldc);
+      }
     };
     // lumps of a range are mutually independent: the order small/wide does not matter
     if (!BACKWARD) {
@@ -669,7 +726,7 @@ struct HipSolveCtx : SolveCtx<T> {
       if (!nP) continue;
       const dim3 gP(nP, (unsigned)nRHS), gT(nT, (unsigned)nRHS);
       if (!BACKWARD) {
-        hipk::solveTriPanel<T, false><<<gP, 64, 0, sym.stream>>>(
+        hipk::solveTriPanel<T, false><<<gP, 256, 0, sym.stream>>>(
             plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, data, C, ldc);
         if (nT) {
           hipk::solveGemvL<T><<<gT, 256, 0, sym.stream>>>(
@@ -682,7 +739,7 @@ struct HipSolveCtx : SolveCtx<T> {
               plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin,
               plan.rowGlobal.as<int32_t>(), data, C, ldc);
         }
-        hipk::solveTriPanel<T, true><<<gP, 64, 0, sym.stream>>>(
+        hipk::solveTriPanel<T, true><<<gP, 256, 0, sym.stream>>>(
             plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, data, C, ldc);
       }
     }
@@ -740,6 +797,23 @@ struct HipOps : Ops {
 }  // namespace
 
 OpsPtr hipOps() { return OpsPtr(new HipOps); }
+
+int hipBackendReadTrace(long long* out, int maxRecords) {
+#ifdef BSP_KTRACE
+  unsigned n = 0;
+  hipCHECK(hipDeviceSynchronize());
+  hipCHECK(hipMemcpyFromSymbol(&n, HIP_SYMBOL(hipk::bspTraceCount), sizeof n));
+  const int cnt = (int)std::min<unsigned>(n, (unsigned)std::min(maxRecords, 8192));
+  hipCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(hipk::bspTrace), sizeof(long long) * 4 * cnt));
+  n = 0;
+  hipCHECK(hipMemcpyToSymbol(HIP_SYMBOL(hipk::bspTraceCount), &n, sizeof n));
+  return cnt;
+#else
+  (void)out;
+  (void)maxRecords;
+  return 0;
+#endif
+}
 
 double hipBackendMfmaF64ProbeTflops() {
   const int blocks = 1024, iters = 4000;

@@ -391,7 +391,18 @@ struct Mfma<float> {
 };
 
 
-#ifdef BSP_KDEBUG
+#if defined(BSP_KTRACE)
+// in-situ trace build (build.sh with BSP_KTRACE=1): every launch of a stamped kernel appends one
+// record of 4 clock values; read back with hipBackendReadTrace()
+__device__ long long bspTrace[8192 * 4];
+__device__ unsigned bspTraceCount;
+__shared__ unsigned bspTraceSlot;
+#define BSP_STAMP(slot)                                                        \
+  if (threadIdx.x == 0 && blockIdx.x == 0) {                                   \
+    if ((slot) == 0) bspTraceSlot = atomicAdd(&bspTraceCount, 1u) & 8191u;     \
+    bspTrace[bspTraceSlot * 4 + (slot)] = clock64();                           \
+  }
+#elif defined(BSP_KDEBUG)
 #define BSP_STAMP(slot) if (threadIdx.x == 0 && blockIdx.x == 0) bspDebugStamps[slot] = clock64()
 __device__ long long bspDebugStamps[16];
 #else
@@ -535,6 +546,23 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
   BSP_STAMP(3);
 }
 
+// DIRECT variants (potrfPanelDirect / trsmPanelDirect / updateTileDirect) serve the levels that
+// hold ONE panel -- the serial chain of a wide lump.  Their descriptors travel in the kernel
+// arguments instead of behind two or three dependent table loads, and every global load of a
+// workgroup is issued up front: the chain is bound by memory round trips (2-3x longer while a
+// bulk update saturates the memory system beside it), so each kernel is cut to one load round
+// trip plus the store.
+template <typename T>
+__global__ __launch_bounds__(256) void potrfPanelDirect(PanelDesc pd, DataRef<T> dref) {
+  __shared__ T raw[kPanelWidth][4];
+  __shared__ T sol[kPanelWidth][4];
+  __shared__ T fin[kPanelWidth][4];
+  __builtin_amdgcn_s_setprio(3);
+  BSP_STAMP(0);
+  potrfTiles<T, 4>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, raw, sol, fin);
+  BSP_STAMP(3);
+}
+
 // ------------------------------------------------------------------------------------------
 // K4  panel trsm: X * L^T = B for a tile of 64 rows below the panel's diagonal block.
 // One wave per task; L and the row tile live in LDS (tile transposed, xs[j][row], padded so
@@ -656,6 +684,86 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
     trsmRows<T, 64>(Ls, invDiag, P, lda, nb, rows, tid);
   }
   BSP_STAMP(6);
+}
+
+// direct variant: the row tile is blockIdx.x, the rows are fetched together with L
+template <typename T, int NB>
+__device__ __forceinline__ void trsmDirectBody(const T* A, T* P, int lda, int nb, int rows, T* Ls,
+                                               T* invDiag) {
+  constexpr int LDL = kPanelWidth + 1, M = NB / 8;
+  constexpr int NL = (NB * NB + 255) / 256;
+  const int tid = threadIdx.x, r = tid >> 2, g = tid & 3;
+  const bool active = r < rows;
+  T* row = P + (int64_t)(active ? r : 0) * lda;
+  T x[M][2], v[NL];
+#pragma unroll
+  for (int m = 0; m < M; m++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) x[m][h] = row[min(8 * m + 2 * g + h, nb - 1)];
+  }
+#pragma unroll
+  for (int it = 0; it < NL; it++) {
+    const int e = tid + 256 * it, i = min(e / NB, nb - 1), j = e % NB;
+    v[it] = A[(int64_t)i * lda + min(j, i)];
+  }
+  const T d = A[(int64_t)min(tid, nb - 1) * (lda + 1)];
+#pragma unroll
+  for (int it = 0; it < NL; it++) {
+    const int e = tid + 256 * it, i = e / NB, j = e % NB;
+    if (e < NB * NB) Ls[i * LDL + j] = (i < nb && j <= i) ? v[it] : T(0);
+  }
+  if (tid < NB) invDiag[tid] = tid < nb ? T(1) / d : T(0);
+#pragma unroll
+  for (int m = 0; m < M; m++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) x[m][h] = (active && 8 * m + 2 * g + h < nb) ? x[m][h] : T(0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    const int mj = j >> 3, gj = (j >> 1) & 3, hj = j & 1;
+    T xj = x[mj][hj] * invDiag[j];
+    xj = quadBcastSel(xj, gj);
+#pragma unroll
+    for (int m = mj; m < M; m++) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int k = 8 * m + 2 * g + h;
+        x[m][h] -= xj * Ls[k * LDL + j];
+      }
+    }
+    x[mj][hj] = (g == gj) ? xj : x[mj][hj];
+  }
+#pragma unroll
+  for (int m = 0; m < M; m++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int k = 8 * m + 2 * g + h;
+      if (active && k < nb) row[k] = x[m][h];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trsmPanelDirect(PanelDesc pd, DataRef<T> dref) {
+  constexpr int LDL = kPanelWidth + 1;
+  __shared__ T Ls[kPanelWidth * LDL];
+  __shared__ T invDiag[kPanelWidth];
+  __builtin_amdgcn_s_setprio(3);
+  T* data = pickData(dref);
+  const T* A = data + pd.diagOff;
+  const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
+  T* P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
+  const int rows = min(kTile, pd.rowsBelow - rowTile);
+  if (nb <= 8) {
+    trsmDirectBody<T, 8>(A, P, lda, nb, rows, Ls, invDiag);
+  } else if (nb <= 16) {
+    trsmDirectBody<T, 16>(A, P, lda, nb, rows, Ls, invDiag);
+  } else if (nb <= 32) {
+    trsmDirectBody<T, 32>(A, P, lda, nb, rows, Ls, invDiag);
+  } else {
+    trsmDirectBody<T, 64>(A, P, lda, nb, rows, Ls, invDiag);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -814,6 +922,124 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
           if (ok[t * 4 + reg]) *ptr[t * 4 + reg] = old[t * 4 + reg] - (*accs[t])[reg];
+        }
+      }
+    }
+  }
+}
+
+// K5d  direct variant for the update tiles of a one-panel level that all belong to ONE
+// intra-lump segment: descriptors by value, the tile is decoded from blockIdx.x (same order as
+// the plan's task list: column tiles of the first `mNow` columns, each with its row tiles, then
+// the XCD-contiguous permutation), the old target values are fetched together with the first K
+// chunk and the next chunk is fetched while the current one is multiplied.
+template <typename T>
+__global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, int nTasks,
+                                                        DataRef<T> dref) {
+  constexpr int KC = kUpdChunk, LD = KC + 2;
+  __shared__ T As[kTile * LD];
+  __shared__ T Bs[kTile * LD];
+  __builtin_amdgcn_s_setprio(2);
+  int idx = blockIdx.x;
+  if (nTasks >= 64) {  // mirror of xcdOrder() in hip_plan.cpp
+    const int base = nTasks >> 3, extra = nTasks & 7, x = idx & 7;
+    idx = x * base + min(x, extra) + (idx >> 3);
+  }
+  int colTile = sd.q0, rowTile;
+  for (;;) {
+    const int cnt = (pd.rowsBelow - colTile + kTile - 1) / kTile;
+    if (idx < cnt) {
+      rowTile = colTile + kTile * idx;
+      break;
+    }
+    idx -= cnt;
+    colTile += kTile;
+  }
+  T* data = pickData(dref);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = pd.K, lda = pd.lda;
+  const T* P = data + pd.off;
+  const bool diagTile = rowTile == colTile;
+  const int segEnd = sd.q0 + sd.m;
+  const T* Bt = diagTile ? As : Bs;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  const int li = lane & 15, lk = lane >> 4;
+  using Acc = typename Mfma<T>::Acc;
+  Acc acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+  const bool skipUpper = diagTile && wr < wc;
+
+  constexpr int RSTEP = 256 / KC, NIT = kTile / RSTEP;
+  const int sk = tid % KC, sr = tid / KC;
+  T va[NIT], vb[NIT];
+  auto fetch = [&](int kBase) {
+    const int kcl = min(kBase + sk, K - 1);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int qa = min(rowTile + sr + RSTEP * it, pd.rowsBelow - 1);
+      va[it] = P[(int64_t)qa * lda + kcl];
+    }
+    if (!diagTile) {
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int qb = min(colTile + sr + RSTEP * it, segEnd - 1);
+        vb[it] = P[(int64_t)qb * lda + kcl];
+      }
+    }
+  };
+  fetch(0);
+  // old target values (masked-off entries are clamped onto valid ones)
+  T* tgt = data + sd.tgtBase;
+  T old[16];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int qc = min(colTile + wc + (t & 1) * 16 + li, segEnd - 1);
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      const int qr = min(rowTile + wr + (t >> 1) * 16 + Mfma<T>::row(lane, reg), pd.rowsBelow - 1);
+      old[t * 4 + reg] = tgt[(int64_t)qr * sd.tgtStride + qc];
+    }
+  }
+  for (int kBase = 0; kBase < K; kBase += KC) {
+    const int kc = min(KC, K - kBase);
+    const int kPad = (kc + 3) & ~3;
+    if (kBase > 0) __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int r = sr + RSTEP * it;
+      As[r * LD + sk] = (sk < kc && rowTile + r < pd.rowsBelow) ? va[it] : T(0);
+    }
+    if (!diagTile) {
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int r = sr + RSTEP * it;
+        Bs[r * LD + sk] = (sk < kc && colTile + r < segEnd) ? vb[it] : T(0);
+      }
+    }
+    __syncthreads();
+    if (kBase + KC < K) fetch(kBase + KC);
+    if (!skipUpper) {
+      for (int k0 = 0; k0 < kPad; k0 += 4) {
+        const T a0 = As[(wr + li) * LD + k0 + lk];
+        const T a1 = As[(wr + 16 + li) * LD + k0 + lk];
+        const T b0 = Bt[(wc + li) * LD + k0 + lk];
+        const T b1 = Bt[(wc + 16 + li) * LD + k0 + lk];
+        acc00 = Mfma<T>::run(a0, b0, acc00);
+        acc01 = Mfma<T>::run(a0, b1, acc01);
+        acc10 = Mfma<T>::run(a1, b0, acc10);
+        acc11 = Mfma<T>::run(a1, b1, acc11);
+      }
+    }
+  }
+  if (!skipUpper) {
+    const Acc* accs[4] = {&acc00, &acc01, &acc10, &acc11};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int qc = colTile + wc + (t & 1) * 16 + li;
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int qr = rowTile + wr + (t >> 1) * 16 + Mfma<T>::row(lane, reg);
+        if (qc < segEnd && qr < pd.rowsBelow && qr >= qc && qr >= sd.rowMin) {
+          tgt[(int64_t)qr * sd.tgtStride + qc] = old[t * 4 + reg] - (*accs[t])[reg];
         }
       }
     }

@@ -467,6 +467,8 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                          plan.panels[buckets[bi + 1][0].panel].lump == plan.panels[bucket[0].panel].lump;
       if (bi > 0 && !out.empty() && out.back().urgentCount > 0) lr.potrfIssuedEarly = 1;
       vector<UpdTask> deferred, big, bigDeferred;
+      int32_t nowSegs = 0, nowSeg = -1;  // segments with non-deferred 64x64 tiles in this level
+      bool nowPlain = true;              // ... all intra-lump, non-atomic, untouched order
       // how many panels of this level hit each target lump
       std::map<int64_t, int> hits;
       for (const auto& pb : bucket) {
@@ -509,6 +511,11 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
               } else {
                 plan.updTasks.push_back(t);
               }
+              if (!defer && !useBig) {
+                if (nowSeg != (int32_t)s) nowSegs++;
+                nowSeg = (int32_t)s;
+                if (sd.kind != kSegIntra || atomic) nowPlain = false;
+              }
             }
           }
           if (anyDeferred) lastDeferredLevel[sd.lump] = levelIdx;
@@ -547,6 +554,10 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       lr.bigDefEnd = (int64_t)plan.updTasks.size();
       plan.numLaunches += (lr.bigEnd > lr.bigBegin) + (lr.bigDefEnd > lr.bigDefBegin);
       if (lr.defEnd > lr.defBegin || lr.bigDefEnd > lr.bigDefBegin) plan.hasDeferred = true;
+      if (bucket.size() == 1) {
+        lr.directPanel = bucket[0].panel;
+        if (nowSegs == 1 && nowPlain) lr.directSeg = nowSeg;
+      }
       xcdOrder(lr.updBegin + lr.urgentCount, lr.updEnd);
       xcdOrder(lr.defBegin, lr.defEnd);
       plan.maxPanelsInLevel = std::max<int64_t>(plan.maxPanelsInLevel, lr.panelEnd - lr.panelBegin);
@@ -641,6 +652,47 @@ HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly)
     }
   }
   return plan;
+}
+
+SolveGatherPlan buildSolveGather(const CoalescedBlockMatrixSkel& sk, const HipPlanHost& plan) {
+  SolveGatherPlan out;
+  const int64_t nSpans = (int64_t)sk.spanStart.size() - 1;
+  vector<int64_t> count(nSpans + 1);
+  for (const ElimRangePlan& er : plan.elimRanges) {
+    const int64_t itemBegin = (int64_t)out.items.size();
+    const int64_t entryBase = (int64_t)out.entries.size();
+    // counting sort of the below-diagonal chains of the small lumps by row span
+    std::fill(count.begin(), count.end(), 0);
+    auto forEachChain = [&](auto&& fn) {
+      for (int64_t l = er.lumpBegin; l < er.lumpEnd; l++) {
+        const int64_t n = sk.lumpStart[l + 1] - sk.lumpStart[l];
+        if (n > kElimSmallMax) continue;
+        const int64_t c0 = sk.chainColPtr[l], cEnd = sk.chainColPtr[l + 1];
+        const int64_t diagCh = sk.boardChainColOrd[sk.boardColPtr[l] + 1];
+        for (int64_t c = c0 + diagCh; c < cEnd; c++) fn(l, n, c);
+      }
+    };
+    forEachChain([&](int64_t, int64_t, int64_t c) { count[sk.chainRowSpan[c] + 1]++; });
+    for (int64_t s = 0; s < nSpans; s++) count[s + 1] += count[s];
+    const int64_t total = count[nSpans];
+    BASPACHO_CHECK_LT(entryBase + total, (int64_t)1 << 31);
+    out.entries.resize(entryBase + total);
+    vector<int64_t> fill(count.begin(), count.end() - 1);
+    forEachChain([&](int64_t l, int64_t n, int64_t c) {
+      out.entries[entryBase + fill[sk.chainRowSpan[c]]++] = {sk.chainData[c],
+                                                             (int32_t)sk.lumpStart[l], (int32_t)n};
+    });
+    for (int64_t s = 0; s < nSpans; s++) {
+      for (int64_t b = count[s]; b < count[s + 1]; b += 256) {
+        out.items.push_back({(int32_t)(entryBase + b),
+                             (int32_t)(entryBase + std::min(b + 256, count[s + 1])),
+                             (int32_t)sk.spanStart[s],
+                             (int32_t)(sk.spanStart[s + 1] - sk.spanStart[s])});
+      }
+    }
+    out.rangeItems.emplace_back(itemBegin, (int64_t)out.items.size());
+  }
+  return out;
 }
 
 }  // namespace BaSpaCho

@@ -99,6 +99,9 @@ struct LevelRange {
   // after them, concurrently with the remaining tiles (the next level then skips its potrf).
   int64_t urgentCount;
   int32_t potrfIssuedEarly;  // this level's potrf was already launched by the previous level
+  // DIRECT chain kernels (hip_kernels.h): set when the level holds one panel; directSeg >= 0 when
+  // its non-deferred tiles [updBegin, updEnd) are exactly the tiles of that one intra segment
+  int32_t directPanel = -1, directSeg = -1;
   int64_t waitDefLevel;          // index (within the same level list) of the level whose deferred
                                  // tiles must be complete before this level's update launch; -1
 };
@@ -175,5 +178,24 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& skel,
 // Solver.cpp:42-64) by k rows: potrfOnly -> Cholesky of the block, rows below untouched;
 // otherwise -> the k rows are solved against the already factored block.
 HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly);
+
+// Forward solve over a sparse-elimination range in gather form: the below-diagonal blocks of
+// the small lumps listed per TARGET row span, so that a workgroup sums the products of up to
+// 256 blocks of one span and issues one atomic per row (hip_solve_kernels.h, K-S2).
+struct SolveGatherEntry {
+  int64_t dataOff;  // data offset of the block (rows x n, row-major)
+  int32_t xOff;     // position of the source lump in the vector
+  int32_t n;        // width of the source lump
+};
+struct SolveGatherItem {
+  int32_t entryBegin, entryEnd;  // <= 256 entries
+  int32_t rowStart, rows;        // target span in the vector
+};
+struct SolveGatherPlan {
+  std::vector<SolveGatherEntry> entries;
+  std::vector<SolveGatherItem> items;
+  std::vector<std::pair<int64_t, int64_t>> rangeItems;  // item range of every elimination range
+};
+SolveGatherPlan buildSolveGather(const CoalescedBlockMatrixSkel& skel, const HipPlanHost& plan);
 
 }  // namespace BaSpaCho

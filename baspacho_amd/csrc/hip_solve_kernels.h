@@ -79,42 +79,121 @@ __global__ __launch_bounds__(256) void solveElimSmall(SkelDev sk, const T* data,
   }
 }
 
+// ---- sparse-elimination ranges, forward pass in gather form --------------------------------
+// K-S1: x_l <- D^-1 x_l for the small lumps of a range (thread per lump)
+template <typename T>
+__global__ __launch_bounds__(256) void solveElimDiagL(SkelDev sk, const T* data, T* vecAll,
+                                                      int64_t ldc, int64_t lumpBegin,
+                                                      int64_t lumpEnd) {
+  const int64_t l = lumpBegin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (l >= lumpEnd) return;
+  const int n = (int)(sk.lumpStart[l + 1] - sk.lumpStart[l]);
+  if (n > kElimSmallMax) return;
+  const T* D = data + sk.chainData[sk.chainColPtr[l]];
+  T* xl = vecAll + (int64_t)blockIdx.y * ldc + sk.lumpStart[l];
+  T x[kElimSmallMax];
+  for (int i = 0; i < n; i++) x[i] = xl[i];
+  for (int i = 0; i < n; i++) {
+    T s = x[i];
+    for (int j = 0; j < i; j++) s -= D[i * n + j] * x[j];
+    x[i] = s / D[i * n + i];
+  }
+  for (int i = 0; i < n; i++) xl[i] = x[i];
+}
+
+// K-S2: y[span] -= sum over the blocks B that sit in that row span, B * x_lump.  The blocks are
+// listed per target span (SolveGatherEntry, sorted by span), an item is <= 256 entries of one
+// span: thread per block, workgroup reduction, ONE atomic per row and item (instead of one per
+// row and block, all on the few camera rows).
+template <typename T>
+__global__ __launch_bounds__(256) void solveElimGatherL(const SolveGatherItem* items,
+                                                        const SolveGatherEntry* entries,
+                                                        const T* data, T* vecAll, int64_t ldc) {
+  __shared__ T part[4];
+  const SolveGatherItem it = items[blockIdx.x];
+  T* vec = vecAll + (int64_t)blockIdx.y * ldc;
+  const int e = it.entryBegin + (int)threadIdx.x;
+  const bool live = e < it.entryEnd;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int n = 0;
+  const T* B = data;
+  T x[kElimSmallMax];
+  if (live) {
+    const SolveGatherEntry en = entries[e];
+    n = en.n;
+    B = data + en.dataOff;
+    const T* xl = vec + en.xOff;
+    for (int k = 0; k < n; k++) x[k] = xl[k];
+  }
+  for (int r = 0; r < it.rows; r++) {
+    T s = T(0);
+    for (int k = 0; k < n; k++) s += B[r * n + k] * x[k];
+    s = waveSum(s);
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicSub(vec + it.rowStart + r, part[0] + part[1] + part[2] + part[3]);
+    __syncthreads();
+  }
+}
+
 // ---- dense panels ----------------------------------------------------------------------------
-// triangular solve with the nb x nb diagonal block of a panel, one workgroup per panel
+// triangular solve with the nb x nb diagonal block of a panel, one workgroup per panel: 256
+// threads stage L (batched, coalesced loads), then wave 0 solves with x_i in lane i and the
+// pivot value broadcast by readlane; the block is padded to 64 x 64 with the identity so the
+// 64-step loop unrolls completely and the LDS reads do not sit on the dependency chain.
+__device__ __forceinline__ double laneBcast(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float laneBcast(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+
 template <typename T, bool BACKWARD>
-__global__ __launch_bounds__(64) void solveTriPanel(const PanelDesc* panels,
-                                                    const int32_t* levelPanels, const T* data,
-                                                    T* vecAll, int64_t ldc) {
-  constexpr int LD = kPanelWidth + 1;
-  __shared__ T Ls[kPanelWidth * LD];
-  __shared__ T xs[kPanelWidth];
+__global__ __launch_bounds__(256) void solveTriPanel(const PanelDesc* panels,
+                                                     const int32_t* levelPanels, const T* data,
+                                                     T* vecAll, int64_t ldc) {
+  constexpr int NB = kPanelWidth, LD = NB + 1;
+  __shared__ T Ls[NB * LD];
   const PanelDesc pd = panels[levelPanels[blockIdx.x]];
   const T* A = data + pd.diagOff;
   T* x = vecAll + (int64_t)blockIdx.y * ldc + pd.vecOff;
-  const int nb = pd.nb, lda = pd.lda, lane = threadIdx.x;
-  for (int i = 0; i < nb; i++) {
-    if (lane <= i) Ls[i * LD + lane] = A[(int64_t)i * lda + lane];
+  const int nb = pd.nb, lda = pd.lda, tid = threadIdx.x;
+  {
+    T v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int e = tid + 256 * i, r = e >> 6, c = e & 63;
+      v[i] = (r < nb && c <= r) ? A[(int64_t)r * lda + c] : (r == c ? T(1) : T(0));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int e = tid + 256 * i, r = e >> 6, c = e & 63;
+      Ls[r * LD + c] = v[i];
+    }
   }
-  if (lane < nb) xs[lane] = x[lane];
   __syncthreads();
+  if (tid >= 64) return;
+  const int lane = tid;
+  T xi = lane < nb ? x[lane] : T(0);
+  const T inv = T(1) / Ls[lane * LD + lane];
   if (!BACKWARD) {
-    for (int j = 0; j < nb; j++) {
-      const T xj = xs[j] / Ls[j * LD + j];
-      __syncthreads();
-      if (lane == j) xs[j] = xj;
-      if (lane > j && lane < nb) xs[lane] -= Ls[lane * LD + j] * xj;
-      __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      const T lij = Ls[lane * LD + j];  // column j of L, lane = row
+      const T xj = laneBcast(xi * inv, j);
+      xi = lane == j ? xj : (lane > j ? xi - lij * xj : xi);
     }
   } else {
-    for (int j = nb - 1; j >= 0; j--) {
-      const T xj = xs[j] / Ls[j * LD + j];
-      __syncthreads();
-      if (lane == j) xs[j] = xj;
-      if (lane < j) xs[lane] -= Ls[j * LD + lane] * xj;
-      __syncthreads();
+#pragma unroll
+    for (int j = NB - 1; j >= 0; j--) {
+      const T lji = Ls[j * LD + lane];  // row j of L, lane = column
+      const T xj = laneBcast(xi * inv, j);
+      xi = lane == j ? xj : (lane < j ? xi - lji * xj : xi);
     }
   }
-  if (lane < nb) x[lane] = xs[lane];
+  if (lane < nb) x[lane] = xi;
 }
 
 __device__ __forceinline__ int solveTargetRow(const PanelDesc& pd, const int32_t* rowGlobal, int q) {
@@ -122,7 +201,9 @@ __device__ __forceinline__ int solveTargetRow(const PanelDesc& pd, const int32_t
   return q < pd.nRest ? pd.vecOff + pd.nb + q : rowGlobal[pd.lumpRowBase + (q - pd.nRest)];
 }
 
-// forward: x[target(q)] -= P[q][:] . x_p for a 64-row tile (wave per row, lanes over k)
+// forward: x[target(q)] -= P[q][:] . x_p for a 64-row tile.  16 lanes share a row (4 columns
+// each), a wave covers 4 rows per step and 16 rows in all; every load is issued before the
+// reductions start.
 template <typename T>
 __global__ __launch_bounds__(256) void solveGemvL(const PanelDesc* panels, const TrsmTask* tasks,
                                                   const int32_t* rowGlobal, const T* data,
@@ -131,18 +212,34 @@ __global__ __launch_bounds__(256) void solveGemvL(const PanelDesc* panels, const
   const PanelDesc pd = panels[task.panel];
   T* vec = vecAll + (int64_t)blockIdx.y * ldc;
   const int nb = pd.nb, lda = pd.lda, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = (lane & 15) * 4, sub = lane >> 4;
   const T* P = data + pd.diagOff + (int64_t)nb * lda;
-  const T xk = lane < nb ? vec[pd.vecOff + lane] : T(0);
+  T xk[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) xk[i] = k0 + i < nb ? vec[pd.vecOff + k0 + i] : T(0);
   const int rows = min(kTile, pd.rowsBelow - task.rowTile);
-  for (int r = wave; r < rows; r += 4) {
-    const int q = task.rowTile + r;
-    const T p = lane < nb ? P[(int64_t)q * lda + lane] : T(0);
-    const T s = waveSum(p * xk);
-    if (lane == 0) atomicSub(vec + solveTargetRow(pd, rowGlobal, q), s);
+  T p[4][4];
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int r = wave * 16 + it * 4 + sub;
+    const T* row = P + (int64_t)(task.rowTile + r) * lda + k0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) p[it][i] = (r < rows && k0 + i < nb) ? row[i] : T(0);
+  }
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int r = wave * 16 + it * 4 + sub;
+    T s = p[it][0] * xk[0] + p[it][1] * xk[1] + p[it][2] * xk[2] + p[it][3] * xk[3];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((lane & 15) == 0 && r < rows) {
+      atomicSub(vec + solveTargetRow(pd, rowGlobal, task.rowTile + r), s);
+    }
   }
 }
 
-// backward: x_p[k] -= sum_q P[q][k] * x[target(q)] over a 64-row tile
+// backward: x_p[k] -= sum_q P[q][k] * x[target(q)] over a 64-row tile (lane = column k, a wave
+// takes 16 rows, loads issued up front)
 template <typename T>
 __global__ __launch_bounds__(256) void solveGemvLt(const PanelDesc* panels, const TrsmTask* tasks,
                                                    const int32_t* rowGlobal, const T* data,
@@ -154,12 +251,17 @@ __global__ __launch_bounds__(256) void solveGemvLt(const PanelDesc* panels, cons
   const int nb = pd.nb, lda = pd.lda, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* P = data + pd.diagOff + (int64_t)nb * lda;
   const int rows = min(kTile, pd.rowsBelow - task.rowTile);
-  T acc = T(0);
-  for (int r = wave; r < rows; r += 4) {
-    const int q = task.rowTile + r;
-    const T xq = vec[solveTargetRow(pd, rowGlobal, q)];
-    if (lane < nb) acc += P[(int64_t)q * lda + lane] * xq;
+  T p[16], xq[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int r = wave * 16 + i, q = task.rowTile + r;
+    const bool ok = r < rows;
+    xq[i] = ok ? vec[solveTargetRow(pd, rowGlobal, q)] : T(0);
+    p[i] = (ok && lane < nb) ? P[(int64_t)q * lda + lane] : T(0);
   }
+  T acc = T(0);
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc += p[i] * xq[i];
   part[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && lane < nb) {
