@@ -473,9 +473,17 @@ struct HipNumericCtx : NumericCtx<T> {
       const int64_t nItems = er.itemEnd - er.itemBegin;
       if (nItems > 0) {
         timer.begin(kProfElimUpdate);
-        hipk::elimGather<BT><<<dim3((unsigned)((nItems + 3) / 4), gy), 256, 0, sym.stream>>>(
+        hipk::elimGatherMfma<BT><<<dim3((unsigned)((nItems + 3) / 4), gy), 256, 0, sym.stream>>>(
             plan.elimItems.as<ElimGatherItem>() + er.itemBegin, plan.elimPairOffJ.as<uint32_t>(),
             plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems);
+        timer.end();
+      }
+      const int64_t nWide = er.ldsEnd - er.ldsBegin;
+      if (nWide > 0) {
+        timer.begin(kProfElimUpdate);
+        hipk::elimGather<BT><<<dim3((unsigned)((nWide + 3) / 4), gy), 256, 0, sym.stream>>>(
+            plan.elimItems.as<ElimGatherItem>() + er.ldsBegin, plan.elimPairOffJ.as<uint32_t>(),
+            plan.elimPairOffI.as<uint32_t>(), ref, (int)nWide);
         timer.end();
       }
       const int64_t nTiny = er.tinyEnd - er.tinyBegin;

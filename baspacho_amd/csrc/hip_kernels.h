@@ -196,6 +196,29 @@ __global__ __launch_bounds__(256) void elimUpdate(SkelDev sk, const int32_t* cha
   }
 }
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<double> {
+  using Acc = double4_t;
+  static __device__ __forceinline__ Acc run(double a, double b, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <>
+struct Mfma<float> {
+  using Acc = float4_t;
+  static __device__ __forceinline__ Acc run(float a, float b, Acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+
 // ------------------------------------------------------------------------------------------
 // K2g  sparse-elimination update, GATHER form (atomic-free, deterministic).  One wave owns one
 // target block (sj,si) and the list of source chain pairs that contribute to it (sorted by target
@@ -329,6 +352,79 @@ __global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, c
   }
 }
 
+// K2m  the gather on the matrix cores, for target blocks of at most 16 x 16 (the 9x9 camera blocks
+// of bundle adjustment).  A pair's product B_j * B_i^T is ONE v_mfma 16x16x4 per 4 source columns:
+// lane (i, k) = (lane & 15, lane >> 4) supplies B_j[i][k] and B_i[i][k], i.e. every lane issues one
+// 8-byte load per operand, the 64 lanes together read the two contiguous source blocks, and nothing
+// goes through LDS (K2g spends 13 LDS wave-instructions per pair and is LDS-bandwidth bound at
+// ~12 G pairs/s).  The sum over the pairs stays in the 4 accumulator registers; loads of 8 pairs
+// are issued before their MFMAs.
+template <typename T>
+__global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* items,
+                                                      const uint32_t* offJ, const uint32_t* offI,
+                                                      DataRef<T> dref, int numItems) {
+  constexpr int U = 8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const int idx = blockIdx.x * 4 + wave;
+  if (idx >= numItems) return;
+  const ElimGatherItem it = items[idx];
+  T* data = pickData(dref);
+  const int rows = it.rows, cols = it.cols, n = it.n;
+  using Acc = typename Mfma<T>::Acc;
+  Acc acc = {0, 0, 0, 0};
+  for (int k0 = 0; k0 < n; k0 += 4) {  // one pass per 4 source columns (n <= 4: a single pass)
+    const int k = k0 + lk;
+    const bool okA = li < rows && k < n, okB = li < cols && k < n;
+    const uint32_t eA = okA ? (uint32_t)(li * n + k) : 0u, eB = okB ? (uint32_t)(li * n + k) : 0u;
+    for (int base = it.pairBegin; base < it.pairEnd; base += 64) {
+      const int cnt = min(64, it.pairEnd - base);
+      const uint32_t myJ = lane < cnt ? offJ[base + lane] : 0u;
+      const uint32_t myI = lane < cnt ? offI[base + lane] : 0u;
+      for (int t0 = 0; t0 < cnt; t0 += U) {
+        T a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int t = min(t0 + u, cnt - 1);
+          const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)myJ, t);
+          const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)myI, t);
+          a[u] = data[oj + eA];
+          b[u] = data[oi + eB];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (t0 + u < cnt) {  // wave-uniform
+            acc = Mfma<T>::run(okA ? a[u] : T(0), okB ? b[u] : T(0), acc);
+          }
+        }
+      }
+    }
+  }
+  T* target = data + it.tgtOff;
+  T* ptr[4];
+  bool ok[4];
+  T old[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int r = Mfma<T>::row(lane, g);
+    ok[g] = r < rows && li < cols && !((it.flags & 2) && li > r);
+    ptr[g] = target + (ok[g] ? (int64_t)r * it.tgtStride + li : 0);
+  }
+  if (it.flags & 1) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (ok[g]) atomicSub(ptr[g], acc[g]);
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; g++) old[g] = *ptr[g];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (ok[g]) *ptr[g] = old[g] - acc[g];
+    }
+  }
+}
+
 // K2t  the same gather for TINY target blocks (<= 16 elements, e.g. the 3x3 blocks of automatically
 // detected elimination ranges): four items per wave, 16 lanes each, operands straight from
 // global memory (a pair's blocks are a few dozen bytes).
@@ -368,29 +464,6 @@ __global__ __launch_bounds__(256) void elimGatherTiny(const ElimGatherItem* item
 // workgroup per panel, whole block in LDS.  Replaces cusolverDn?potrf / potrfBatched
 // (MatOpsCuda.cu:508-548, 727-755) on the panel granularity.
 // ------------------------------------------------------------------------------------------
-typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef float float4_t __attribute__((ext_vector_type(4)));
-
-template <typename T>
-struct Mfma;
-template <>
-struct Mfma<double> {
-  using Acc = double4_t;
-  static __device__ __forceinline__ Acc run(double a, double b, Acc c) {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
-};
-template <>
-struct Mfma<float> {
-  using Acc = float4_t;
-  static __device__ __forceinline__ Acc run(float a, float b, Acc c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
-};
-
-
 #if defined(BSP_KTRACE)
 // in-situ trace build (build.sh with BSP_KTRACE=1): every launch of a stamped kernel appends one
 // record of 4 clock values; read back with hipBackendReadTrace()

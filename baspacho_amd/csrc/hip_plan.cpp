@@ -155,20 +155,30 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   // items whose target block has at most 16 elements (e.g. 3x3 blocks of automatically detected
   // ranges) go to the kernel that packs four items per wave: move them behind the others
   {
-    vector<ElimGatherItem> large, tiny;
-    vector<int64_t> tagL, tagT;
+    vector<ElimGatherItem> large, tiny, wide;
+    vector<int64_t> tagL;
     for (int64_t k = er.itemBegin; k < er.itemEnd; k++) {
       const ElimGatherItem& it = plan.elimItems[k];
-      const bool isTiny = int(it.rows) * int(it.cols) <= 16;
-      (isTiny ? tiny : large).push_back(it);
-      (isTiny ? tagT : tagL).push_back(itemRowTag[k - er.itemBegin]);
+      if (int(it.rows) * int(it.cols) <= 16) {
+        tiny.push_back(it);
+      } else if (it.rows > 16 || it.cols > 16) {
+        wide.push_back(it);  // does not fit one 16x16 MFMA tile
+      } else {
+        large.push_back(it);
+        tagL.push_back(itemRowTag[k - er.itemBegin]);
+      }
     }
-    std::copy(large.begin(), large.end(), plan.elimItems.begin() + er.itemBegin);
-    std::copy(tiny.begin(), tiny.end(), plan.elimItems.begin() + er.itemBegin + (int64_t)large.size());
+    auto dst = plan.elimItems.begin() + er.itemBegin;
+    dst = std::copy(large.begin(), large.end(), dst);
+    dst = std::copy(tiny.begin(), tiny.end(), dst);
+    std::copy(wide.begin(), wide.end(), dst);
     itemRowTag = tagL;
+    itemChunk.assign(large.size(), 0);
     er.itemEnd = er.itemBegin + (int64_t)large.size();
     er.tinyBegin = er.itemEnd;
     er.tinyEnd = er.tinyBegin + (int64_t)tiny.size();
+    er.ldsBegin = er.tinyEnd;
+    er.ldsEnd = er.ldsBegin + (int64_t)wide.size();
   }
   // XCD-aware order (speed only).  A workgroup takes 4 consecutive items and workgroup b runs on
   // XCD b % 8, each XCD with its own 4 MB L2.  All items of one target ROW (same sj) read the same

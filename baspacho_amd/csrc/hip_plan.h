@@ -134,6 +134,8 @@ struct ElimRangePlan {
   bool useGather = false;             // pair updates in gather form (atomic-free) ...
   int64_t itemBegin = 0, itemEnd = 0; // ... over these ElimGatherItems (one wave per item)
   int64_t tinyBegin = 0, tinyEnd = 0; // items with <= 16 target elements: 4 items per wave
+  int64_t ldsBegin = 0, ldsEnd = 0;   // items wider or taller than 16: LDS-staged kernel (K2g);
+                                      // [itemBegin, itemEnd) go to the MFMA kernel (K2m)
 };
 
 struct HipPlanHost {
