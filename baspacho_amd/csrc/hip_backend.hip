@@ -137,7 +137,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_NO_LOOKAHEAD")) lookaheadEnabled = e[0] == '0';
     if (const char* e = std::getenv("BSP_NO_CRIT_STREAM")) critEnabled = e[0] == '0';
     if (const char* e = std::getenv("BSP_BULK_EXTRA_LDS")) bulkExtraLds = (unsigned)atoi(e);
-    if (const char* e = std::getenv("BSP_NO_EARLY_POTRF")) earlyPotrf = e[0] == '0';
+    if (const char* e = std::getenv("BSP_FUSE_POTRF")) fusePotrf = e[0] != '0';
     if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
   }
 
@@ -145,7 +145,6 @@ struct HipSymbolicCtx : SymbolicCtx {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
     if (crit) (void)hipStreamDestroy(crit);
-    if (third) (void)hipStreamDestroy(third);
   }
 
   virtual void setSparseElimRanges(const vector<int64_t>& ranges) override {
@@ -257,10 +256,6 @@ struct HipSymbolicCtx : SymbolicCtx {
     }
     return side;
   }
-  hipStream_t thirdStream() {
-    if (!third) hipCHECK(hipStreamCreateWithFlags(&third, hipStreamNonBlocking));
-    return third;
-  }
   // high-priority stream for the latency-critical chain while a bulk update runs beside it
   hipStream_t critStream() {
     if (!crit && reserveEvery() >= 2 && std::getenv("BSP_PIN_CHAIN")) {
@@ -293,8 +288,8 @@ struct HipSymbolicCtx : SymbolicCtx {
   unsigned bulkExtraLds = 6 * 1024;
   bool critEnabled = false;  // measured: no gain from stream priorities on MI355X
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
-  hipStream_t side = nullptr, crit = nullptr, third = nullptr;
-  bool earlyPotrf = false;  // measured SLOWER (15.2 vs 13.1 ms): cross-stream events per panel cost more than the overlap saves
+  hipStream_t side = nullptr, crit = nullptr;
+  bool fusePotrf = true;    // next panel's potrf inside the update launch (BSP_FUSE_POTRF=0 disables)
   bool directChain = true;  // descriptor-by-value kernels on one-panel levels (BSP_DIRECT_CHAIN=0 disables)
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
@@ -343,18 +338,15 @@ struct HipNumericCtx : NumericCtx<T> {
     const dim3 gy(1, (unsigned)batchSize, 1);
     const bool lookahead = sym.profile == nullptr && sym.lookaheadEnabled;
     vector<hipEvent_t> defDone(levels.size(), nullptr);
-    hipEvent_t potrfDone = nullptr;
+    bool potrfFused = false;  // this level's potrf ran inside the previous level's update launch
     bool sideUsed = false;
     for (size_t li = 0; li < levels.size(); li++) {
       const LevelRange& lr = levels[li];
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
-      const bool early = lookahead && sym.earlyPotrf;
       const bool direct = sym.directChain && lr.directPanel >= 0;
-      if (nP && early && lr.potrfIssuedEarly && potrfDone) {
-        // this level's potrf already ran on the third stream: just order after it
-        hipCHECK(hipStreamWaitEvent(sym.stream, potrfDone, 0));
-        potrfDone = nullptr;
+      if (potrfFused) {
+        potrfFused = false;
       } else if (nP) {
         timer.begin(kProfPotrf);
         if (direct) {
@@ -385,25 +377,19 @@ struct HipNumericCtx : NumericCtx<T> {
         launchUpdateBig(plan, lr.bigBegin, lr.bigEnd, ref, sym.stream);
         timer.end();
       }
-      int64_t updBegin = lr.updBegin;
-      if (early && lr.urgentCount > 0 && li + 1 < levels.size()) {
-        // the tile that completes the next panel's diagonal block goes first; the next level's
-        // potrf then runs on the third stream beside the rest of this level's update
-        launchUpdate(plan, updBegin, updBegin + lr.urgentCount, ref, sym.stream);
-        updBegin += lr.urgentCount;
-        hipEvent_t urgentDone = sym.eventFromPool();
-        hipCHECK(hipEventRecord(urgentDone, sym.stream));
-        hipCHECK(hipStreamWaitEvent(sym.thirdStream(), urgentDone, 0));
-        const LevelRange& nx = levels[li + 1];
-        hipk::potrfPanel<BT><<<dim3((unsigned)(nx.panelEnd - nx.panelBegin), gy.y), 256, 0,
-                               sym.thirdStream()>>>(
-            plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + nx.panelBegin, ref);
-        potrfDone = sym.eventFromPool();
-        hipCHECK(hipEventRecord(potrfDone, sym.thirdStream()));
-      }
+      const int64_t updBegin = lr.updBegin;
       if (lr.updEnd > updBegin) {
         timer.begin(kProfUpdate);
-        if (direct && lr.directSeg >= 0 && updBegin == lr.updBegin) {
+        const bool fuse = direct && lr.directSeg >= 0 && lr.fuseNext && sym.fusePotrf &&
+                          li + 1 < levels.size() && levels[li + 1].directPanel >= 0;
+        if (fuse) {
+          const SegDesc& sd = plan.host.segs[lr.directSeg];
+          hipk::updateTileDirectPotrf<BT><<<dim3((unsigned)(lr.updEnd - updBegin), gy.y), 256, 0,
+                                          sym.stream>>>(
+              plan.host.srcs[sd.src], sd, (int)(lr.updEnd - updBegin),
+              plan.host.panels[levels[li + 1].directPanel], ref);
+          potrfFused = true;
+        } else if (direct && lr.directSeg >= 0) {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
           hipk::updateTileDirect<BT><<<dim3((unsigned)(lr.updEnd - updBegin), gy.y), 256, 0,
                                      sym.stream>>>(plan.host.srcs[sd.src], sd,
@@ -423,11 +409,17 @@ struct HipNumericCtx : NumericCtx<T> {
         if (lr.bigDefEnd > lr.bigDefBegin) {
           launchUpdateBig(plan, lr.bigDefBegin, lr.bigDefEnd, ref, sym.sideStream());
         }
-        if (lr.defEnd > lr.defBegin) {
-          launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+        // first the tiles the next block's own update must wait for, then (event) the rest:
+        // the side stream keeps running them while the chain goes on, and the next block's
+        // deferred tiles queue up right behind
+        if (lr.defMid > lr.defBegin) {
+          launchUpdate(plan, lr.defBegin, lr.defMid, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
         }
         defDone[li] = sym.eventFromPool();
         hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
+        if (lr.defEnd > lr.defMid) {
+          launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+        }
         sideUsed = true;
       }
       if (!lookahead && lr.bigDefEnd > lr.bigDefBegin) {

@@ -487,9 +487,16 @@ __device__ long long bspDebugStamps[16];
 // 184 us + 77 us per outer block against ~165 us for the four 64-wide panel steps they would
 // replace -- the serial dependent-latency per 4-column step dominates either way -- so the
 // 64-wide panel chain stays.
-template <typename T, int NT>
+struct NoPreUpdate {
+  template <typename A>
+  __device__ __forceinline__ void operator()(A*) const {}
+};
+
+// `pre(acc)` runs between the load of the block and the factorization: the fused kernel
+// (updateTileDirectPotrf) applies the pending rank-K update of the block there.
+template <typename T, int NT, typename Pre = NoPreUpdate>
 __device__ __forceinline__ void potrfTiles(T* A, int nb, int lda, T (*raw)[4], T (*sol)[4],
-                                           T (*fin)[4]) {
+                                           T (*fin)[4], Pre pre = Pre()) {
   // The block lives in MFMA accumulator layout: wave w owns tile row w (16x16 tiles (w,0..w));
   // lane l / register r of tile (ti,tj) hold row 16ti + Mfma::row(l,r), column 16tj + (l&15).
   // One step per 4-column pivot block (two barriers each):
@@ -522,6 +529,7 @@ __device__ __forceinline__ void potrfTiles(T* A, int nb, int lda, T (*raw)[4], T
       acc[tj] = Acc{0, 0, 0, 0};
     }
   }
+  pre(acc);
   BSP_STAMP(1);
   const int nSteps = (nb + 3) >> 2;
 #pragma unroll 1
@@ -1006,18 +1014,19 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
 // the plan's task list: column tiles of the first `mNow` columns, each with its row tiles, then
 // the XCD-contiguous permutation), the old target values are fetched together with the first K
 // chunk and the next chunk is fetched while the current one is multiplied.
+// XCD-contiguous permutation of a launch's tile indices (workgroup b lands on XCD b % 8): XCD x
+// gets a contiguous run of the tile list
+__device__ __forceinline__ int xcdContiguous(int b, int n) {
+  if (n < 64) return b;
+  const int base = n >> 3, extra = n & 7, x = b & 7;
+  return x * base + min(x, extra) + (b >> 3);
+}
+
+// tile `idx` of the segment in the order: column tiles from sd.q0 on, each with its row tiles
 template <typename T>
-__global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, int nTasks,
-                                                        DataRef<T> dref) {
+__device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const SegDesc& sd, int idx,
+                                                     T* data, T* As, T* Bs) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
-  __shared__ T As[kTile * LD];
-  __shared__ T Bs[kTile * LD];
-  __builtin_amdgcn_s_setprio(2);
-  int idx = blockIdx.x;
-  if (nTasks >= 64) {  // mirror of xcdOrder() in hip_plan.cpp
-    const int base = nTasks >> 3, extra = nTasks & 7, x = idx & 7;
-    idx = x * base + min(x, extra) + (idx >> 3);
-  }
   int colTile = sd.q0, rowTile;
   for (;;) {
     const int cnt = (pd.rowsBelow - colTile + kTile - 1) / kTile;
@@ -1028,7 +1037,6 @@ __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, 
     idx -= cnt;
     colTile += kTile;
   }
-  T* data = pickData(dref);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = pd.K, lda = pd.lda;
   const T* P = data + pd.off;
@@ -1117,6 +1125,82 @@ __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, 
       }
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, int nTasks,
+                                                        DataRef<T> dref) {
+  constexpr int LD = kUpdChunk + 2;
+  __shared__ T As[kTile * LD];
+  __shared__ T Bs[kTile * LD];
+  __builtin_amdgcn_s_setprio(2);
+  updateTileDirectBody<T>(pd, sd, xcdContiguous(blockIdx.x, nTasks), pickData(dref), As, Bs);
+}
+
+// K5f  the same launch with the NEXT panel's potrf fused in.  Tile 0 of the segment is the next
+// panel's diagonal block: workgroup 0 applies that tile's update inside the potrf (the block is
+// already in MFMA accumulator layout there) and factors it, while the other workgroups update
+// the remaining tiles -- the potrf (the longest kernel of the chain) overlaps the update instead
+// of following it, with no second stream and no event.
+template <typename T>
+__global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc sd, int nTasks,
+                                                             PanelDesc next, DataRef<T> dref) {
+  constexpr int KC = kUpdChunk, LD = KC + 2;
+  __shared__ T As[kTile * LD];
+  __shared__ T Bs[kTile * LD];
+  T* data = pickData(dref);
+  if (blockIdx.x != 0) {
+    __builtin_amdgcn_s_setprio(2);
+    updateTileDirectBody<T>(pd, sd, 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1), data, As, Bs);
+    return;
+  }
+  __builtin_amdgcn_s_setprio(3);
+  T(*raw)[4] = reinterpret_cast<T(*)[4]>(Bs);
+  T(*sol)[4] = raw + kPanelWidth;
+  T(*fin)[4] = sol + kPanelWidth;
+  const int K = pd.K, lda = pd.lda, nb = next.nb;
+  const T* X = data + pd.off + (int64_t)sd.q0 * lda;  // rows of the next panel, source columns
+  using Acc = typename Mfma<T>::Acc;
+  auto pre = [&](Acc* acc) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+    constexpr int RSTEP = 256 / KC, NIT = kTile / RSTEP;
+    const int sk = tid % KC, sr = tid / KC;
+    T v[NIT];
+    // the product is summed on its own and subtracted once, as the unfused tile update does
+    Acc upd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    auto fetch = [&](int kBase) {
+      const int kcl = min(kBase + sk, K - 1);
+#pragma unroll
+      for (int it = 0; it < NIT; it++) v[it] = X[(int64_t)min(sr + RSTEP * it, nb - 1) * lda + kcl];
+    };
+    fetch(0);
+    for (int kBase = 0; kBase < K; kBase += KC) {
+      const int kc = min(KC, K - kBase);
+      const int kPad = (kc + 3) & ~3;
+      if (kBase > 0) __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int r = sr + RSTEP * it;
+        As[r * LD + sk] = (sk < kc && r < nb) ? v[it] : T(0);
+      }
+      __syncthreads();
+      if (kBase + KC < K) fetch(kBase + KC);
+      for (int k0 = 0; k0 < kPad; k0 += 4) {
+        const T a = As[(16 * w + li) * LD + k0 + lk];
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++) {
+          if (tj <= w) upd[tj] = Mfma<T>::run(a, As[(16 * tj + li) * LD + k0 + lk], upd[tj]);
+        }
+      }
+    }
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++) {
+      if (tj <= w) acc[tj] -= upd[tj];
+    }
+  };
+  BSP_STAMP(0);
+  potrfTiles<T, 4>(data + next.diagOff, nb, next.lda, raw, sol, fin, pre);
+  BSP_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------

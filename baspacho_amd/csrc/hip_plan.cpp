@@ -467,16 +467,13 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       lr.trsmBegin = (int64_t)plan.trsmTasks.size();
       lr.updBegin = (int64_t)plan.updTasks.size();
       lr.waitDefLevel = -1;
-      lr.urgentCount = 0;
-      lr.potrfIssuedEarly = 0;
       const int64_t levelIdx = (int64_t)out.size();
       // single-panel level followed by a single-panel level of the same lump?
       const size_t bi = (size_t)(&bucket - &buckets[0]);
       const bool chain = bucket.size() == 1 && bi + 1 < buckets.size() &&
                          buckets[bi + 1].size() == 1 &&
                          plan.panels[buckets[bi + 1][0].panel].lump == plan.panels[bucket[0].panel].lump;
-      if (bi > 0 && !out.empty() && out.back().urgentCount > 0) lr.potrfIssuedEarly = 1;
-      vector<UpdTask> deferred, big, bigDeferred;
+      vector<UpdTask> deferred, deferredLate, big, bigDeferred;
       int32_t nowSegs = 0, nowSeg = -1;  // segments with non-deferred 64x64 tiles in this level
       bool nowPlain = true;              // ... all intra-lump, non-atomic, untouched order
       // how many panels of this level hit each target lump
@@ -509,15 +506,11 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             for (int32_t rT = cT; rT < sr.rowsBelow; rT += step) {
               const UpdTask t{(int32_t)s, rT, cT, atomic};
               if (defer) {
-                (useBig ? bigDeferred : deferred).push_back(t);
+                const bool late = cT - sd.q0 >= 2 * kOuterWidth;
+                (useBig ? bigDeferred : (late ? deferredLate : deferred)).push_back(t);
                 anyDeferred = true;
               } else if (useBig) {
                 big.push_back(t);
-              } else if (chain && sd.kind == kSegIntra && sd.q0 == 0 && cT == 0 && rT == 0 &&
-                         s == panelSegBegin[pb.panel]) {
-                // tile (0,0) of the panel's first intra-lump segment = next panel's diagonal block
-                plan.updTasks.insert(plan.updTasks.begin() + lr.updBegin, t);
-                lr.urgentCount = 1;
               } else {
                 plan.updTasks.push_back(t);
               }
@@ -539,6 +532,8 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       lr.updEnd = (int64_t)plan.updTasks.size();
       lr.defBegin = lr.updEnd;
       plan.updTasks.insert(plan.updTasks.end(), deferred.begin(), deferred.end());
+      lr.defMid = (int64_t)plan.updTasks.size();
+      plan.updTasks.insert(plan.updTasks.end(), deferredLate.begin(), deferredLate.end());
       lr.defEnd = (int64_t)plan.updTasks.size();
       // XCD-aware order: workgroup b lands on XCD b % 8 (observed dispatch; each XCD has its own
       // L2), so hand every XCD a CONTIGUOUS run of the tile list (neighbouring tiles share
@@ -567,9 +562,19 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       if (bucket.size() == 1) {
         lr.directPanel = bucket[0].panel;
         if (nowSegs == 1 && nowPlain) lr.directSeg = nowSeg;
+        if (chain && lr.directSeg >= 0) {
+          const SegDesc& sd = plan.segs[lr.directSeg];
+          const PanelDesc& next = plan.panels[buckets[bi + 1][0].panel];
+          // (a narrower next panel does not fill tile 0: its rows below the panel would be missed)
+          if (sd.q0 == 0 && sd.rowMin == 0 && sd.tgtBase == next.diagOff && next.nb == kTile &&
+              sd.tgtStride == next.lda && lr.updEnd - lr.updBegin >= 2) {
+            lr.fuseNext = 1;
+          }
+        }
       }
-      xcdOrder(lr.updBegin + lr.urgentCount, lr.updEnd);
-      xcdOrder(lr.defBegin, lr.defEnd);
+      xcdOrder(lr.updBegin, lr.updEnd);
+      xcdOrder(lr.defBegin, lr.defMid);
+      xcdOrder(lr.defMid, lr.defEnd);
       plan.maxPanelsInLevel = std::max<int64_t>(plan.maxPanelsInLevel, lr.panelEnd - lr.panelBegin);
       plan.numLaunches += 1 + (lr.trsmEnd > lr.trsmBegin) + (lr.updEnd > lr.updBegin) +
                           (lr.defEnd > lr.defBegin);
@@ -654,10 +659,8 @@ HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly)
         addSeg(sr, n - blockEnd, offA + blockEnd * n + blockEnd);
       }
       lr.updEnd = (int64_t)plan.updTasks.size();
-      lr.defBegin = lr.defEnd = lr.updEnd;
+      lr.defBegin = lr.defMid = lr.defEnd = lr.updEnd;
       lr.bigBegin = lr.bigEnd = lr.bigDefBegin = lr.bigDefEnd = lr.updEnd;
-      lr.urgentCount = 0;
-      lr.potrfIssuedEarly = 0;
       plan.levels.push_back(lr);
     }
   }

@@ -91,17 +91,18 @@ struct LevelRange {
   // and may run on a second stream concurrently with the following levels.  They must be complete
   // before the update launch of level `waitDefLevel`-consumers (see below).
   int64_t defBegin, defEnd;      // into updTasks (deferred tiles of this level)
+  // [defBegin, defMid): the deferred tiles in the columns of the outer block AFTER the next one,
+  // i.e. the only ones the next block's own update launch must wait for; they run first
+  int64_t defMid = 0;
   // the same two lists for the 128x128-tile kernel (large segments)
   int64_t bigBegin, bigEnd, bigDefBegin, bigDefEnd;
-  // EARLY POTRF.  When this level and the next one each hold a single panel of the same lump,
-  // the first `urgentCount` tiles of [updBegin, updEnd) are the ones that complete the next
-  // panel's diagonal block: they are launched first and the next level's potrf may start right
-  // after them, concurrently with the remaining tiles (the next level then skips its potrf).
-  int64_t urgentCount;
-  int32_t potrfIssuedEarly;  // this level's potrf was already launched by the previous level
   // DIRECT chain kernels (hip_kernels.h): set when the level holds one panel; directSeg >= 0 when
   // its non-deferred tiles [updBegin, updEnd) are exactly the tiles of that one intra segment
   int32_t directPanel = -1, directSeg = -1;
+  // fuseNext: tile 0 of directSeg is the diagonal block of the NEXT level's (single) panel, whose
+  // potrf is fused into this level's update launch (updateTileDirectPotrf); the next level then
+  // starts at its trsm
+  int32_t fuseNext = 0;
   int64_t waitDefLevel;          // index (within the same level list) of the level whose deferred
                                  // tiles must be complete before this level's update launch; -1
 };
