@@ -30,7 +30,7 @@ _SKEL_IDS = {
     "boardColLump": 13, "boardColOrd": 14,
 }
 
-PROF_KINDS = ["elim_factor", "elim_update", "potrf", "trsm", "update"]
+PROF_KINDS = ["elim_factor", "elim_update", "potrf", "trsm", "update", "chain_update"]
 
 
 class _CSettings(ctypes.Structure):
@@ -43,7 +43,8 @@ class _CSettings(ctypes.Structure):
 class _CPlanStats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in
                 ["flops", "upd_elems", "upd_flops", "elim_pair_elems", "elim_pair_flops",
-                 "elim_col_elems"]] + \
+                 "elim_col_elems", "upd_flops_direct", "elim_pair_operand_elems",
+                 "elim_target_elems", "trsm_flops", "potrf_flops"]] + \
                [(n, ctypes.c_int64) for n in
                 ["num_launches", "num_levels", "num_panels", "num_segs", "num_upd_tasks",
                  "num_trsm_tasks", "chain_tab_entries", "max_panels_in_level",
@@ -339,8 +340,8 @@ class Solver:
         """one factor() with every launch bracketed by HIP events on the execution stream;
         returns {kernel class: (total ms, launches)}"""
         self._check_data(data)
-        ms = (ctypes.c_double * 5)()
-        ln = (ctypes.c_int64 * 5)()
+        ms = (ctypes.c_double * 6)()
+        ln = (ctypes.c_int64 * 6)()
         _check(self._lib.bsp_factor_profiled_f64(self._h, ctypes.c_void_p(_ptr_of(data)), ms, ln))
         return {k: (ms[i], ln[i]) for i, k in enumerate(PROF_KINDS)}
 

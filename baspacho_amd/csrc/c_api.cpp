@@ -300,6 +300,11 @@ int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out) {
   out->elim_pair_elems = p.elimPairElems;
   out->elim_pair_flops = p.elimPairFlops;
   out->elim_col_elems = p.elimColElems;
+  out->upd_flops_direct = p.updFlopsDirect;
+  out->elim_pair_operand_elems = p.elimPairOperandElems;
+  out->elim_target_elems = p.elimTargetElems;
+  out->trsm_flops = p.trsmFlops;
+  out->potrf_flops = p.potrfFlops;
   out->num_launches = p.numLaunches;
   out->num_levels = p.numLevels;
   out->num_panels = p.numPanels;
@@ -324,7 +329,7 @@ int bsp_debug_read_trace(long long* out, int max_records, int* n_records) {
   BSP_CATCH
 }
 
-int bsp_factor_profiled_f64(bsp_solver* s, double* d, double ms[5], int64_t launches[5]) {
+int bsp_factor_profiled_f64(bsp_solver* s, double* d, double ms[6], int64_t launches[6]) {
   BSP_TRY
   HipKernelProfile prof;
   SymbolicCtx& sym = s->solver->internalSymbolicContext();

@@ -13,18 +13,20 @@ enum HipProfKind {
   kProfElimUpdate = 1,
   kProfPotrf = 2,
   kProfTrsm = 3,
-  kProfUpdate = 4,
-  kProfNumKinds = 5
+  kProfUpdate = 4,       // updateTile launches (task lists; the bulk of the flops)
+  kProfChainUpdate = 5,  // updateTileDirect / updateTileDirectPotrf launches of one-panel levels
+  kProfNumKinds = 6
 };
 
 struct HipKernelProfile {
-  double ms[kProfNumKinds] = {0, 0, 0, 0, 0};
-  int64_t launches[kProfNumKinds] = {0, 0, 0, 0, 0};
+  double ms[kProfNumKinds] = {0, 0, 0, 0, 0, 0};
+  int64_t launches[kProfNumKinds] = {0, 0, 0, 0, 0, 0};
 };
 
 struct HipPlanStats {
   double flops = 0, updElems = 0, updFlops = 0, elimPairElems = 0, elimPairFlops = 0,
-         elimColElems = 0;
+         elimColElems = 0, updFlopsDirect = 0, elimPairOperandElems = 0, elimTargetElems = 0,
+         trsmFlops = 0, potrfFlops = 0;
   int64_t numLaunches = 0, numLevels = 0, numPanels = 0, numSegs = 0, numUpdTasks = 0,
           numTrsmTasks = 0, chainTabEntries = 0, maxPanelsInLevel = 0, numAtomicUpdTasks = 0;
 };

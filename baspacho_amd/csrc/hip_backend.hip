@@ -379,7 +379,7 @@ struct HipNumericCtx : NumericCtx<T> {
       }
       const int64_t updBegin = lr.updBegin;
       if (lr.updEnd > updBegin) {
-        timer.begin(kProfUpdate);
+        timer.begin(direct && lr.directSeg >= 0 ? kProfChainUpdate : kProfUpdate);
         const bool fuse = direct && lr.directSeg >= 0 && lr.fuseNext && sym.fusePotrf &&
                           li + 1 < levels.size() && levels[li + 1].directPanel >= 0;
         if (fuse) {
@@ -859,6 +859,11 @@ HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t up
   s.elimPairElems = p.elimPairElems;
   s.elimPairFlops = p.elimPairFlops;
   s.elimColElems = p.elimColElems;
+  s.updFlopsDirect = p.updFlopsDirect;
+  s.elimPairOperandElems = p.elimPairOperandElems;
+  s.elimTargetElems = p.elimTargetElems;
+  s.trsmFlops = p.trsmFlops;
+  s.potrfFlops = p.potrfFlops;
   s.numLaunches = p.numLaunches;
   s.numLevels = (int64_t)p.levels.size();
   s.numPanels = (int64_t)p.panels.size();

@@ -118,6 +118,10 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
       const int64_t si = sorted[q].si;
       const int64_t t = sk.spanToLump[si];
       const size_t firstItem = plan.elimItems.size();
+      {
+        const double cols = double(sk.spanStart[si + 1] - sk.spanStart[si]);
+        plan.elimTargetElems += sj == si ? double(rows) * (rows + 1) / 2 : double(rows) * cols;
+      }
       int64_t u = q;
       while (u < q1) {  // split by source width and by length
         int64_t u1 = u;
@@ -282,6 +286,8 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         pd.vecOff = (int32_t)(sk.lumpStart[l] + c0);
         pd.pad = 0;
         plan.panels.push_back(pd);
+        plan.potrfFlops += double(nb) * nb * nb / 3.0;
+        plan.trsmFlops += double(pd.rowsBelow) * nb * nb;
         panelSegBegin.push_back((int64_t)plan.segs.size());
         const int64_t innerCols = blockEnd - c0 - nb;
         if (innerCols > 0) {
@@ -377,13 +383,17 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       {
         // pair updates of this column: for chains i<=j below the diagonal, |sj| x |si| elements
         // (lower triangle only when i==j)
-        double rowsAfter = 0, pairElems = 0;
+        double rowsAfter = 0, chainsAfter = 0, pairElems = 0, operandElems = 0;
         for (int64_t c = g.chain0 + g.nChains - 1; c >= g.chain0 + g.diagChains; c--) {
           const int64_t span = sk.chainRowSpan[c];
           const double sz = double(sk.spanStart[span + 1] - sk.spanStart[span]);
           pairElems += sz * (sz + 1) / 2 + rowsAfter * sz;
+          // both source blocks of every pair (i <= j): (s_i + s_j) * width values
+          operandElems += double(g.width) * (2 * sz + chainsAfter * sz + rowsAfter);
           rowsAfter += sz;
+          chainsAfter += 1;
         }
+        plan.elimPairOperandElems += operandElems;
         plan.elimPairElems += pairElems;
         plan.elimPairFlops += 2.0 * g.width * pairElems;
         plan.elimColElems += double(g.width) * (g.width + g.rowsBelow);
@@ -561,7 +571,14 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       if (lr.defEnd > lr.defBegin || lr.bigDefEnd > lr.bigDefBegin) plan.hasDeferred = true;
       if (bucket.size() == 1) {
         lr.directPanel = bucket[0].panel;
-        if (nowSegs == 1 && nowPlain) lr.directSeg = nowSeg;
+        if (nowSegs == 1 && nowPlain) {
+          lr.directSeg = nowSeg;
+          const SegDesc& sd = plan.segs[nowSeg];
+          const SrcDesc& sr = plan.srcs[sd.src];
+          const double R = double(sr.rowsBelow - sd.q0);
+          const double m = double(sd.outer ? std::min<int32_t>(sd.m, kOuterWidth) : sd.m);
+          plan.updFlopsDirect += 2.0 * sr.K * (m * R - m * (m - 1) / 2);
+        }
         if (chain && lr.directSeg >= 0) {
           const SegDesc& sd = plan.segs[lr.directSeg];
           const PanelDesc& next = plan.panels[buckets[bi + 1][0].panel];

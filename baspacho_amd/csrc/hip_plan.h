@@ -153,6 +153,8 @@ struct HipPlanHost {
   std::vector<int32_t> rowChain, rowLocal, rowColOff;  // per chain row of every dense lump
   std::vector<int32_t> rowGlobal;                      // ... and its row index in the full matrix
 
+  double updFlopsDirect = 0, elimPairOperandElems = 0, elimTargetElems = 0, trsmFlops = 0,
+         potrfFlops = 0;  // part of updFlops launched through the direct chain kernels
   std::vector<int32_t> levelPanels;
   std::vector<TrsmTask> trsmTasks;
   std::vector<UpdTask> updTasks;

@@ -31,6 +31,8 @@ if ROOT not in sys.path:
 import baspacho_amd as B  # noqa: E402
 from baspacho_amd import testing as T  # noqa: E402
 
+HERE = os.path.dirname(os.path.abspath(__file__))
+DT = "double"
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix (= vector) peak, AMD datasheet
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -179,48 +181,63 @@ def main():
             prof = sol.factorProfiled(work)
             tot = sum(v[0] for v in prof.values())
             out["kernel_ms"] = {k: [round(v[0], 4), v[1]] for k, v in prof.items()}
+            # algorithmic work of every kernel class, from the plan (DESIGN.md "Kernels"):
+            #   update / chain_update: 2 K per lower-trapezoid target element (symmetric update)
+            #   elim_update: the source blocks of every pair read once (the operands of the
+            #     products) + one read-modify-write of every target element
+            #   elim_factor: every element of the eliminated columns read and written once
+            pair_src_bytes = 8.0 * 2.0 * st["elim_pair_operand_elems"]
+            work_of = {
+                "update": ("updateTile<%s>" % DT, "mfma", st["upd_flops"] - st["upd_flops_direct"]),
+                "chain_update": ("updateTileDirectPotrf<%s>" % DT, "mfma", st["upd_flops_direct"]),
+                "elim_update": ("elimGatherMfma<%s>" % DT, "hbm",
+                                pair_src_bytes + 16.0 * st["elim_target_elems"]),
+                "elim_factor": ("elimFactorSmall<%s>" % DT, "hbm", 16.0 * st["elim_col_elems"]),
+                "trsm": ("trsmPanel<%s>" % DT, "mfma", st["trsm_flops"]),
+                "potrf": ("potrfPanel<%s>" % DT, "mfma", st["potrf_flops"]),
+            }
             dom = max(prof, key=lambda k: prof[k][0])
             ms, launches = prof[dom]
-            if dom in ("update", "potrf", "trsm"):
-                fl = {"update": st["upd_flops"]}.get(dom, 0.0)
-                if dom == "update":
-                    ach = fl / (ms * 1e-3) / 1e12
-                    out["roofline"] = {"kernel": "updateTile<double>", "bound": "mfma",
-                                       "achieved": round(ach, 3), "peak": PEAK_FP64_MFMA_TFLOPS,
-                                       "unit": "TFLOP/s", "frac": round(ach / PEAK_FP64_MFMA_TFLOPS, 4),
-                                       "traffic": None, "launches": launches,
-                                       "avg_launch_ms": round(ms / max(launches, 1), 5),
-                                       "algorithmic_flops_per_launch": fl / max(launches, 1),
-                                       "share_of_factor": round(ms / tot, 3)}
-            if "roofline" not in out:
-                # HBM-bound kernels: algorithmic bytes = read+write every element of the
-                # eliminated columns once (16 B) + RMW of every pair-update target element (16 B)
-                byt = {"elim_update": 16.0 * st["elim_pair_elems"] + 8.0 * st["elim_col_elems"],
-                       "elim_factor": 16.0 * st["elim_col_elems"]}.get(dom, 0.0)
-                ach = byt / (ms * 1e-3) / 1e9
-                out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1),
-                                   "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
-                                   "launches": launches,
-                                   "avg_launch_ms": round(ms / max(launches, 1), 5),
-                                   "algorithmic_bytes_per_launch": byt / max(launches, 1),
-                                   "share_of_factor": round(ms / tot, 3)}
-            if out["roofline"]["bound"] == "mfma":
+            kname, bound, amount = work_of[dom]
+            rate = amount / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9)
+            peak = PEAK_FP64_MFMA_TFLOPS if bound == "mfma" else PEAK_HBM_GBS
+            roof = {"kernel": kname, "bound": bound, "achieved": round(rate, 3), "peak": peak,
+                    "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                    "frac": round(rate / peak, 4), "traffic": None, "launches": launches,
+                    "avg_launch_ms": round(ms / max(launches, 1), 5),
+                    ("algorithmic_flops_per_launch" if bound == "mfma"
+                     else "algorithmic_bytes_per_launch"): amount / max(launches, 1),
+                    "share_of_factor": round(ms / tot, 3)}
+            # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+            # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported), same workload
+            try:
+                with open(os.path.join(HERE, "profiles", "pmc_traffic.json")) as f:
+                    pmc = json.load(f)
+                ent = pmc.get(args.workload, {}).get(kname.split("<")[0])
+                if ent:
+                    roof["traffic"] = (2.0 * ent["fetch_KB_per_factor"] +
+                                       ent["write_KB_per_factor"]) * 1024.0 / max(launches, 1)
+                    roof["traffic_source"] = pmc.get("_source", "profiles/pmc_traffic.json")
+            except (OSError, ValueError):
+                pass
+            if bound == "mfma":
                 # what back-to-back fp64 MFMAs sustain on this very GPU (register-only probe)
                 probe = B.probe_mfma_f64_tflops()
-                out["roofline"]["measured_mfma_probe"] = round(probe, 2)
-                out["roofline"]["frac_of_probe"] = round(out["roofline"]["achieved"] / probe, 4)
-            # secondary kernels, for the record
+                roof["measured_mfma_probe"] = round(probe, 2)
+                roof["frac_of_probe"] = round(rate / probe, 4)
+            out["roofline"] = roof
+            # every kernel class, for the record
             sec = {}
-            if prof["update"][0] > 0:
-                sec["update_TFLOPs"] = round(st["upd_flops"] / (prof["update"][0] * 1e-3) / 1e12, 3)
-            if prof["elim_update"][0] > 0:
-                b = 16.0 * st["elim_pair_elems"] + 8.0 * st["elim_col_elems"]
-                sec["elim_update_GBs"] = round(b / (prof["elim_update"][0] * 1e-3) / 1e9, 1)
-            if prof["elim_factor"][0] > 0:
-                sec["elim_factor_GBs"] = round(16.0 * st["elim_col_elems"] /
-                                               (prof["elim_factor"][0] * 1e-3) / 1e9, 1)
+            for k, (nm, bd, amt) in work_of.items():
+                if prof[k][0] > 0 and amt > 0:
+                    r = amt / (prof[k][0] * 1e-3) / (1e12 if bd == "mfma" else 1e9)
+                    sec[k] = {"kernel": nm, "rate": round(r, 3 if bd == "mfma" else 1),
+                              "unit": "TFLOP/s" if bd == "mfma" else "GB/s"}
             out["kernel_rates"] = sec
+            # whole-factor roofline: max(flops / MFMA peak, compulsory bytes / HBM peak)
+            t_roof = max(flops / (PEAK_FP64_MFMA_TFLOPS * 1e12),
+                         16.0 * sol.dataSize() / (PEAK_HBM_GBS * 1e9))
+            out["factor_roofline_frac"] = round(t_roof / (ms_per_step * 1e-3), 4)
 
         # ---- device solve() on the last factor (not part of the metric; BENCHMARK_RESULTS.md of the
         #      reference reports solve-1 timings separately too)

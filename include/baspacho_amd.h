@@ -155,7 +155,11 @@ int bsp_solve_lt_f32(bsp_solver* s, const float* dev_mat, float* dev_vec, int64_
 double bsp_factor_flops(const bsp_solver* s);
 
 typedef struct bsp_plan_stats {
-  double flops, upd_elems, upd_flops, elim_pair_elems, elim_pair_flops, elim_col_elems;
+  double flops, upd_elems, upd_flops, elim_pair_elems, elim_pair_flops, elim_col_elems,
+      upd_flops_direct,        /* part of upd_flops launched by the one-panel-level kernels */
+      elim_pair_operand_elems, /* values of both source blocks, summed over the pairs */
+      elim_target_elems,       /* distinct target elements of the sparse-elimination update */
+      trsm_flops, potrf_flops; /* dense panels: rowsBelow*nb^2 and nb^3/3 */
   int64_t num_launches, num_levels, num_panels, num_segs, num_upd_tasks, num_trsm_tasks,
       chain_tab_entries, max_panels_in_level, num_atomic_upd_tasks;
 } bsp_plan_stats;
@@ -167,10 +171,11 @@ enum {
   BSP_PROF_ELIM_UPDATE = 1,
   BSP_PROF_POTRF = 2,
   BSP_PROF_TRSM = 3,
-  BSP_PROF_UPDATE = 4,
-  BSP_PROF_NUM_KINDS = 5
+  BSP_PROF_UPDATE = 4,       /* updateTile: task-list launches, the bulk of the flops */
+  BSP_PROF_CHAIN_UPDATE = 5, /* update launches of one-panel levels (next potrf fused in) */
+  BSP_PROF_NUM_KINDS = 6
 };
-int bsp_factor_profiled_f64(bsp_solver* s, double* dev_data, double ms[5], int64_t launches[5]);
+int bsp_factor_profiled_f64(bsp_solver* s, double* dev_data, double ms[6], int64_t launches[6]);
 
 /* sustained v_mfma_f64_16x16x4_f64 rate of the current GPU (TFLOP/s), register-only probe */
 int bsp_probe_mfma_f64(double* tflops);
