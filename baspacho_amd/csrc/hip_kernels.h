@@ -32,6 +32,13 @@ __device__ __forceinline__ void waveSync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory
+// counter, i.e. it waits for every global store in flight (hundreds of cycles when a kernel
+// stores to memory between barriers, as the panel Cholesky does with its finished columns)
+__device__ __forceinline__ void ldsBarrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // 1/sqrt(x): hardware estimate (v_rsq_f64 / v_rsq_f32) refined by Newton steps to full precision.
 // The library rsqrt() expands to a full-precision sqrt plus a division (hundreds of dependent
 // cycles), which sits on the serial critical path of the panel Cholesky.
@@ -494,22 +501,27 @@ struct NoPreUpdate {
 
 // `pre(acc)` runs between the load of the block and the factorization: the fused kernel
 // (updateTileDirectPotrf) applies the pending rank-K update of the block there.
+// blk: 3 x (16 NT) rows of 4 values (ring of column blocks), sol: 16 NT rows of 4 values.
 template <typename T, int NT, typename Pre = NoPreUpdate>
-__device__ __forceinline__ void potrfTiles(T* A, int nb, int lda, T (*raw)[4], T (*sol)[4],
-                                           T (*fin)[4], Pre pre = Pre()) {
+__device__ __forceinline__ void potrfTiles(T* A, int nb, int lda, T (*blk)[4], T (*sol)[4],
+                                           Pre pre = Pre()) {
   // The block lives in MFMA accumulator layout: wave w owns tile row w (16x16 tiles (w,0..w));
   // lane l / register r of tile (ti,tj) hold row 16ti + Mfma::row(l,r), column 16tj + (l&15).
-  // One step per 4-column pivot block (two barriers each):
-  //   (1) the lanes that hold columns 4J..4J+3 publish them (raw[row][0..3]);
-  //   (2) thread (i,g) = (tid/4, tid%4) factors the 4x4 pivot redundantly (hardware rsq + Newton),
-  //       solves row i against it and publishes sol[i][g] (zero for rows that are done) and the
-  //       final entry fin[i][g] = L(i, 4J+g);
-  //   (3) every live tile gets the rank-4 update  D -= sol_rows * sol_cols^T  as ONE v_mfma
-  //       16x16x4 (operands: one LDS read each) and the holder lanes install the final column
-  //       block.
+  // One step per 4-column pivot block.  The serial path of a step touches only LDS and the
+  // vector ALU; the matrix cores keep the trailing block up to date BEHIND it:
+  //   * a column block is copied out of the accumulators ("published") into a ring slot two
+  //     steps before it becomes the pivot block, and brought up to date there by thread (i,g) =
+  //     (tid/4, tid%4) with 4 FMAs per step -- so a step never waits for the MFMA of the
+  //     previous one, nor for a round trip through the accumulator layout;
+  //   * (1) thread (i,g) factors the 4x4 pivot redundantly (hardware rsq + Newton), solves row i
+  //     against it, publishes sol[i][g] (zero for rows that are done) and stores the final entry
+  //     L(i, 4J+g) straight to memory;  -- barrier --
+  //   * (2) thread-level update of the next two column blocks; every live tile gets the rank-4
+  //     update  D -= sol_rows * sol_cols^T  as ONE v_mfma 16x16x4 (fire and forget);  -- barrier --
   // Finished columns are protected by the zeros in sol, so full-tile updates need no masks.
   // Strictly-upper entries are carried as finite mirror values and never written back; rows and
   // columns beyond nb are padded with the identity.
+  constexpr int N = 16 * NT;
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
   const int i = tid >> 2, g = tid & 3;
@@ -532,98 +544,100 @@ __device__ __forceinline__ void potrfTiles(T* A, int nb, int lda, T (*raw)[4], T
   pre(acc);
   BSP_STAMP(1);
   const int nSteps = (nb + 3) >> 2;
-#pragma unroll 1
-  for (int J = 0; J < nSteps; J++) {
-    const int j0 = 4 * J, tjJ = J >> 2, cbase = 4 * (J & 3);
-    const bool holder = w >= tjJ && li >= cbase && li < cbase + 4;
-    // (1) publish the raw column block
+  // copy column block c (columns 4c..4c+3, rows of the tile rows that hold them) out of the
+  // accumulators into ring slot c % 3
+  auto publish = [&](int c) {
+    const int tjc = c >> 2, cbase = 4 * (c & 3);
+    if (w >= tjc && li >= cbase && li < cbase + 4) {
+      T(*dst)[4] = blk + (c % 3) * N;
 #pragma unroll
-    for (int tj = 0; tj < NT; tj++) {
-      if (tj == tjJ && holder) {
+      for (int tj = 0; tj < NT; tj++) {
+        if (tj == tjc) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) raw[16 * w + Mfma<T>::row(lane, r)][li - cbase] = acc[tj][r];
+          for (int r = 0; r < 4; r++) dst[16 * w + Mfma<T>::row(lane, r)][li - cbase] = acc[tj][r];
+        }
       }
     }
-    __syncthreads();
-    // (2) pivot block + own row
+  };
+  publish(0);
+  if (nSteps > 1) publish(1);
+  ldsBarrier();
+#pragma unroll 1
+  for (int J = 0; J < nSteps; J++) {
+    const int j0 = 4 * J, tjJ = J >> 2;
+    T(*raw)[4] = blk + (J % 3) * N;
+    // (1) pivot block + own row
+    const T p00 = raw[j0][0];
+    const T p10 = raw[j0 + 1][0], p11 = raw[j0 + 1][1];
+    const T p20 = raw[j0 + 2][0], p21 = raw[j0 + 2][1], p22 = raw[j0 + 2][2];
+    const T p30 = raw[j0 + 3][0], p31 = raw[j0 + 3][1], p32 = raw[j0 + 3][2],
+            p33 = raw[j0 + 3][3];
+    const T r0 = raw[i][0], r1 = raw[i][1], r2 = raw[i][2], r3 = raw[i][3];
+    const T i0 = fastRsqrt(p00);
+    const T l00 = p00 * i0, l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+    const T q11 = p11 - l10 * l10;
+    const T i1 = fastRsqrt(q11);
+    const T l11 = q11 * i1, l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+    const T q22 = p22 - l20 * l20 - l21 * l21;
+    const T i2 = fastRsqrt(q22);
+    const T l22 = q22 * i2, l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+    const T q33 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
+    const T i3 = fastRsqrt(q33);
+    const T l33 = q33 * i3;
+    const bool below = i >= j0 + 4;
+    // own row solved against the pivot block (zero for rows that are done or inside the block)
+    T c0 = r0 * i0;
+    T c1 = (r1 - c0 * l10) * i1;
+    T c2 = (r2 - c0 * l20 - c1 * l21) * i2;
+    T c3 = (r3 - c0 * l30 - c1 * l31 - c2 * l32) * i3;
+    c0 = below ? c0 : T(0);
+    c1 = below ? c1 : T(0);
+    c2 = below ? c2 : T(0);
+    c3 = below ? c3 : T(0);
+    const T solved = g == 0 ? c0 : g == 1 ? c1 : g == 2 ? c2 : c3;
+    sol[i][g] = solved;
+    // (the previous step's MFMAs have had the whole pivot chain to complete: no stall here)
+    if (J + 2 < nSteps) publish(J + 2);  // state: rank-4 updates of steps < J
     {
-      const T p00 = raw[j0][0];
-      const T p10 = raw[j0 + 1][0], p11 = raw[j0 + 1][1];
-      const T p20 = raw[j0 + 2][0], p21 = raw[j0 + 2][1], p22 = raw[j0 + 2][2];
-      const T p30 = raw[j0 + 3][0], p31 = raw[j0 + 3][1], p32 = raw[j0 + 3][2],
-              p33 = raw[j0 + 3][3];
-      const T r0 = raw[i][0], r1 = raw[i][1], r2 = raw[i][2], r3 = raw[i][3];
-      const T i0 = fastRsqrt(p00);
-      const T l00 = p00 * i0, l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
-      const T q11 = p11 - l10 * l10;
-      const T i1 = fastRsqrt(q11);
-      const T l11 = q11 * i1, l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
-      const T q22 = p22 - l20 * l20 - l21 * l21;
-      const T i2 = fastRsqrt(q22);
-      const T l22 = q22 * i2, l32 = (p32 - l30 * l20 - l31 * l21) * i2;
-      const T q33 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
-      const T i3 = fastRsqrt(q33);
-      const T l33 = q33 * i3;
-      const T c0 = r0 * i0;
-      const T c1 = (r1 - c0 * l10) * i1;
-      const T c2 = (r2 - c0 * l20 - c1 * l21) * i2;
-      const T c3 = (r3 - c0 * l30 - c1 * l31 - c2 * l32) * i3;
-      const bool below = i >= j0 + 4;
       const int di = i - j0;  // row inside the pivot block when 0..3
       const T lrow0 = di == 0 ? l00 : di == 1 ? l10 : di == 2 ? l20 : l30;
       const T lrow1 = di == 1 ? l11 : di == 2 ? l21 : l31;
       const T lrow2 = di == 2 ? l22 : l32;
       const T inPiv = g == 0 ? lrow0 : g == 1 ? lrow1 : g == 2 ? lrow2 : l33;
-      const T solved = g == 0 ? c0 : g == 1 ? c1 : g == 2 ? c2 : c3;
-      sol[i][g] = below ? solved : T(0);
-      fin[i][g] = below ? solved : ((di >= 0 && g <= di) ? inPiv : T(0));
+      if (i < nb && j0 + g < nb && di >= g) A[(int64_t)i * lda + j0 + g] = below ? solved : inPiv;
     }
-    __syncthreads();
-    // (3) rank-4 update of every live tile + install the final column block
+    ldsBarrier();
+    // (2) bring the next two column blocks up to date, rank-4 update of every live tile
+#pragma unroll
+    for (int ahead = 1; ahead <= 2; ahead++) {
+      if (J + ahead < nSteps) {
+        T(*nx)[4] = blk + ((J + ahead) % 3) * N;
+        const int jr = j0 + 4 * ahead + g;
+        nx[i][g] -= c0 * sol[jr][0] + c1 * sol[jr][1] + c2 * sol[jr][2] + c3 * sol[jr][3];
+      }
+    }
     {
       const T sa = -sol[16 * w + li][lk];
 #pragma unroll
       for (int tj = 0; tj < NT; tj++) {
         if (tj <= w && tj >= tjJ) {  // wave-uniform; tile columns left of the pivot are final
-          const T sb = sol[16 * tj + li][lk];
-          acc[tj] = Mfma<T>::run(sa, sb, acc[tj]);
-        }
-      }
-#pragma unroll
-      for (int tj = 0; tj < NT; tj++) {
-        if (tj == tjJ && holder) {
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int row = 16 * w + Mfma<T>::row(lane, r);
-            const T f = fin[row][li - cbase];
-            acc[tj][r] = row >= j0 ? f : acc[tj][r];
-          }
+          acc[tj] = Mfma<T>::run(sa, sol[16 * tj + li][lk], acc[tj]);
         }
       }
     }
+    ldsBarrier();
   }
   BSP_STAMP(2);
-#pragma unroll
-  for (int tj = 0; tj < NT; tj++) {
-    if (tj <= w) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = 16 * w + Mfma<T>::row(lane, r), col = 16 * tj + li;
-        if (row < nb && col <= row) A[(int64_t)row * lda + col] = acc[tj][r];
-      }
-    }
-  }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
                                                   const int32_t* levelPanels, DataRef<T> dref) {
-  __shared__ T raw[kPanelWidth][4];
+  __shared__ T blk[3 * kPanelWidth][4];
   __shared__ T sol[kPanelWidth][4];
-  __shared__ T fin[kPanelWidth][4];
   BSP_STAMP(0);
   const PanelDesc pd = panels[levelPanels[blockIdx.x]];
-  potrfTiles<T, 4>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, raw, sol, fin);
+  potrfTiles<T, 4>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, blk, sol);
   BSP_STAMP(3);
 }
 
@@ -635,12 +649,11 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
 // trip plus the store.
 template <typename T>
 __global__ __launch_bounds__(256) void potrfPanelDirect(PanelDesc pd, DataRef<T> dref) {
-  __shared__ T raw[kPanelWidth][4];
+  __shared__ T blk[3 * kPanelWidth][4];
   __shared__ T sol[kPanelWidth][4];
-  __shared__ T fin[kPanelWidth][4];
   __builtin_amdgcn_s_setprio(3);
   BSP_STAMP(0);
-  potrfTiles<T, 4>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, raw, sol, fin);
+  potrfTiles<T, 4>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, blk, sol);
   BSP_STAMP(3);
 }
 
@@ -1155,9 +1168,8 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
     return;
   }
   __builtin_amdgcn_s_setprio(3);
-  T(*raw)[4] = reinterpret_cast<T(*)[4]>(Bs);
-  T(*sol)[4] = raw + kPanelWidth;
-  T(*fin)[4] = sol + kPanelWidth;
+  T(*blk)[4] = reinterpret_cast<T(*)[4]>(Bs);
+  T(*sol)[4] = blk + 3 * kPanelWidth;
   const int K = pd.K, lda = pd.lda, nb = next.nb;
   const T* X = data + pd.off + (int64_t)sd.q0 * lda;  // rows of the next panel, source columns
   using Acc = typename Mfma<T>::Acc;
@@ -1199,7 +1211,7 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
     }
   };
   BSP_STAMP(0);
-  potrfTiles<T, 4>(data + next.diagOff, nb, next.lda, raw, sol, fin, pre);
+  potrfTiles<T, 4>(data + next.diagOff, nb, next.lda, blk, sol, pre);
   BSP_STAMP(3);
 }
 
