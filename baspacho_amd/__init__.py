@@ -311,9 +311,20 @@ class Solver:
             self._h, ctypes.c_void_p(_ptr_of(data)), ctypes.c_int64(elim_range_index)))
 
     def _solve(self, name, mat, vec, stride, nrhs):
-        self._check_data(mat)
         if stride is None:
             stride = self.order()
+        if isinstance(mat, (list, tuple)):  # batch: one factored matrix and one vector block each
+            assert isinstance(vec, (list, tuple)) and len(vec) == len(mat)
+            for t in mat:
+                self._check_data(t)
+            which = {"bsp_solve_": 0, "bsp_solve_l_": 1, "bsp_solve_lt_": 2}[name]
+            mats = (ctypes.c_void_p * len(mat))(*[_ptr_of(t) for t in mat])
+            vecs = (ctypes.c_void_p * len(vec))(*[_ptr_of(t) for t in vec])
+            _check(getattr(self._lib, "bsp_solve_batched_" + _suffix(mat[0]))(
+                self._h, mats, vecs, ctypes.c_int32(len(mat)), ctypes.c_int64(stride),
+                ctypes.c_int32(nrhs), ctypes.c_int32(which)))
+            return
+        self._check_data(mat)
         _check(getattr(self._lib, name + _suffix(mat))(
             self._h, ctypes.c_void_p(_ptr_of(mat)), ctypes.c_void_p(_ptr_of(vec)),
             ctypes.c_int64(stride), ctypes.c_int32(nrhs)))

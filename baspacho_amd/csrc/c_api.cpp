@@ -288,6 +288,35 @@ int bsp_solve_lt_f32(bsp_solver* s, const float* m, float* v, int64_t stride, in
   BSP_CATCH
 }
 
+// batched solve: which = 0 solve, 1 solveL, 2 solveLt
+template <typename T>
+static void solveBatched(bsp_solver* s, const T* const* mats, T* const* vecs, int32_t batch,
+                         int64_t stride, int32_t nrhs, int32_t which) {
+  std::vector<T*> m(batch), v(vecs, vecs + batch);
+  for (int32_t q = 0; q < batch; q++) m[q] = const_cast<T*>(mats[q]);
+  if (which == 0) {
+    s->solver->solve(&m, &v, stride, nrhs);
+  } else if (which == 1) {
+    s->solver->solveL(&m, &v, stride, nrhs);
+  } else if (which == 2) {
+    s->solver->solveLt(&m, &v, stride, nrhs);
+  } else {
+    throw std::runtime_error("bsp_solve_batched: which must be 0 (solve), 1 (L) or 2 (Lt)");
+  }
+}
+int bsp_solve_batched_f64(bsp_solver* s, const double* const* mats, double* const* vecs,
+                          int32_t batch, int64_t stride, int32_t nrhs, int32_t which) {
+  BSP_TRY
+  solveBatched<double>(s, mats, vecs, batch, stride, nrhs, which);
+  BSP_CATCH
+}
+int bsp_solve_batched_f32(bsp_solver* s, const float* const* mats, float* const* vecs,
+                          int32_t batch, int64_t stride, int32_t nrhs, int32_t which) {
+  BSP_TRY
+  solveBatched<float>(s, mats, vecs, batch, stride, nrhs, which);
+  BSP_CATCH
+}
+
 double bsp_factor_flops(const bsp_solver* s) { return s->solver->factorFlops(); }
 
 int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out) {

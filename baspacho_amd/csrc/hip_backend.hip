@@ -678,87 +678,92 @@ NumericCtxBase* HipSymbolicCtx::createNumericCtxForType(std::type_index tIdx, in
 // Triangular solves on the device, fused over a lump range (SolveCtx extension of mat_ops.h).
 template <typename T>
 struct HipSolveCtx : SolveCtx<T> {
-  HipSolveCtx(HipSymbolicCtx& sym_, int nRHS_) : sym(sym_), nRHS(nRHS_) {}
+  using BT = BaseType<T>;
+  HipSolveCtx(HipSymbolicCtx& sym_, int nRHS_, int batch_) : sym(sym_), nRHS(nRHS_), batch(batch_) {}
 
   virtual bool hasFusedSolve() const override { return true; }
 
+  dim3 grid(unsigned x) const { return dim3(x, (unsigned)nRHS, (unsigned)batch); }
+
   template <bool BACKWARD>
-  void elimRange(DevPlan& plan, const ElimRangePlan& er, const T* data, T* C, int64_t ldc) {
+  void elimRange(DevPlan& plan, const ElimRangePlan& er, hipk::SolveRef<BT> ref) {
     hipk::SkelDev sk = sym.skelDev();
     const int64_t nLumps = er.lumpEnd - er.lumpBegin;
     if (nLumps <= 0) return;
     auto small = [&] {
-      const dim3 gL((unsigned)((nLumps + 255) / 256), (unsigned)nRHS);
+      const dim3 gL = grid((unsigned)((nLumps + 255) / 256));
       if (BACKWARD) {
-        hipk::solveElimSmall<T, true><<<gL, 256, 0, sym.stream>>>(sk, data, C, ldc, er.lumpBegin,
-                                                                  er.lumpEnd);
+        hipk::solveElimSmall<BT, true><<<gL, 256, 0, sym.stream>>>(sk, ref, er.lumpBegin, er.lumpEnd);
         return;
       }
       plan.ensureSolveGather(sym.skel);
       const auto items = plan.solveGather.rangeItems[&er - plan.host.elimRanges.data()];
-      hipk::solveElimDiagL<T><<<gL, 256, 0, sym.stream>>>(sk, data, C, ldc, er.lumpBegin,
-                                                          er.lumpEnd);
+      hipk::solveElimDiagL<BT><<<gL, 256, 0, sym.stream>>>(sk, ref, er.lumpBegin, er.lumpEnd);
       if (items.second > items.first) {
-        hipk::solveElimGatherL<T><<<dim3((unsigned)(items.second - items.first), (unsigned)nRHS),
-                                    256, 0, sym.stream>>>(
+        hipk::solveElimGatherL<BT><<<grid((unsigned)(items.second - items.first)), 256, 0,
+                                     sym.stream>>>(
             plan.solveItems.as<SolveGatherItem>() + items.first,
-            plan.solveEntries.as<SolveGatherEntry>(), data, C, ldc);
+            plan.solveEntries.as<SolveGatherEntry>(), ref);
       }
     };
     // lumps of a range are mutually independent: the order small/wide does not matter
     if (!BACKWARD) {
       small();
-      denseLevels<false>(plan, er.bigLevels, data, C, ldc);
+      denseLevels<false>(plan, er.bigLevels, ref);
     } else {
-      denseLevels<true>(plan, er.bigLevels, data, C, ldc);
+      denseLevels<true>(plan, er.bigLevels, ref);
       small();
     }
   }
 
   template <bool BACKWARD>
-  void denseLevels(DevPlan& plan, const vector<LevelRange>& levels, const T* data, T* C,
-                   int64_t ldc) {
+  void denseLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::SolveRef<BT> ref) {
     const int64_t nL = (int64_t)levels.size();
     for (int64_t k = 0; k < nL; k++) {
       const LevelRange& lr = levels[BACKWARD ? nL - 1 - k : k];
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
       if (!nP) continue;
-      const dim3 gP(nP, (unsigned)nRHS), gT(nT, (unsigned)nRHS);
+      const dim3 gP = grid(nP), gT = grid(nT);
       if (!BACKWARD) {
-        hipk::solveTriPanel<T, false><<<gP, 256, 0, sym.stream>>>(
-            plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, data, C, ldc);
+        hipk::solveTriPanel<BT, false><<<gP, 256, 0, sym.stream>>>(
+            plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, ref);
         if (nT) {
-          hipk::solveGemvL<T><<<gT, 256, 0, sym.stream>>>(
+          hipk::solveGemvL<BT><<<gT, 256, 0, sym.stream>>>(
               plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin,
-              plan.rowGlobal.as<int32_t>(), data, C, ldc);
+              plan.rowGlobal.as<int32_t>(), ref);
         }
       } else {
         if (nT) {
-          hipk::solveGemvLt<T><<<gT, 256, 0, sym.stream>>>(
+          hipk::solveGemvLt<BT><<<gT, 256, 0, sym.stream>>>(
               plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin,
-              plan.rowGlobal.as<int32_t>(), data, C, ldc);
+              plan.rowGlobal.as<int32_t>(), ref);
         }
-        hipk::solveTriPanel<T, true><<<gP, 256, 0, sym.stream>>>(
-            plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, data, C, ldc);
+        hipk::solveTriPanel<BT, true><<<gP, 256, 0, sym.stream>>>(
+            plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, ref);
       }
     }
   }
 
+  // single matrix: the pointers themselves; batch: the two pointer arrays, uploaded per call
+  hipk::SolveRef<BT> makeRef(const T* data, T* C, int64_t ldc);
+
   virtual void solveLRange(const T* data, int64_t startLump, int64_t upToLump, T* C,
                            int64_t ldc) override {
     DevPlan& plan = sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
-    for (const ElimRangePlan& er : plan.host.elimRanges) elimRange<false>(plan, er, data, C, ldc);
-    denseLevels<false>(plan, plan.host.levels, data, C, ldc);
+    hipk::SolveRef<BT> ref = makeRef(data, C, ldc);
+    for (const ElimRangePlan& er : plan.host.elimRanges) elimRange<false>(plan, er, ref);
+    denseLevels<false>(plan, plan.host.levels, ref);
     hipCHECK(hipGetLastError());
   }
 
   virtual void solveLtRange(const T* data, int64_t startLump, int64_t upToLump, T* C,
                             int64_t ldc) override {
     DevPlan& plan = sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
-    denseLevels<true>(plan, plan.host.levels, data, C, ldc);
+    hipk::SolveRef<BT> ref = makeRef(data, C, ldc);
+    denseLevels<true>(plan, plan.host.levels, ref);
     for (auto it = plan.host.elimRanges.rbegin(); it != plan.host.elimRanges.rend(); ++it) {
-      elimRange<true>(plan, *it, data, C, ldc);
+      elimRange<true>(plan, *it, ref);
     }
     hipCHECK(hipGetLastError());
   }
@@ -778,13 +783,47 @@ struct HipSolveCtx : SolveCtx<T> {
   virtual void assembleVecT(const T*, int64_t, int64_t, int64_t) override { perOp("assembleVecT"); }
 
   HipSymbolicCtx& sym;
-  int nRHS;
+  int nRHS, batch;
+  DevBuf devMats, devVecs;
 };
 
-SolveCtxBase* HipSymbolicCtx::createSolveCtxForType(std::type_index tIdx, int nRHS, int) {
-  if (tIdx == std::type_index(typeid(double))) return new HipSolveCtx<double>(*this, nRHS);
-  if (tIdx == std::type_index(typeid(float))) return new HipSolveCtx<float>(*this, nRHS);
-  throw std::runtime_error("HIP backend: batched solve is not available yet");
+template <>
+hipk::SolveRef<double> HipSolveCtx<double>::makeRef(const double* data, double* C, int64_t ldc) {
+  return {data, C, nullptr, nullptr, ldc};
+}
+template <>
+hipk::SolveRef<float> HipSolveCtx<float>::makeRef(const float* data, float* C, int64_t ldc) {
+  return {data, C, nullptr, nullptr, ldc};
+}
+template <>
+hipk::SolveRef<double> HipSolveCtx<vector<double*>>::makeRef(const vector<double*>* data,
+                                                             vector<double*>* C, int64_t ldc) {
+  BASPACHO_CHECK_EQ((int)data->size(), batch);
+  BASPACHO_CHECK_EQ((int)C->size(), batch);
+  devMats.upload(*data);
+  devVecs.upload(*C);
+  return {nullptr, nullptr, devMats.as<const double*>(), devVecs.as<double*>(), ldc};
+}
+template <>
+hipk::SolveRef<float> HipSolveCtx<vector<float*>>::makeRef(const vector<float*>* data,
+                                                           vector<float*>* C, int64_t ldc) {
+  BASPACHO_CHECK_EQ((int)data->size(), batch);
+  BASPACHO_CHECK_EQ((int)C->size(), batch);
+  devMats.upload(*data);
+  devVecs.upload(*C);
+  return {nullptr, nullptr, devMats.as<const float*>(), devVecs.as<float*>(), ldc};
+}
+
+SolveCtxBase* HipSymbolicCtx::createSolveCtxForType(std::type_index tIdx, int nRHS, int batch) {
+  if (tIdx == std::type_index(typeid(double))) return new HipSolveCtx<double>(*this, nRHS, 1);
+  if (tIdx == std::type_index(typeid(float))) return new HipSolveCtx<float>(*this, nRHS, 1);
+  if (tIdx == std::type_index(typeid(vector<double*>))) {
+    return new HipSolveCtx<vector<double*>>(*this, nRHS, batch);
+  }
+  if (tIdx == std::type_index(typeid(vector<float*>))) {
+    return new HipSolveCtx<vector<float*>>(*this, nRHS, batch);
+  }
+  return nullptr;
 }
 
 struct HipOps : Ops {

@@ -11,6 +11,25 @@
 namespace BaSpaCho {
 namespace hipk {
 
+// matrix data and right-hand sides of one launch: a single pair, or one pair per batch entry
+// (blockIdx.z); nRHS columns of a vector are ldc apart (blockIdx.y)
+template <typename T>
+struct SolveRef {
+  const T* mat;
+  T* vec;
+  const T* const* mats;
+  T* const* vecs;
+  int64_t ldc;
+};
+template <typename T>
+__device__ __forceinline__ const T* solveMat(const SolveRef<T>& r) {
+  return r.mats ? r.mats[blockIdx.z] : r.mat;
+}
+template <typename T>
+__device__ __forceinline__ T* solveVec(const SolveRef<T>& r) {
+  return (r.vecs ? r.vecs[blockIdx.z] : r.vec) + (int64_t)blockIdx.y * r.ldc;
+}
+
 __device__ __forceinline__ double waveSum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -27,14 +46,14 @@ __device__ __forceinline__ float waveSum(float v) {
 //           hit the same rows)          (reference: sparseElim_diagSolveL + subDiagMult, :883-946)
 // backward: x_l -= sum B^T x[rows] ;  x_l <- D^-T x_l                 (:949-1012)
 template <typename T, bool BACKWARD>
-__global__ __launch_bounds__(256) void solveElimSmall(SkelDev sk, const T* data, T* vecAll,
-                                                      int64_t ldc, int64_t lumpBegin,
-                                                      int64_t lumpEnd) {
+__global__ __launch_bounds__(256) void solveElimSmall(SkelDev sk, SolveRef<T> ref,
+                                                      int64_t lumpBegin, int64_t lumpEnd) {
   const int64_t l = lumpBegin + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (l >= lumpEnd) return;
   const int n = (int)(sk.lumpStart[l + 1] - sk.lumpStart[l]);
   if (n > kElimSmallMax) return;  // wide lumps go through the panel kernels
-  T* vec = vecAll + (int64_t)blockIdx.y * ldc;
+  const T* data = solveMat(ref);
+  T* vec = solveVec(ref);
   const int64_t c0 = sk.chainColPtr[l], cEnd = sk.chainColPtr[l + 1];
   const int64_t diagCh = sk.boardChainColOrd[sk.boardColPtr[l] + 1];
   const T* D = data + sk.chainData[c0];
@@ -82,15 +101,14 @@ __global__ __launch_bounds__(256) void solveElimSmall(SkelDev sk, const T* data,
 // ---- sparse-elimination ranges, forward pass in gather form --------------------------------
 // K-S1: x_l <- D^-1 x_l for the small lumps of a range (thread per lump)
 template <typename T>
-__global__ __launch_bounds__(256) void solveElimDiagL(SkelDev sk, const T* data, T* vecAll,
-                                                      int64_t ldc, int64_t lumpBegin,
-                                                      int64_t lumpEnd) {
+__global__ __launch_bounds__(256) void solveElimDiagL(SkelDev sk, SolveRef<T> ref,
+                                                      int64_t lumpBegin, int64_t lumpEnd) {
   const int64_t l = lumpBegin + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (l >= lumpEnd) return;
   const int n = (int)(sk.lumpStart[l + 1] - sk.lumpStart[l]);
   if (n > kElimSmallMax) return;
-  const T* D = data + sk.chainData[sk.chainColPtr[l]];
-  T* xl = vecAll + (int64_t)blockIdx.y * ldc + sk.lumpStart[l];
+  const T* D = solveMat(ref) + sk.chainData[sk.chainColPtr[l]];
+  T* xl = solveVec(ref) + sk.lumpStart[l];
   T x[kElimSmallMax];
   for (int i = 0; i < n; i++) x[i] = xl[i];
   for (int i = 0; i < n; i++) {
@@ -108,10 +126,11 @@ __global__ __launch_bounds__(256) void solveElimDiagL(SkelDev sk, const T* data,
 template <typename T>
 __global__ __launch_bounds__(256) void solveElimGatherL(const SolveGatherItem* items,
                                                         const SolveGatherEntry* entries,
-                                                        const T* data, T* vecAll, int64_t ldc) {
+                                                        SolveRef<T> ref) {
   __shared__ T part[4];
   const SolveGatherItem it = items[blockIdx.x];
-  T* vec = vecAll + (int64_t)blockIdx.y * ldc;
+  const T* data = solveMat(ref);
+  T* vec = solveVec(ref);
   const int e = it.entryBegin + (int)threadIdx.x;
   const bool live = e < it.entryEnd;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,13 +171,13 @@ __device__ __forceinline__ float laneBcast(float v, int j) {
 
 template <typename T, bool BACKWARD>
 __global__ __launch_bounds__(256) void solveTriPanel(const PanelDesc* panels,
-                                                     const int32_t* levelPanels, const T* data,
-                                                     T* vecAll, int64_t ldc) {
+                                                     const int32_t* levelPanels,
+                                                     SolveRef<T> ref) {
   constexpr int NB = kPanelWidth, LD = NB + 1;
   __shared__ T Ls[NB * LD];
   const PanelDesc pd = panels[levelPanels[blockIdx.x]];
-  const T* A = data + pd.diagOff;
-  T* x = vecAll + (int64_t)blockIdx.y * ldc + pd.vecOff;
+  const T* A = solveMat(ref) + pd.diagOff;
+  T* x = solveVec(ref) + pd.vecOff;
   const int nb = pd.nb, lda = pd.lda, tid = threadIdx.x;
   {
     T v[16];
@@ -206,11 +225,11 @@ __device__ __forceinline__ int solveTargetRow(const PanelDesc& pd, const int32_t
 // reductions start.
 template <typename T>
 __global__ __launch_bounds__(256) void solveGemvL(const PanelDesc* panels, const TrsmTask* tasks,
-                                                  const int32_t* rowGlobal, const T* data,
-                                                  T* vecAll, int64_t ldc) {
+                                                  const int32_t* rowGlobal, SolveRef<T> ref) {
   const TrsmTask task = tasks[blockIdx.x];
   const PanelDesc pd = panels[task.panel];
-  T* vec = vecAll + (int64_t)blockIdx.y * ldc;
+  const T* data = solveMat(ref);
+  T* vec = solveVec(ref);
   const int nb = pd.nb, lda = pd.lda, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k0 = (lane & 15) * 4, sub = lane >> 4;
   const T* P = data + pd.diagOff + (int64_t)nb * lda;
@@ -242,12 +261,12 @@ __global__ __launch_bounds__(256) void solveGemvL(const PanelDesc* panels, const
 // takes 16 rows, loads issued up front)
 template <typename T>
 __global__ __launch_bounds__(256) void solveGemvLt(const PanelDesc* panels, const TrsmTask* tasks,
-                                                   const int32_t* rowGlobal, const T* data,
-                                                   T* vecAll, int64_t ldc) {
+                                                   const int32_t* rowGlobal, SolveRef<T> ref) {
   __shared__ T part[4][kPanelWidth];
   const TrsmTask task = tasks[blockIdx.x];
   const PanelDesc pd = panels[task.panel];
-  T* vec = vecAll + (int64_t)blockIdx.y * ldc;
+  const T* data = solveMat(ref);
+  T* vec = solveVec(ref);
   const int nb = pd.nb, lda = pd.lda, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* P = data + pd.diagOff + (int64_t)nb * lda;
   const int rows = min(kTile, pd.rowsBelow - task.rowTile);

@@ -149,6 +149,13 @@ int bsp_solve_l_f32(bsp_solver* s, const float* dev_mat, float* dev_vec, int64_t
                     int32_t nrhs);
 int bsp_solve_lt_f32(bsp_solver* s, const float* dev_mat, float* dev_vec, int64_t stride,
                      int32_t nrhs);
+/* Solver::solve<std::vector<T*>> etc. (Solver.h:64-73 with the batch types of MatOps.h:38-42):
+   `batch` factored matrices of the same structure and one block of right-hand sides each
+   (host arrays of device pointers).  which: 0 = solve, 1 = solveL, 2 = solveLt */
+int bsp_solve_batched_f64(bsp_solver* s, const double* const* dev_mats, double* const* dev_vecs,
+                          int32_t batch, int64_t stride, int32_t nrhs, int32_t which);
+int bsp_solve_batched_f32(bsp_solver* s, const float* const* dev_mats, float* const* dev_vecs,
+                          int32_t batch, int64_t stride, int32_t nrhs, int32_t which);
 
 /* ---- measurement helpers (no reference counterpart; Solver::printStats is the analogue) */
 /* algorithmic flops of a full factor: sum over lumps n^3/3 + r n^2 + r^2 n */

@@ -70,6 +70,32 @@ def test_solve_many(dtype, model):
             assert np.linalg.norm(X - ref.reshape(nrhs, n).T) < 1e-10
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_batched_solve(dtype):
+    """Solver::solve<std::vector<T*>>: several factored matrices of one structure, one block of
+    right-hand sides each; must equal the per-matrix solves (also solveL / solveLt)"""
+    sol, _, _ = solver_random(71, fill=0.03, elim=(0, 60), ranges=[0, 60])
+    n, nrhs, batch = sol.order(), 3, 4
+    mats, rhs = [], []
+    for q in range(batch):
+        data = spd_data(sol, 20 + q, dtype=dtype)
+        mats.append(_factor_on_gpu(sol, data))
+        rhs.append(T.random_data(n * nrhs, -1, 1, 90 + q).astype(dtype))
+    for name in ("solve", "solveL", "solveLt"):
+        single = []
+        for q in range(batch):
+            v = to_dev(rhs[q])
+            getattr(sol, name)(mats[q], v, n, nrhs)
+            single.append(v.cpu().numpy())
+        vecs = [to_dev(r) for r in rhs]
+        getattr(sol, name)(mats, vecs, n, nrhs)
+        for q in range(batch):
+            got = vecs[q].cpu().numpy()
+            # same kernels, same order of operations except for the atomics: equal to rounding
+            assert np.linalg.norm(got - single[q]) <= 1e-12 * (1 if dtype == np.float64 else 1e7) * \
+                max(1.0, np.linalg.norm(single[q])), (name, q)
+
+
 def test_solve_l_then_lt_equals_solve_with_stride():
     """solveL followed by solveLt == solve; leading dimension larger than the order"""
     sol, _, _ = solver_random(63, fill=0.03, elim=(0, 60), ranges=[0, 60])
