@@ -338,6 +338,27 @@ class Solver:
     def solveLt(self, mat, vec, stride=None, nRHS=1):
         self._solve("bsp_solve_lt_", mat, vec, stride, nRHS)
 
+    def _solve_partial(self, which, mat, span_index, vec, stride, nrhs):
+        self._check_data(mat)
+        if stride is None:
+            stride = self.order()
+        _check(getattr(self._lib, "bsp_solve_partial_" + _suffix(mat))(
+            self._h, ctypes.c_void_p(_ptr_of(mat)), ctypes.c_void_p(_ptr_of(vec)),
+            ctypes.c_int64(stride), ctypes.c_int32(nrhs), ctypes.c_int32(which),
+            ctypes.c_int64(span_index)))
+
+    def solveLUpTo(self, mat, span_index, vec, stride=None, nRHS=1):
+        self._solve_partial(0, mat, span_index, vec, stride, nRHS)
+
+    def solveLtUpTo(self, mat, span_index, vec, stride=None, nRHS=1):
+        self._solve_partial(1, mat, span_index, vec, stride, nRHS)
+
+    def solveLFrom(self, mat, span_index, vec, stride=None, nRHS=1):
+        self._solve_partial(2, mat, span_index, vec, stride, nRHS)
+
+    def solveLtFrom(self, mat, span_index, vec, stride=None, nRHS=1):
+        self._solve_partial(3, mat, span_index, vec, stride, nRHS)
+
     # ---- measurement --------------------------------------------------------------------
     def factorFlops(self):
         return float(self._lib.bsp_factor_flops(self._h))

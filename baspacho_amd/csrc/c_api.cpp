@@ -288,6 +288,35 @@ int bsp_solve_lt_f32(bsp_solver* s, const float* m, float* v, int64_t stride, in
   BSP_CATCH
 }
 
+// partial solves: which = 0 solveLUpTo, 1 solveLtUpTo, 2 solveLFrom, 3 solveLtFrom
+template <typename T>
+static void solvePartial(bsp_solver* s, const T* m, T* v, int64_t stride, int32_t nrhs,
+                         int32_t which, int64_t span) {
+  if (which == 0) {
+    s->solver->solveLUpTo(m, span, v, stride, nrhs);
+  } else if (which == 1) {
+    s->solver->solveLtUpTo(m, span, v, stride, nrhs);
+  } else if (which == 2) {
+    s->solver->solveLFrom(m, span, v, stride, nrhs);
+  } else if (which == 3) {
+    s->solver->solveLtFrom(m, span, v, stride, nrhs);
+  } else {
+    throw std::runtime_error("bsp_solve_partial: which must be 0..3");
+  }
+}
+int bsp_solve_partial_f64(bsp_solver* s, const double* m, double* v, int64_t stride, int32_t nrhs,
+                          int32_t which, int64_t span) {
+  BSP_TRY
+  solvePartial<double>(s, m, v, stride, nrhs, which, span);
+  BSP_CATCH
+}
+int bsp_solve_partial_f32(bsp_solver* s, const float* m, float* v, int64_t stride, int32_t nrhs,
+                          int32_t which, int64_t span) {
+  BSP_TRY
+  solvePartial<float>(s, m, v, stride, nrhs, which, span);
+  BSP_CATCH
+}
+
 // batched solve: which = 0 solve, 1 solveL, 2 solveLt
 template <typename T>
 static void solveBatched(bsp_solver* s, const T* const* mats, T* const* vecs, int32_t batch,

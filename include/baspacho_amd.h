@@ -149,6 +149,12 @@ int bsp_solve_l_f32(bsp_solver* s, const float* dev_mat, float* dev_vec, int64_t
                     int32_t nrhs);
 int bsp_solve_lt_f32(bsp_solver* s, const float* dev_mat, float* dev_vec, int64_t stride,
                      int32_t nrhs);
+/* Solver::solveLUpTo / solveLtUpTo / solveLFrom / solveLtFrom  Solver.h:79-108 (span_index must
+   be a lump boundary).  which: 0 = LUpTo, 1 = LtUpTo, 2 = LFrom, 3 = LtFrom */
+int bsp_solve_partial_f64(bsp_solver* s, const double* dev_mat, double* dev_vec, int64_t stride,
+                          int32_t nrhs, int32_t which, int64_t span_index);
+int bsp_solve_partial_f32(bsp_solver* s, const float* dev_mat, float* dev_vec, int64_t stride,
+                          int32_t nrhs, int32_t which, int64_t span_index);
 /* Solver::solve<std::vector<T*>> etc. (Solver.h:64-73 with the batch types of MatOps.h:38-42):
    `batch` factored matrices of the same structure and one block of right-hand sides each
    (host arrays of device pointers).  which: 0 = solve, 1 = solveL, 2 = solveLt */

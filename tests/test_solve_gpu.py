@@ -96,6 +96,62 @@ def test_batched_solve(dtype):
                 max(1.0, np.linalg.norm(single[q])), (name, q)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_partial_solves(dtype):
+    """PartialFactorSolveTest.cpp:157-262: solveLUpTo / solveLtUpTo at a lump boundary, with `data`
+    taken as the factor itself (diagonal damped to 3) exactly as the reference's test does; plus
+    solveLFrom / solveLtFrom on the trailing block"""
+    for i in range(6):
+        sol, _, _ = solver_random(57 + i, size=215, fill=0.03, elim=(0, 150), psize_seed=47,
+                                  pmin=2, pmax=3)
+        sk = sol.skel()
+        ranges = sol.sparseEliminationRanges()
+        dense_from = int(ranges[-1]) if len(ranges) else 0
+        lump = dense_from + (7 * i) % max(1, sol.numLumps() - dense_from)
+        span = int(sk["lumpToSpan"][lump])
+        n, nrhs = sol.order(), 3
+        bar = int(sk["spanStart"][span])
+        data = T.random_data(sol.dataSize(), -1.0, 1.0, 9 + i).astype(dtype)
+        sol.damp(data, dtype(0), dtype(3.0))
+        Lm = lower_of(sol, data)
+        d = to_dev(data)
+        tol = 1e-9 if dtype == np.float64 else 2e-5
+        for j in range(3):
+            rhs = T.random_data(n * nrhs, -1.0, 1.0, 49 + j + i)
+            V = rhs.reshape(nrhs, n).T
+
+            def run(name, *args):
+                v = to_dev(rhs.astype(dtype))
+                getattr(sol, name)(d, *args, v, n, nrhs)
+                return v.cpu().numpy().astype(np.float64).reshape(nrhs, n).T
+
+            ref = V.copy()
+            if bar:
+                ref[:bar] = np.linalg.solve(Lm[:bar, :bar], V[:bar])
+                ref[bar:] -= Lm[bar:, :bar] @ ref[:bar]
+            got = run("solveLUpTo", span)
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, ("LUpTo", i, j)
+
+            ref = V.copy()
+            if bar:
+                ref[:bar] -= Lm[bar:, :bar].T @ ref[bar:]
+                ref[:bar] = np.linalg.solve(Lm[:bar, :bar].T, ref[:bar])
+            got = run("solveLtUpTo", span)
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, ("LtUpTo", i, j)
+
+            ref = V.copy()
+            if bar < n:
+                ref[bar:] = np.linalg.solve(Lm[bar:, bar:], V[bar:])
+            got = run("solveLFrom", span)
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, ("LFrom", i, j)
+
+            ref = V.copy()
+            if bar < n:
+                ref[bar:] = np.linalg.solve(Lm[bar:, bar:].T, V[bar:])
+            got = run("solveLtFrom", span)
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, ("LtFrom", i, j)
+
+
 def test_solve_l_then_lt_equals_solve_with_stride():
     """solveL followed by solveLt == solve; leading dimension larger than the order"""
     sol, _, _ = solver_random(63, fill=0.03, elim=(0, 60), ranges=[0, 60])
