@@ -61,7 +61,7 @@ struct DevBuf {
 struct DevPlan {
   HipPlanHost host;
   DevBuf panels, srcs, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
-      updTasks, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal;
+      updTasks, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc;
   // forward-solve gather lists, built on the first solve that needs them
   bool solveGatherReady = false;
   SolveGatherPlan solveGather;
@@ -87,6 +87,7 @@ struct DevPlan {
     trsmTasks.upload(host.trsmTasks);
     updTasks.upload(host.updTasks);
     elimChainLump.upload(host.elimChainLump);
+    elimLumpDesc.upload(host.elimLumpDesc);
     elimItems.upload(host.elimItems);
     elimPairOffJ.upload(host.elimPairOffJ);
     elimPairOffI.upload(host.elimPairOffI);
@@ -138,6 +139,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_NO_CRIT_STREAM")) critEnabled = e[0] == '0';
     if (const char* e = std::getenv("BSP_BULK_EXTRA_LDS")) bulkExtraLds = (unsigned)atoi(e);
     if (const char* e = std::getenv("BSP_FUSE_POTRF")) fusePotrf = e[0] != '0';
+    if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
     if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
   }
 
@@ -289,6 +291,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool critEnabled = false;  // measured: no gain from stream priorities on MI355X
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
   hipStream_t side = nullptr, crit = nullptr;
+  bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
   bool fusePotrf = true;    // next panel's potrf inside the update launch (BSP_FUSE_POTRF=0 disables)
   bool directChain = true;  // descriptor-by-value kernels on one-panel levels (BSP_DIRECT_CHAIN=0 disables)
   vector<hipEvent_t> events;
@@ -448,7 +451,10 @@ struct HipNumericCtx : NumericCtx<T> {
     if (nLumps <= 0) return;
     const unsigned gF = (unsigned)((nLumps + 3) / 4);
     timer.begin(kProfElimFactor);
-    if (er.maxWidth <= 4) {
+    if (er.maxWidth <= 4 && sym.elimFactorDesc) {
+      hipk::elimFactorTiny<BT><<<dim3(gF, gy), 256, 0, sym.stream>>>(
+          plan.elimLumpDesc.as<ElimLumpDesc>() + er.descBegin, ref, (int)nLumps);
+    } else if (er.maxWidth <= 4) {
       hipk::elimFactorSmall<BT, 4><<<dim3(gF, gy), 256, 0, sym.stream>>>(sk, ref, er.lumpBegin,
                                                                         er.lumpEnd);
     } else if (er.maxWidth <= 8) {

@@ -146,6 +146,86 @@ __global__ __launch_bounds__(256) void elimFactorSmall(SkelDev sk, DataRef<T> dr
   }
 }
 
+// K1t  the same for lumps of width <= 4 (the 3-wide point columns of bundle adjustment), driven by
+// ElimLumpDesc: one descriptor load, then the diagonal block (every lane reads all of it) and the
+// lane's row in flight together; the n x n Cholesky runs redundantly in every lane's registers
+// (hardware rsq + Newton, no LDS, no wave synchronisation, no division).  K1 spends ~7 dependent
+// memory round trips per wave and is latency bound at 2 TB/s.
+template <typename T>
+__global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs, DataRef<T> dref,
+                                                      int numLumps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + wave;
+  if (idx >= numLumps) return;
+  const ElimLumpDesc ld = descs[idx];
+  const int n = ld.n;
+  if (n > 4) return;  // (the caller checks the range's maximum width)
+  T* D = pickData(dref) + ld.diagOff;
+  T* B = D + n * n;
+  // diagonal block (lower part), padded with the identity
+  T a[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      const T v = D[min(i, n - 1) * n + min(j, n - 1)];
+      a[i][j] = (i < n && j < n) ? v : (i == j ? T(1) : T(0));
+    }
+  }
+  // first pass of rows of this lane
+  T x[4];
+  const bool has = lane < ld.rowsBelow;
+  {
+    const T* row = B + (int64_t)(has ? lane : 0) * n;
+#pragma unroll
+    for (int j = 0; j < 4; j++) x[j] = row[min(j, n - 1)];
+  }
+  // Cholesky in registers: l[i][j], inv[j] = 1 / l[j][j]
+  T inv[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    T d = a[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= a[j][k] * a[j][k];
+    inv[j] = fastRsqrt(d);
+    a[j][j] = d * inv[j];
+#pragma unroll
+    for (int i = j + 1; i < 4; i++) {
+      T s = a[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= a[i][k] * a[j][k];
+      a[i][j] = s * inv[j];
+    }
+  }
+  // write the factor of the diagonal block: lane e holds entry e = i * n + j
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      if (i < n && lane == i * n + j) D[i * n + j] = a[i][j];
+    }
+  }
+  // rows below: x * L^T = b
+  for (int r = lane; r < ld.rowsBelow; r += 64) {
+    T* row = B + (int64_t)r * n;
+    if (r != lane) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) x[j] = row[min(j, n - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      T s = x[j];
+#pragma unroll
+      for (int i = 0; i < j; i++) s -= x[i] * a[j][i];
+      x[j] = s * inv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (j < n) row[j] = x[j];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K2  sparse-elimination update: for column l and every pair of below-diagonal chains i<=j:
 //     target(sj,si) -= L(sj,l) * L(si,l)^T.

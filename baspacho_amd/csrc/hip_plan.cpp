@@ -375,10 +375,12 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     er.chainEnd = sk.chainColPtr[re];
     er.chainLumpOff = (int64_t)plan.elimChainLump.size();
     er.maxWidth = 0;
+    er.descBegin = (int64_t)plan.elimLumpDesc.size();
     vector<vector<PanelBuild>> big;
     for (int64_t l = rb; l < re; l++) {
       LumpCols g = lumpCols(sk, l);
       er.maxWidth = std::max<int32_t>(er.maxWidth, (int32_t)g.width);
+      plan.elimLumpDesc.push_back({g.diagOff, (int32_t)g.width, (int32_t)g.rowsBelow});
       for (int64_t c = 0; c < g.nChains; c++) plan.elimChainLump.push_back((int32_t)l);
       {
         // pair updates of this column: for chains i<=j below the diagonal, |sj| x |si| elements

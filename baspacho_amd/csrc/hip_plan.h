@@ -126,11 +126,21 @@ constexpr uint32_t kGatherChunkElems = 0xffffffffu;  // optional slicing of the 
                                                      // BAL-871 (more items + atomics), so disabled
 
 // one sparse-elimination range restricted to the planned lump range
+// One eliminated lump as the small-lump factor kernel wants it: everything behind one 16-byte load
+// instead of a chain of dependent skeleton lookups (the column is one dense (n + rows) x n block:
+// rows start right after the n x n diagonal block).
+struct ElimLumpDesc {
+  int64_t diagOff;
+  int32_t n;
+  int32_t rowsBelow;
+};
+
 struct ElimRangePlan {
   int64_t lumpBegin, lumpEnd;
   int64_t chainBegin, chainEnd;  // absolute chain indices covered by the range
   int64_t chainLumpOff;          // offset into elimChainLump of chain `chainBegin`
   int32_t maxWidth;              // widest lump of the range
+  int64_t descBegin = 0;         // offset into elimLumpDesc of lump `lumpBegin`
   std::vector<LevelRange> bigLevels;  // lumps wider than kElimSmallMax go through panels
   bool useGather = false;             // pair updates in gather form (atomic-free) ...
   int64_t itemBegin = 0, itemEnd = 0; // ... over these ElimGatherItems (one wave per item)
@@ -143,6 +153,7 @@ struct HipPlanHost {
   int64_t startLump = 0, upToLump = 0;
   std::vector<ElimRangePlan> elimRanges;
   std::vector<int32_t> elimChainLump;  // lump of every chain inside elimination ranges
+  std::vector<ElimLumpDesc> elimLumpDesc;  // every lump of every elimination range
   std::vector<ElimGatherItem> elimItems;
   std::vector<uint32_t> elimPairOffJ, elimPairOffI;
 
