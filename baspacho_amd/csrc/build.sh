@@ -4,7 +4,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libbaspacho_amd.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -munsafe-fp-atomics ${BSP_KTRACE:+-DBSP_KTRACE=1}"
+FLAGS="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -munsafe-fp-atomics ${BSP_KTRACE:+-DBSP_KTRACE=1} ${BSP_EXTRA_DEFS:-}"
 SRCS="bsp_utils.cpp sparse_structure.cpp min_degree.cpp computation_model.cpp elimination_tree.cpp skeleton.cpp solver.cpp hip_plan.cpp c_api.cpp"
 mkdir -p ../_build
 OBJS=""

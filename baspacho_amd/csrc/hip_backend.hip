@@ -61,7 +61,8 @@ struct DevBuf {
 struct DevPlan {
   HipPlanHost host;
   DevBuf panels, srcs, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
-      updTasks, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc;
+      updTasks, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc,
+      elimPairSlot, elimRows, elimRowSlots;
   // forward-solve gather lists, built on the first solve that needs them
   bool solveGatherReady = false;
   SolveGatherPlan solveGather;
@@ -88,6 +89,9 @@ struct DevPlan {
     updTasks.upload(host.updTasks);
     elimChainLump.upload(host.elimChainLump);
     elimLumpDesc.upload(host.elimLumpDesc);
+    elimPairSlot.upload(host.elimPairSlot);
+    elimRows.upload(host.elimRows);
+    elimRowSlots.upload(host.elimRowSlots);
     elimItems.upload(host.elimItems);
     elimPairOffJ.upload(host.elimPairOffJ);
     elimPairOffI.upload(host.elimPairOffI);
@@ -467,7 +471,22 @@ struct HipNumericCtx : NumericCtx<T> {
     timer.end();
     launchLevels(plan, er.bigLevels, ref, timer);
     const int64_t nChains = er.chainEnd - er.chainBegin;
-    if (er.useGather) {
+    if (er.useRowForm) {
+      const int64_t nRows = er.rowEnd - er.rowBegin;
+      const int ldsBytes = sizeof(BT) == 8 ? er.rowLdsBytes : er.rowLdsBytesF32;
+      static bool attrSet = false;  // (per instantiation: BT is part of the enclosing class)
+      if (!attrSet) {
+        hipCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hipk::elimRowMfma<BT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attrSet = true;
+      }
+      timer.begin(kProfElimUpdate);
+      hipk::elimRowMfma<BT><<<dim3((unsigned)nRows, gy), 1024, (size_t)ldsBytes, sym.stream>>>(
+          plan.elimRows.as<ElimRowItem>() + er.rowBegin, plan.elimRowSlots.as<ElimRowSlot>(),
+          plan.elimPairOffJ.as<uint32_t>(), plan.elimPairOffI.as<uint32_t>(),
+          plan.elimPairSlot.as<uint16_t>(), ref, (uint32_t)(sym.skel.dataSize() - 1));
+      timer.end();
+    } else if (er.useGather) {
       const int64_t nItems = er.itemEnd - er.itemBegin;
       if (nItems > 0) {
         timer.begin(kProfElimUpdate);

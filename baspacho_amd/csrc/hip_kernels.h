@@ -512,6 +512,144 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
   }
 }
 
+// K2r  ROW FORM of the sparse-elimination update.  K2m fetches both source blocks of every pair
+// from wherever they lie (7 GB of L2 misses for 0.64 GB of distinct source data on BAL-871: the
+// waves of one row of targets drift apart, nothing is reused in L2).  Here one workgroup (16
+// waves) owns one ROW of targets (sj, *): its pairs are ordered by source column, so the blocks
+// B_i a column contributes are the contiguous head of that column and B_j is its next block;
+// every pair is one v_mfma 16x16x4 into a fresh accumulator whose valid entries are added to the
+// target's slot in LDS (ds_add_f64); when the row is done the slots are subtracted from memory,
+// once, without atomics (a row belongs to one workgroup).
+template <typename T>
+__global__ __launch_bounds__(1024) void elimRowMfma(const ElimRowItem* rowItems,
+                                                    const ElimRowSlot* slots, const uint32_t* offJ,
+                                                    const uint32_t* offI, const uint16_t* slotIdx,
+                                                    DataRef<T> dref, uint32_t lastElem) {
+  extern __shared__ __align__(16) unsigned char ldsRaw[];
+  constexpr int U = 8, WAVES = 16;
+  const ElimRowItem it = rowItems[blockIdx.x];
+  T* acc = reinterpret_cast<T*>(ldsRaw);
+  const int nSlots = it.slotEnd - it.slotBegin;
+  ElimRowSlot* tab = reinterpret_cast<ElimRowSlot*>(acc + ((it.ldsElems + 3) & ~3));
+  const int tid = threadIdx.x;
+  for (int e = tid; e < it.ldsElems; e += 1024) acc[e] = T(0);
+  for (int s = tid; s < nSlots; s += 1024) tab[s] = slots[it.slotBegin + s];
+  __syncthreads();
+  T* data = pickData(dref);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int rows = it.rows, n = it.n;
+  using Acc = typename Mfma<T>::Acc;
+  // add the valid entries of one pair's product to its slot
+  auto deposit = [&](const Acc& prod, int s) {
+    const int cols = tab[s].cols, ldsOff = tab[s].ldsOff;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int r = Mfma<T>::row(lane, g);
+      if (r < rows && li < cols) unsafeAtomicAdd(&acc[ldsOff + r * cols + li], prod[g]);
+    }
+  };
+  if (n <= 4) {
+    // one MFMA per pair; operand loads of the NEXT group of 8 pairs are in flight while the
+    // current group is multiplied and deposited, the offsets of the next 64 pairs are fetched
+    // one batch ahead
+    const bool okA = li < rows && lk < n, okK = lk < n;
+    const uint32_t eA = okA ? (uint32_t)(li * n + lk) : 0u;
+    const uint32_t eB = (uint32_t)(li * n + min(lk, n - 1));
+    int base = it.pairBegin + 64 * wave;
+    uint32_t nxJ = 0, nxI = 0;
+    int nxS = 0;
+    auto fetchMeta = [&](int b0) {
+      const int c = min(64, it.pairEnd - b0);
+      nxJ = (b0 < it.pairEnd && lane < c) ? offJ[b0 + lane] : 0u;
+      nxI = (b0 < it.pairEnd && lane < c) ? offI[b0 + lane] : 0u;
+      nxS = (b0 < it.pairEnd && lane < c) ? (int)slotIdx[b0 + lane] : 0;
+    };
+    fetchMeta(base);
+    for (; base < it.pairEnd; base += 64 * WAVES) {
+      const int cnt = min(64, it.pairEnd - base);
+      const uint32_t myJ = nxJ, myI = nxI;
+      const int myS = nxS;
+      fetchMeta(base + 64 * WAVES);
+      T a0[U], b0[U], a1[U], b1[U];
+      auto issue = [&](int t0, T* a, T* b) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int t = min(t0 + u, cnt - 1);
+          const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)myJ, t);
+          const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)myI, t);
+          a[u] = data[oj + eA];
+          b[u] = data[min(oi + eB, lastElem)];
+        }
+      };
+      auto consume = [&](int t0, const T* a, const T* b) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (t0 + u < cnt) {  // wave-uniform
+            const int s = __builtin_amdgcn_readlane(myS, t0 + u);
+            const int cols = tab[s].cols;
+            const Acc prod = Mfma<T>::run(okA ? a[u] : T(0), (okK && li < cols) ? b[u] : T(0),
+                                          Acc{0, 0, 0, 0});
+            deposit(prod, s);
+          }
+        }
+      };
+      issue(0, a0, b0);
+      for (int t0 = 0; t0 < cnt; t0 += 2 * U) {
+        if (t0 + U < cnt) issue(t0 + U, a1, b1);
+        consume(t0, a0, b0);
+        if (t0 + 2 * U < cnt) issue(t0 + 2 * U, a0, b0);
+        if (t0 + U < cnt) consume(t0 + U, a1, b1);
+      }
+    }
+  } else {
+    for (int base = it.pairBegin + 64 * wave; base < it.pairEnd; base += 64 * WAVES) {
+      const int cnt = min(64, it.pairEnd - base);
+      const uint32_t myJ = lane < cnt ? offJ[base + lane] : 0u;
+      const uint32_t myI = lane < cnt ? offI[base + lane] : 0u;
+      const int myS = lane < cnt ? (int)slotIdx[base + lane] : 0;
+      for (int t = 0; t < cnt; t++) {
+        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)myJ, t);
+        const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)myI, t);
+        const int s = __builtin_amdgcn_readlane(myS, t);
+        const int cols = tab[s].cols;
+        Acc prod = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < n; k0 += 4) {
+          const int k = k0 + lk;
+          const bool okA = li < rows && k < n, okB = li < cols && k < n;
+          const T a = okA ? data[oj + (uint32_t)(li * n + k)] : T(0);
+          const T b = okB ? data[oi + (uint32_t)(li * n + k)] : T(0);
+          prod = Mfma<T>::run(a, b, prod);
+        }
+        deposit(prod, s);
+      }
+    }
+  }
+  __syncthreads();
+  // subtract the row's accumulators from the targets
+  for (int e = tid; e < it.ldsElems; e += 1024) {
+    int lo = 0, hi = nSlots;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tab[mid].ldsOff <= e) {
+        lo = mid;
+      } else {
+        hi = mid;
+      }
+    }
+    const ElimRowSlot sd = tab[lo];
+    const int e2 = e - sd.ldsOff, r = e2 / sd.cols, c = e2 - r * sd.cols;
+    if (!((sd.flags & 2) && c > r)) {
+      T* p = data + sd.tgtOff + (int64_t)r * sd.tgtStride + c;
+      if (it.shared) {
+        atomicSub(p, acc[e]);
+      } else {
+        *p -= acc[e];
+      }
+    }
+  }
+}
+
 // K2t  the same gather for TINY target blocks (<= 16 elements, e.g. the 3x3 blocks of automatically
 // detected elimination ranges): four items per wave, 16 lanes each, operands straight from
 // global memory (a pair's blocks are a few dozen bytes).

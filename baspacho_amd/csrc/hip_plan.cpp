@@ -98,6 +98,150 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
     });
   }
   lap("bucket by target chain");
+  // ---- ROW FORM (opt-in, BSP_GATHER_ROW_FORM=1; every block must fit a 16x16 MFMA tile): one
+  //      workgroup per row of targets, pairs ordered by source column.  Measured on BAL-871:
+  //      2.2 ms against 1.76 ms for the item form below -- it fetches 21 % fewer bytes (5.5 GB
+  //      instead of 7.0 GB) but back-to-back loads of neighbouring blocks each miss on the cache
+  //      line they share, and 16 waves per CU (LDS is full of accumulators) hide less latency
+  //      than the 32 of the item form.
+  const bool rowFormEnabled = [] {
+    const char* e = std::getenv("BSP_GATHER_ROW_FORM");
+    return e && e[0] == '1';
+  }();
+  if (rowFormEnabled) {
+    bool ok = true;
+    vector<ElimRowItem> rowItems;
+    vector<ElimRowSlot> rowSlots;
+    vector<uint32_t> oj, oi;
+    vector<uint16_t> sl;
+    oj.reserve((size_t)nPairs);
+    oi.reserve((size_t)nPairs);
+    sl.reserve((size_t)nPairs);
+    double targetElems = 0;
+    int32_t maxLds = 0, maxSlots = 0;
+    vector<int32_t> sis;
+    for (int64_t c = 0; c < nChainsTot && ok; c++) {
+      const int64_t b = bucketPtr[c], e = bucketPtr[c + 1];
+      if (b == e) continue;
+      const int64_t sj = sk.chainRowSpan[c];
+      const int64_t rows = sk.spanStart[sj + 1] - sk.spanStart[sj];
+      const int32_t width = sorted[b].width;
+      if (rows > 16 || width > 16) {
+        ok = false;
+        break;
+      }
+      std::sort(sorted.begin() + b, sorted.begin() + e, [](const Pair& x, const Pair& y) {
+        return x.offJ != y.offJ ? x.offJ < y.offJ : x.si < y.si;
+      });
+      sis.clear();
+      for (int64_t k = b; k < e; k++) sis.push_back(sorted[k].si);
+      std::sort(sis.begin(), sis.end());
+      sis.erase(std::unique(sis.begin(), sis.end()), sis.end());
+      if (sis.size() > 60000) ok = false;
+      // a row whose accumulators do not fit LDS is cut into parts by target column (disjoint
+      // targets, each part with the pairs of its own targets only)
+      vector<int32_t> partOfSlot(sis.size()), slotInPart(sis.size());
+      vector<int32_t> partFirstSlot;  // index into sis of every part's first slot
+      {
+        int32_t used = 0;
+        for (size_t q = 0; q < sis.size(); q++) {
+          const int64_t cols = sk.spanStart[sis[q] + 1] - sk.spanStart[sis[q]];
+          if (cols > 16) ok = false;
+          const int32_t need = (int32_t)(rows * cols);
+          if (partFirstSlot.empty() || used + need > kRowFormMaxLdsElems) {
+            partFirstSlot.push_back((int32_t)q);
+            used = 0;
+          }
+          partOfSlot[q] = (int32_t)partFirstSlot.size() - 1;
+          slotInPart[q] = (int32_t)q - partFirstSlot.back();
+          used += need;
+        }
+      }
+      const size_t nParts = partFirstSlot.size();
+      vector<vector<int64_t>> partPairs(nParts);
+      for (int64_t k = b; k < e && ok; k++) {
+        if (sorted[k].width != width) ok = false;
+        const size_t q = std::lower_bound(sis.begin(), sis.end(), sorted[k].si) - sis.begin();
+        partPairs[partOfSlot[q]].push_back(k);
+      }
+      for (size_t part = 0; part < nParts && ok; part++) {
+        const size_t q0 = partFirstSlot[part];
+        const size_t q1 = part + 1 < nParts ? (size_t)partFirstSlot[part + 1] : sis.size();
+        ElimRowItem it{};
+        it.pairBegin = (int32_t)(plan.elimPairOffJ.size() + oj.size());
+        it.slotBegin = (int32_t)(plan.elimRowSlots.size() + rowSlots.size());
+        int32_t ldsOff = 0;
+        for (size_t q = q0; q < q1; q++) {
+          const int32_t si = sis[q];
+          const int64_t cols = sk.spanStart[si + 1] - sk.spanStart[si];
+          const int64_t t = sk.spanToLump[si];
+          ElimRowSlot sd{};
+          sd.tgtOff = sk.chainData[c] + sk.spanOffsetInLump[si];
+          sd.tgtStride = (int32_t)(sk.lumpStart[t + 1] - sk.lumpStart[t]);
+          sd.ldsOff = ldsOff;
+          sd.cols = (int16_t)cols;
+          sd.flags = (int16_t)(sj == si ? 2 : 0);
+          rowSlots.push_back(sd);
+          ldsOff += (int32_t)(rows * cols);
+          targetElems += sj == si ? double(rows) * (rows + 1) / 2 : double(rows) * cols;
+        }
+        for (int64_t k : partPairs[part]) {
+          const size_t q = std::lower_bound(sis.begin(), sis.end(), sorted[k].si) - sis.begin();
+          oj.push_back(sorted[k].offJ);
+          oi.push_back(sorted[k].offI);
+          sl.push_back((uint16_t)slotInPart[q]);
+        }
+        it.pairEnd = (int32_t)(plan.elimPairOffJ.size() + oj.size());
+        it.slotEnd = (int32_t)(plan.elimRowSlots.size() + rowSlots.size());
+        it.ldsElems = ldsOff;
+        it.rows = (int16_t)rows;
+        it.n = (int16_t)width;
+        // long rows are cut by source-column range so that no workgroup runs much longer than
+        // the others (the longest row of BAL-871 holds 1.5x the per-CU average of the pairs)
+        const int32_t nPairsIt = it.pairEnd - it.pairBegin;
+        const int32_t cuts = (nPairsIt + kRowFormMaxPairs - 1) / kRowFormMaxPairs;
+        if (cuts > 1) {
+          const int32_t first = it.pairBegin;
+          for (int32_t q = 0; q < cuts; q++) {
+            ElimRowItem piece = it;
+            piece.pairBegin = first + (int32_t)((int64_t)nPairsIt * q / cuts);
+            piece.pairEnd = first + (int32_t)((int64_t)nPairsIt * (q + 1) / cuts);
+            piece.shared = 1;
+            rowItems.push_back(piece);
+          }
+        } else {
+          rowItems.push_back(it);
+        }
+        maxLds = std::max(maxLds, ldsOff);
+        maxSlots = std::max(maxSlots, (int32_t)(q1 - q0));
+      }
+    }
+    if (ok) {
+      // longest rows first: with one workgroup per CU the tail of the launch is the last rows
+      std::stable_sort(rowItems.begin(), rowItems.end(), [](const ElimRowItem& x, const ElimRowItem& y) {
+        return x.pairEnd - x.pairBegin > y.pairEnd - y.pairBegin;
+      });
+      // slotIdx stream is padded to the pair streams (they are shared with the item form)
+      plan.elimPairSlot.resize(plan.elimPairOffJ.size(), 0);
+      plan.elimPairOffJ.insert(plan.elimPairOffJ.end(), oj.begin(), oj.end());
+      plan.elimPairOffI.insert(plan.elimPairOffI.end(), oi.begin(), oi.end());
+      plan.elimPairSlot.insert(plan.elimPairSlot.end(), sl.begin(), sl.end());
+      er.rowBegin = (int64_t)plan.elimRows.size();
+      plan.elimRows.insert(plan.elimRows.end(), rowItems.begin(), rowItems.end());
+      er.rowEnd = (int64_t)plan.elimRows.size();
+      plan.elimRowSlots.insert(plan.elimRowSlots.end(), rowSlots.begin(), rowSlots.end());
+      const int32_t accElems = (maxLds + 3) & ~3;
+      er.rowLdsBytes = accElems * 8 + maxSlots * (int32_t)sizeof(ElimRowSlot);
+      er.rowLdsBytesF32 = accElems * 4 + maxSlots * (int32_t)sizeof(ElimRowSlot);
+      er.useRowForm = true;
+      er.useGather = true;
+      er.itemBegin = er.itemEnd = er.tinyBegin = er.tinyEnd = er.ldsBegin = er.ldsEnd =
+          (int64_t)plan.elimItems.size();
+      plan.elimTargetElems += targetElems;
+      lap("row form");
+      return;
+    }
+  }
   plan.elimPairOffJ.reserve(plan.elimPairOffJ.size() + (size_t)nPairs);
   plan.elimPairOffI.reserve(plan.elimPairOffI.size() + (size_t)nPairs);
   er.itemBegin = (int64_t)plan.elimItems.size();

@@ -126,6 +126,30 @@ constexpr uint32_t kGatherChunkElems = 0xffffffffu;  // optional slicing of the 
                                                      // BAL-871 (more items + atomics), so disabled
 
 // one sparse-elimination range restricted to the planned lump range
+// ROW FORM of the sparse-elimination update (K2r, hip_kernels.h): one workgroup per ROW of target
+// blocks (all targets (sj, *) of one row span sj).  Its pairs are ordered by source column, then by
+// target column, so that for one source column the blocks B_i it needs are the contiguous head of
+// that column; every target of the row has an accumulator slot in LDS.
+struct ElimRowItem {
+  int32_t pairBegin, pairEnd;  // into elimPairOffJ / elimPairOffI / elimPairSlot
+  int32_t slotBegin, slotEnd;  // into elimRowSlots
+  int32_t ldsElems;            // accumulator values of the row (sum of rows x cols of its slots)
+  int16_t rows, n;             // |sj|, width of the source lumps
+  int32_t shared;              // 1: the row is cut into several items (by source column range)
+                               // that share its targets: subtract with atomics
+};
+constexpr int kRowFormMaxPairs = 12288;  // pairs per item: bounds the longest workgroup
+struct ElimRowSlot {
+  int64_t tgtOff;     // data offset of the target block
+  int32_t tgtStride;  // row stride of the target lump
+  int32_t ldsOff;     // first accumulator value of the slot
+  int16_t cols;       // |si|
+  int16_t flags;      // bit1: diagonal block (lower triangle only)
+  int32_t pad;
+};
+constexpr int kRowFormMaxLdsElems = 18432;  // 144 KB of fp64 accumulators per workgroup; rows with
+                                            // more are cut into parts by target column
+
 // One eliminated lump as the small-lump factor kernel wants it: everything behind one 16-byte load
 // instead of a chain of dependent skeleton lookups (the column is one dense (n + rows) x n block:
 // rows start right after the n x n diagonal block).
@@ -145,6 +169,9 @@ struct ElimRangePlan {
   bool useGather = false;             // pair updates in gather form (atomic-free) ...
   int64_t itemBegin = 0, itemEnd = 0; // ... over these ElimGatherItems (one wave per item)
   int64_t tinyBegin = 0, tinyEnd = 0; // items with <= 16 target elements: 4 items per wave
+  bool useRowForm = false;            // pair updates in row form instead ...
+  int64_t rowBegin = 0, rowEnd = 0;   // ... over these ElimRowItems (one workgroup per row)
+  int32_t rowLdsBytes = 0, rowLdsBytesF32 = 0;  // dynamic LDS of the launch (fp64 / fp32)
   int64_t ldsBegin = 0, ldsEnd = 0;   // items wider or taller than 16: LDS-staged kernel (K2g);
                                       // [itemBegin, itemEnd) go to the MFMA kernel (K2m)
 };
@@ -156,6 +183,9 @@ struct HipPlanHost {
   std::vector<ElimLumpDesc> elimLumpDesc;  // every lump of every elimination range
   std::vector<ElimGatherItem> elimItems;
   std::vector<uint32_t> elimPairOffJ, elimPairOffI;
+  std::vector<uint16_t> elimPairSlot;  // row form: accumulator slot of every pair
+  std::vector<ElimRowItem> elimRows;
+  std::vector<ElimRowSlot> elimRowSlots;
 
   std::vector<PanelDesc> panels;
   std::vector<SrcDesc> srcs;

@@ -215,6 +215,22 @@ def test_bal_like_and_grid_against_oracle():
     assert np.linalg.norm(Lg - L) < 1e-8
 
 
+def test_row_form_elimination(monkeypatch):
+    """the opt-in row form of the sparse-elimination update (one workgroup per row of targets, LDS
+    accumulators) must give the same factor as the oracle, fp64 and fp32"""
+    monkeypatch.setenv("BSP_GATHER_ROW_FORM", "1")
+    sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=50, num_pts=5000, band=8, seed=9)
+    sol = B.create_solver(B.Settings(), sizes, ss, [0, 5000])
+    data = spd_data(sol, 13, beta_factor=1.2)
+    ref = data.copy()
+    cref.factor(sol.skel(), ref, sol.sparseEliminationRanges())
+    mask = sol.lowerMask()
+    got = _gpu_factor(sol, data)
+    assert np.linalg.norm((got - ref)[mask]) / np.linalg.norm(ref[mask]) < 1e-12
+    got32 = _gpu_factor(sol, data.astype(np.float32)).astype(np.float64)
+    assert np.linalg.norm((got32 - ref)[mask]) / np.linalg.norm(ref[mask]) < 5e-5
+
+
 def test_wide_dense_lump_residual():
     """one wide supernode (multi-panel, intra-lump trailing updates): north-star residual
     ||L L^T - A|| / ||A|| < 1e-10 in fp64"""
