@@ -143,6 +143,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_NO_CRIT_STREAM")) critEnabled = e[0] == '0';
     if (const char* e = std::getenv("BSP_BULK_EXTRA_LDS")) bulkExtraLds = (unsigned)atoi(e);
     if (const char* e = std::getenv("BSP_FUSE_POTRF")) fusePotrf = e[0] != '0';
+    if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
     if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
   }
@@ -296,6 +297,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
   hipStream_t side = nullptr, crit = nullptr;
   bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
+  bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
   bool fusePotrf = true;    // next panel's potrf inside the update launch (BSP_FUSE_POTRF=0 disables)
   bool directChain = true;  // descriptor-by-value kernels on one-panel levels (BSP_DIRECT_CHAIN=0 disables)
   vector<hipEvent_t> events;
@@ -365,9 +367,24 @@ struct HipNumericCtx : NumericCtx<T> {
         }
         timer.end();
       }
+      // (decided before the trsm launch: with splitK one extra workgroup of that launch already
+      //  touches tile 0 of the block-wide segment)
+      const bool fuse = direct && lr.directSeg >= 0 && lr.fuseNext && sym.fusePotrf &&
+                        li + 1 < levels.size() && levels[li + 1].directPanel >= 0 &&
+                        lr.updEnd > lr.updBegin;
+      const int splitK = (fuse && sym.splitDiag && nT) ? lr.splitK : 0;
+      if (splitK && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
+        hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
+      }
       if (nT) {
         timer.begin(kProfTrsm);
-        if (direct) {
+        if (splitK) {
+          const SegDesc& sd = plan.host.segs[lr.directSeg];
+          SrcDesc part = plan.host.srcs[sd.src];
+          part.K = splitK;
+          hipk::trsmPanelDirectPlus<BT><<<dim3(nT + 1, gy.y), 256, 0, sym.stream>>>(
+              plan.host.panels[lr.directPanel], part, sd, ref);
+        } else if (direct) {
           hipk::trsmPanelDirect<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
               plan.host.panels[lr.directPanel], ref);
         } else {
@@ -387,14 +404,12 @@ struct HipNumericCtx : NumericCtx<T> {
       const int64_t updBegin = lr.updBegin;
       if (lr.updEnd > updBegin) {
         timer.begin(direct && lr.directSeg >= 0 ? kProfChainUpdate : kProfUpdate);
-        const bool fuse = direct && lr.directSeg >= 0 && lr.fuseNext && sym.fusePotrf &&
-                          li + 1 < levels.size() && levels[li + 1].directPanel >= 0;
         if (fuse) {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
           hipk::updateTileDirectPotrf<BT><<<dim3((unsigned)(lr.updEnd - updBegin), gy.y), 256, 0,
                                           sym.stream>>>(
               plan.host.srcs[sd.src], sd, (int)(lr.updEnd - updBegin),
-              plan.host.panels[levels[li + 1].directPanel], ref);
+              plan.host.panels[levels[li + 1].directPanel], ref, splitK);
           potrfFused = true;
         } else if (direct && lr.directSeg >= 0) {
           const SegDesc& sd = plan.host.segs[lr.directSeg];

@@ -1373,9 +1373,42 @@ __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, 
 // already in MFMA accumulator layout there) and factors it, while the other workgroups update
 // the remaining tiles -- the potrf (the longest kernel of the chain) overlaps the update instead
 // of following it, with no second stream and no event.
+// trsm launch of the LAST panel of an outer block, plus one workgroup (the last) that applies to
+// tile 0 of the block-wide segment the update by the block's first `part.K` source columns (they
+// are final for the rows of that tile); the potrf workgroup of the following update launch then
+// starts at source column part.K (kStart) instead of summing all 256 columns on its own.
+template <typename T>
+__global__ __launch_bounds__(256) void trsmPanelDirectPlus(PanelDesc pd, SrcDesc part, SegDesc sd,
+                                                           DataRef<T> dref) {
+  constexpr int LDL = kPanelWidth + 1, LD = kUpdChunk + 2;
+  __shared__ T lds[2 * kTile * LD];  // >= 64 x 65 + 64
+  __builtin_amdgcn_s_setprio(3);
+  T* data = pickData(dref);
+  if (blockIdx.x == gridDim.x - 1) {
+    updateTileDirectBody<T>(part, sd, 0, data, lds, lds + kTile * LD);
+    return;
+  }
+  const T* A = data + pd.diagOff;
+  const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
+  T* P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
+  const int rows = min(kTile, pd.rowsBelow - rowTile);
+  T* Ls = lds;
+  T* invDiag = lds + kPanelWidth * LDL;
+  if (nb <= 8) {
+    trsmDirectBody<T, 8>(A, P, lda, nb, rows, Ls, invDiag);
+  } else if (nb <= 16) {
+    trsmDirectBody<T, 16>(A, P, lda, nb, rows, Ls, invDiag);
+  } else if (nb <= 32) {
+    trsmDirectBody<T, 32>(A, P, lda, nb, rows, Ls, invDiag);
+  } else {
+    trsmDirectBody<T, 64>(A, P, lda, nb, rows, Ls, invDiag);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc sd, int nTasks,
-                                                             PanelDesc next, DataRef<T> dref) {
+                                                             PanelDesc next, DataRef<T> dref,
+                                                             int kStart) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
   __shared__ T As[kTile * LD];
   __shared__ T Bs[kTile * LD];
@@ -1388,8 +1421,9 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
   __builtin_amdgcn_s_setprio(3);
   T(*blk)[4] = reinterpret_cast<T(*)[4]>(Bs);
   T(*sol)[4] = blk + 3 * kPanelWidth;
-  const int K = pd.K, lda = pd.lda, nb = next.nb;
-  const T* X = data + pd.off + (int64_t)sd.q0 * lda;  // rows of the next panel, source columns
+  const int K = pd.K - kStart, lda = pd.lda, nb = next.nb;
+  // rows of the next panel, source columns from kStart on
+  const T* X = data + pd.off + (int64_t)sd.q0 * lda + kStart;
   using Acc = typename Mfma<T>::Acc;
   auto pre = [&](Acc* acc) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;

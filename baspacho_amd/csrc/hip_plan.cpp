@@ -732,6 +732,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           if (sd.q0 == 0 && sd.rowMin == 0 && sd.tgtBase == next.diagOff && next.nb == kTile &&
               sd.tgtStride == next.lda && lr.updEnd - lr.updBegin >= 2) {
             lr.fuseNext = 1;
+            const SrcDesc& sr = plan.srcs[sd.src];
+            const int32_t nbLast = plan.panels[bucket[0].panel].nb;
+            if (sd.outer && sr.K > nbLast) lr.splitK = sr.K - nbLast;
           }
         }
       }

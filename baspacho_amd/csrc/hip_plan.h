@@ -103,6 +103,11 @@ struct LevelRange {
   // potrf is fused into this level's update launch (updateTileDirectPotrf); the next level then
   // starts at its trsm
   int32_t fuseNext = 0;
+  // splitK > 0 (block-wide segment, fuseNext): the update of tile 0 by the block's first splitK
+  // source columns (final since the previous levels) is done by one extra workgroup of THIS
+  // level's trsm launch, so that the potrf workgroup of the update launch only applies the
+  // columns of the last panel
+  int32_t splitK = 0;
   int64_t waitDefLevel;          // index (within the same level list) of the level whose deferred
                                  // tiles must be complete before this level's update launch; -1
 };
