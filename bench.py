@@ -192,7 +192,7 @@ def main():
                 "chain_update": ("updateTileDirectPotrf<%s>" % DT, "mfma", st["upd_flops_direct"]),
                 "elim_update": ("elimGatherMfma<%s>" % DT, "hbm",
                                 pair_src_bytes + 16.0 * st["elim_target_elems"]),
-                "elim_factor": ("elimFactorSmall<%s>" % DT, "hbm", 16.0 * st["elim_col_elems"]),
+                "elim_factor": ("elimFactorTiny|elimFactorSmall<%s>" % DT, "hbm", 16.0 * st["elim_col_elems"]),
                 "trsm": ("trsmPanel<%s>" % DT, "mfma", st["trsm_flops"]),
                 "potrf": ("potrfPanel<%s>" % DT, "mfma", st["potrf_flops"]),
             }

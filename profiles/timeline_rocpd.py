@@ -1,11 +1,13 @@
+"""Per-stream timeline of ONE factor() call from a rocprofv3 kernel trace (rocpd sqlite):
+usage: python profiles/timeline_rocpd.py <trace dir> <first kernel> <last kernel>  (0 0 = totals only)"""
 import sqlite3, re, glob, sys
 f=glob.glob(sys.argv[1]+'/*/*.db')[0]
 db=sqlite3.connect(f)
 rows=db.execute("select name,start,end,stream_id,queue_id,grid_x,lds_size from kernels order by start").fetchall()
 def short(n):
     m=re.search(r'hipk::(\w+)',n); return m.group(1) if m else n[:20]
-idx=[i for i,r in enumerate(rows) if 'elimFactorSmall' in r[0]]
-i0=idx[4]; i1=idx[5]
+idx=[i for i,r in enumerate(rows) if 'elimFactor' in r[0]]
+i0=idx[min(4, len(idx)-2)]; i1=idx[min(5, len(idx)-1)]
 t0=rows[i0][1]
 seg=rows[i0:i1]
 print('iteration span ms', (max(r[2] for r in seg)-t0)/1e6)
