@@ -77,3 +77,20 @@ def test_c4_grid_batch_full():
     for q in range(0, 64, 8):
         r = _probe(sol, hosts[q], devs[q].cpu().numpy(), 5 + q)
         assert r < 1e-10, (q, r)
+
+
+def test_c5_bal1723_fp32_refined_full():
+    """C5: BAL-1723-shaped problem (1723 cams, 156 502 pts, ~0.68 M observations; synthetic
+    stand-in), fp32 factor on the device + fp64 iterative refinement to ||r|| / ||b|| < 1e-10"""
+    import torch
+    from baspacho_amd.refine import solve_refined
+    sizes, ss, cam, _ = T.gen_bal_synthetic(num_cams=1723, num_pts=156502, mean_track=4.95, band=24,
+                                            seed=11)
+    assert 0.6e6 < len(cam) < 0.76e6
+    sol = B.create_solver(B.Settings(), sizes, ss, [0, 156502])
+    host = _data(sol, 37)
+    A = torch.from_numpy(host).cuda()
+    b = torch.from_numpy(T.random_data(sol.order(), -1, 1, 4)).cuda()
+    x, iters, hist = solve_refined(sol, A, b, tol=1e-10)
+    assert hist[-1] < 1e-10, hist
+    assert iters <= 8, hist
