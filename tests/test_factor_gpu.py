@@ -231,6 +231,50 @@ def test_row_form_elimination(monkeypatch):
     assert np.linalg.norm((got32 - ref)[mask]) / np.linalg.norm(ref[mask]) < 5e-5
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lump_widths_around_panel_and_block_boundaries(dtype):
+    """explicit skeletons (Solver(skel, ...), Solver.h:37-38): one lump of width W (spans of
+    mixed sizes) followed by rows that belong to two further lumps, for W around the panel (64)
+    and outer-block (256) boundaries -- exercises the direct / fused-potrf / split-update launches
+    and their hand-over to the generic task-list launches (boards of the lump column)"""
+    for W in (1, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 321, 515):
+        # spans: sizes cycle 1,2,3 until the lump holds W columns; then 2 lumps of 40 and 30
+        sizes, tot = [], 0
+        while tot < W:
+            s = min(1 + len(sizes) % 3, W - tot)
+            sizes.append(s)
+            tot += s
+        n0 = len(sizes)
+        tail1 = [3] * 13 + [1]      # 40
+        tail2 = [2] * 15            # 30
+        sizes = sizes + tail1 + tail2
+        span_start = np.concatenate([[0], np.cumsum(sizes)])
+        l2s = [0, n0, n0 + len(tail1), n0 + len(tail1) + len(tail2)]
+        nspans = len(sizes)
+        # lump 0 sees every span of the tail except a few (sparse boards), lumps 1 and 2 are dense
+        rows0 = list(range(n0)) + [q for q in range(n0, nspans) if (q * 7 + W) % 5 != 0]
+        rows1 = list(range(n0, nspans))
+        rows2 = list(range(n0 + len(tail1), nspans))
+        col_ptr = np.cumsum([0, len(rows0), len(rows1), len(rows2)])
+        sol = B.Solver.from_skeleton(span_start, l2s, col_ptr, rows0 + rows1 + rows2)
+        data = spd_data(sol, 100 + W, beta_factor=1.5, dtype=dtype)
+        L, A = dense_lower_chol(sol, data)
+        got = lower_of(sol, _gpu_factor(sol, data))
+        err = np.linalg.norm(got @ got.T - A) / np.linalg.norm(A)
+        assert err < (1e-10 if dtype == np.float64 else 5e-5), (W, err)
+        assert np.linalg.norm(got - L) < EPS[dtype][1] * (1 if dtype == np.float64 else 10), W
+        # and the device solve on the same skeleton (panels narrower than 64, boards)
+        d = to_dev(data)
+        sol.factor(d)
+        n = sol.order()
+        rhs = T.random_data(n * 2, -1, 1, 7 + W)
+        v = to_dev(rhs.astype(dtype))
+        sol.solve(d, v, n, 2)
+        X = v.cpu().numpy().astype(np.float64).reshape(2, n).T
+        want = np.linalg.solve(A, rhs.reshape(2, n).T)
+        assert np.linalg.norm(X - want) / np.linalg.norm(want) < (1e-10 if dtype == np.float64 else 1e-4), W
+
+
 def test_wide_dense_lump_residual():
     """one wide supernode (multi-panel, intra-lump trailing updates): north-star residual
     ||L L^T - A|| / ||A|| < 1e-10 in fp64"""
