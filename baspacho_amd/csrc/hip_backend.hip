@@ -140,7 +140,6 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipSymbolicCtx(const CoalescedBlockMatrixSkel& skel_, const vector<int64_t>& permutation_)
       : skel(skel_), permutation(permutation_) {
     if (const char* e = std::getenv("BSP_NO_LOOKAHEAD")) lookaheadEnabled = e[0] == '0';
-    if (const char* e = std::getenv("BSP_NO_CRIT_STREAM")) critEnabled = e[0] == '0';
     if (const char* e = std::getenv("BSP_BULK_EXTRA_LDS")) bulkExtraLds = (unsigned)atoi(e);
     if (const char* e = std::getenv("BSP_FUSE_POTRF")) fusePotrf = e[0] != '0';
     if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
@@ -151,7 +150,6 @@ struct HipSymbolicCtx : SymbolicCtx {
   virtual ~HipSymbolicCtx() override {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
-    if (crit) (void)hipStreamDestroy(crit);
   }
 
   virtual void setSparseElimRanges(const vector<int64_t>& ranges) override {
@@ -228,53 +226,17 @@ struct HipSymbolicCtx : SymbolicCtx {
   virtual SolveCtxBase* createSolveCtxForType(std::type_index tIdx, int nRHS,
                                               int batchSize) override;
 
-  // side stream + event pool of the lookahead schedule (created on first use)
-  // CU mask with every k-th CU set (invert = false) or cleared (invert = true)
-  static std::vector<uint32_t> everyKthCuMask(int k, bool invert) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    hipCHECK(hipGetDevice(&dev));
-    hipCHECK(hipGetDeviceProperties(&prop, dev));
-    const int nCu = prop.multiProcessorCount;
-    std::vector<uint32_t> mask((nCu + 31) / 32, 0u);
-    for (int cu = 0; cu < nCu; cu++) {
-      const bool kth = cu % k == k - 1;
-      if (kth != invert) mask[cu / 32] |= 1u << (cu % 32);
-    }
-    return mask;
-  }
-  static int reserveEvery() {
-    const char* e = std::getenv("BSP_RESERVE_EVERY");
-    return e ? atoi(e) : 0;
-  }
+  // side stream + event pool of the lookahead schedule (created on first use).  Lowest priority;
+  // neither stream priorities nor CU masks separate the bulk tiles from the chain on this stack
+  // (hipExtStreamCreateWithCUMask is not honoured: a masked saturating kernel ran on all 256 CUs,
+  // tools/throttle_probe.hip), what does is s_setprio inside the chain kernels.
   hipStream_t sideStream() {
     if (!side) {
-      // Optional experiment (BSP_RESERVE_EVERY=k): keep every k-th CU free of bulk work with a CU
-      // mask (and pin the critical chain to those CUs, see critStream).
-      const int k = reserveEvery();
-      if (k >= 2) {
-        std::vector<uint32_t> mask = everyKthCuMask(k, /*invert=*/true);
-        hipCHECK(hipExtStreamCreateWithCUMask(&side, (uint32_t)mask.size(), mask.data()));
-      } else {
-        int least = 0, greatest = 0;
-        hipCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        hipCHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least));
-      }
-    }
-    return side;
-  }
-  // high-priority stream for the latency-critical chain while a bulk update runs beside it
-  hipStream_t critStream() {
-    if (!crit && reserveEvery() >= 2 && std::getenv("BSP_PIN_CHAIN")) {
-      std::vector<uint32_t> mask = everyKthCuMask(reserveEvery(), /*invert=*/false);
-      hipCHECK(hipExtStreamCreateWithCUMask(&crit, (uint32_t)mask.size(), mask.data()));
-    }
-    if (!crit) {
       int least = 0, greatest = 0;
       hipCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      hipCHECK(hipStreamCreateWithPriority(&crit, hipStreamNonBlocking, greatest));
+      hipCHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least));
     }
-    return crit;
+    return side;
   }
   hipEvent_t eventFromPool() {
     if (nextEvent == events.size()) {
@@ -293,9 +255,8 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipKernelProfile* profile = nullptr;
   bool lookaheadEnabled = true;
   unsigned bulkExtraLds = 6 * 1024;
-  bool critEnabled = false;  // measured: no gain from stream priorities on MI355X
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
-  hipStream_t side = nullptr, crit = nullptr;
+  hipStream_t side = nullptr;
   bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
   bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
   bool fusePotrf = true;    // next panel's potrf inside the update launch (BSP_FUSE_POTRF=0 disables)
@@ -330,14 +291,6 @@ struct HipNumericCtx : NumericCtx<T> {
         plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(), plan.updTasks.as<UpdTask>() + begin,
         plan.chainOffTab.as<int64_t>(), plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(),
         plan.rowColOff.as<int32_t>(), ref, altTarget, altStride);
-  }
-
-  void launchUpdateBig(DevPlan& plan, int64_t begin, int64_t end, hipk::DataRef<BT> ref,
-                       hipStream_t stream) {
-    hipk::updateTileBig<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, 0, stream>>>(
-        plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(), plan.updTasks.as<UpdTask>() + begin,
-        plan.chainOffTab.as<int64_t>(), plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(),
-        plan.rowColOff.as<int32_t>(), ref);
   }
 
   // One level = potrf -> trsm -> update on the execution stream.  Deferred (lookahead) tiles go to
@@ -396,11 +349,6 @@ struct HipNumericCtx : NumericCtx<T> {
       if (lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
         hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
       }
-      if (lr.bigEnd > lr.bigBegin) {
-        timer.begin(kProfUpdate);
-        launchUpdateBig(plan, lr.bigBegin, lr.bigEnd, ref, sym.stream);
-        timer.end();
-      }
       const int64_t updBegin = lr.updBegin;
       if (lr.updEnd > updBegin) {
         timer.begin(direct && lr.directSeg >= 0 ? kProfChainUpdate : kProfUpdate);
@@ -421,16 +369,13 @@ struct HipNumericCtx : NumericCtx<T> {
         }
         timer.end();
       }
-      const bool anyDef = lr.defEnd > lr.defBegin || lr.bigDefEnd > lr.bigDefBegin;
+      const bool anyDef = lr.defEnd > lr.defBegin;
       if (lookahead && anyDef) {
         // Fork AFTER the level's own update launch: those "now" tiles (the next outer block's
         // columns) are on the critical path and run 3x faster alone than beside the bulk tiles.
         hipEvent_t fork = sym.eventFromPool();
         hipCHECK(hipEventRecord(fork, sym.stream));
         hipCHECK(hipStreamWaitEvent(sym.sideStream(), fork, 0));
-        if (lr.bigDefEnd > lr.bigDefBegin) {
-          launchUpdateBig(plan, lr.bigDefBegin, lr.bigDefEnd, ref, sym.sideStream());
-        }
         // first the tiles the next block's own update must wait for, then (event) the rest:
         // the side stream keeps running them while the chain goes on, and the next block's
         // deferred tiles queue up right behind
@@ -443,11 +388,6 @@ struct HipNumericCtx : NumericCtx<T> {
           launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
         }
         sideUsed = true;
-      }
-      if (!lookahead && lr.bigDefEnd > lr.bigDefBegin) {
-        timer.begin(kProfUpdate);
-        launchUpdateBig(plan, lr.bigDefBegin, lr.bigDefEnd, ref, sym.stream);
-        timer.end();
       }
       if (!lookahead && lr.defEnd > lr.defBegin) {
         timer.begin(kProfUpdate);
@@ -541,32 +481,9 @@ struct HipNumericCtx : NumericCtx<T> {
     hipk::DataRef<BT> ref = makeRef(data);
     LaunchTimer timer(sym.stream, sym.profile);
     sym.resetEventPool();
-    // With lookahead the whole call runs on an internal high-priority stream (forked from / joined
-    // to the caller's stream by events) so that the critical chain wins dispatch slots against the
-    // low-priority bulk tiles.
-    const bool useCrit = sym.profile == nullptr && sym.lookaheadEnabled && sym.critEnabled &&
-                         plan.host.hasDeferred;
-    hipStream_t userStream = sym.stream;
-    if (useCrit) {
-      hipEvent_t fork = sym.eventFromPool();
-      hipCHECK(hipEventRecord(fork, userStream));
-      hipCHECK(hipStreamWaitEvent(sym.critStream(), fork, 0));
-      sym.stream = sym.critStream();
-    }
-    try {
-      for (const ElimRangePlan& er : plan.host.elimRanges) launchElim(plan, er, ref, timer);
-      launchLevels(plan, plan.host.levels, ref, timer);
-      hipCHECK(hipGetLastError());
-    } catch (...) {
-      sym.stream = userStream;
-      throw;
-    }
-    if (useCrit) {
-      hipEvent_t join = sym.eventFromPool();
-      hipCHECK(hipEventRecord(join, sym.stream));
-      sym.stream = userStream;
-      hipCHECK(hipStreamWaitEvent(userStream, join, 0));
-    }
+    for (const ElimRangePlan& er : plan.host.elimRanges) launchElim(plan, er, ref, timer);
+    launchLevels(plan, plan.host.levels, ref, timer);
+    hipCHECK(hipGetLastError());
     timer.finish();
   }
 

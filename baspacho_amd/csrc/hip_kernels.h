@@ -1467,173 +1467,8 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
   BSP_STAMP(3);
 }
 
-// ------------------------------------------------------------------------------------------
-// K5b  the same rank-K update on a 128x128 tile, for the large segments (bulk of the flops).
-//   * 256 threads = 4 waves, each wave a 64x64 sub-tile = 4x4 MFMA 16x16 tiles (16 accumulators,
-//     64 fp64 accumulator values per lane): 4x the MFMA work per byte staged and per scatter
-//   * K loop in chunks of 32 columns; the NEXT chunk is fetched into registers (32 values per
-//     lane) while the current one is multiplied out of LDS, so global latency hides behind MFMA
-//   * one LDS buffer of 2 x 128 x 34 doubles (row stride 34 == 2 mod 4 doubles: conflict-free
-//     operand fetch); 70 KB per workgroup leaves room for the panel kernels of the critical path
-// ------------------------------------------------------------------------------------------
-constexpr int kBigTile = 128;
-constexpr int kBigChunk = 32;
-
-template <typename T>
-__global__ __launch_bounds__(256) void updateTileBig(const SrcDesc* srcs, const SegDesc* segs,
-                                                     const UpdTask* tasks,
-                                                     const int64_t* chainOffTab,
-                                                     const int32_t* rowChain,
-                                                     const int32_t* rowLocal,
-                                                     const int32_t* rowColOff, DataRef<T> dref) {
-  constexpr int LD = kBigChunk + 2;
-  __shared__ T As[kBigTile * LD];
-  __shared__ T Bs[kBigTile * LD];
-  __shared__ int64_t rowBase[kBigTile];
-  __shared__ int32_t colOff[kBigTile];
-
-  const UpdTask task = tasks[blockIdx.x];
-  const SegDesc sd = segs[task.seg];
-  const SrcDesc pd = srcs[sd.src];
-  T* data = pickData(dref);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = pd.K, lda = pd.lda;
-  const T* P = data + pd.off;
-  const bool diagTile = task.rowTile == task.colTile;
-  const int segEnd = sd.q0 + sd.m;
-
-  if (tid < kBigTile) {
-    const int q = task.rowTile + tid;
-    int64_t base = 0;
-    if (q < pd.rowsBelow) {
-      if (sd.kind == kSegIntra) {
-        base = sd.tgtBase + (int64_t)q * sd.tgtStride;
-      } else {
-        const int rr = pd.lumpRowBase + (q - pd.nRest);
-        base = chainOffTab[sd.chainTabPtr + (rowChain[rr] - sd.firstChainOrd)] +
-               (int64_t)rowLocal[rr] * sd.tgtStride;
-      }
-    }
-    rowBase[tid] = base;
-  } else {
-    const int cidx = tid - kBigTile;
-    const int q = task.colTile + cidx;
-    int32_t off = 0;
-    if (q < segEnd) off = sd.kind == kSegIntra ? q : rowColOff[pd.lumpRowBase + (q - pd.nRest)];
-    colOff[cidx] = off;
-  }
-
-  const T* Bt = diagTile ? As : Bs;
-  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
-  const int li = lane & 15, lk = lane >> 4;
-  using Acc = typename Mfma<T>::Acc;
-  Acc acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = Acc{0, 0, 0, 0};
-  }
-  const bool skipUpper = diagTile && wr < wc;
-
-  // staging map: lane quarter k = tid & 31 (column inside the chunk), rows (tid >> 5) + 8*it
-  const int sk = tid & 31, sr = tid >> 5;
-  T va[16], vb[16];
-  auto fetch = [&](int kBase) {
-    const int kc = min(kBigChunk, K - kBase);
-    const int kcl = kBase + min(sk, kc - 1);
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const int qa = min(task.rowTile + sr + 8 * it, pd.rowsBelow - 1);
-      va[it] = P[(int64_t)qa * lda + kcl];
-    }
-    if (!diagTile) {
-#pragma unroll
-      for (int it = 0; it < 16; it++) {
-        const int qb = min(task.colTile + sr + 8 * it, segEnd - 1);
-        vb[it] = P[(int64_t)qb * lda + kcl];
-      }
-    }
-  };
-  auto park = [&](int kBase) {
-    const int kc = min(kBigChunk, K - kBase);
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const int r = sr + 8 * it;
-      As[r * LD + sk] = (sk < kc && task.rowTile + r < pd.rowsBelow) ? va[it] : T(0);
-    }
-    if (!diagTile) {
-#pragma unroll
-      for (int it = 0; it < 16; it++) {
-        const int r = sr + 8 * it;
-        Bs[r * LD + sk] = (sk < kc && task.colTile + r < segEnd) ? vb[it] : T(0);
-      }
-    }
-  };
-
-  fetch(0);
-  for (int kBase = 0; kBase < K; kBase += kBigChunk) {
-    if (kBase > 0) __syncthreads();  // everyone is done reading the previous chunk
-    park(kBase);
-    __syncthreads();
-    if (kBase + kBigChunk < K) fetch(kBase + kBigChunk);  // in flight during the MFMAs below
-    if (!skipUpper) {
-      const int kPad = (min(kBigChunk, K - kBase) + 3) & ~3;
-      for (int k0 = 0; k0 < kPad; k0 += 4) {
-        T a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) a[i] = As[(wr + 16 * i + li) * LD + k0 + lk];
-#pragma unroll
-        for (int j = 0; j < 4; j++) b[j] = Bt[(wc + 16 * j + li) * LD + k0 + lk];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
-        }
-      }
-    }
-  }
-  if (skipUpper) return;
-
-  // scatter: 16 MFMA tiles x 4 values per lane, in groups of 16 (gather old values, then store)
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    T* ptr[16];
-    bool ok[16];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int cIn = wc + 16 * j + li;
-      const int qc = task.colTile + cIn;
-      const int32_t co = colOff[cIn];
-#pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        const int rIn = wr + 16 * i + Mfma<T>::row(lane, reg);
-        const int qr = task.rowTile + rIn;
-        ok[j * 4 + reg] = qc < segEnd && qr < pd.rowsBelow && qr >= qc && qr >= sd.rowMin;
-        ptr[j * 4 + reg] = data + rowBase[rIn] + co;
-      }
-    }
-    if (task.atomic) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-          if (ok[j * 4 + reg]) atomicSub(ptr[j * 4 + reg], acc[i][j][reg]);
-        }
-      }
-    } else {
-      T old[16];
-#pragma unroll
-      for (int e = 0; e < 16; e++) old[e] = *ptr[e];  // masked-off entries point at valid memory
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-          if (ok[j * 4 + reg]) *ptr[j * 4 + reg] = old[j * 4 + reg] - acc[i][j][reg];
-        }
-      }
-    }
-  }
-}
+// (A 128x128-tile variant of K5 -- 4x4 MFMA tiles per wave, 70 KB LDS, 2 workgroups per CU -- was
+// measured at 32-35 TF/s against 42 for the 64x64 tile at K = 256, and removed.)
 
 // ------------------------------------------------------------------------------------------
 // Measurement helper: sustained rate of back-to-back independent v_mfma_f64_16x16x4_f64 (4

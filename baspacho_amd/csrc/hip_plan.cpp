@@ -629,7 +629,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       const bool chain = bucket.size() == 1 && bi + 1 < buckets.size() &&
                          buckets[bi + 1].size() == 1 &&
                          plan.panels[buckets[bi + 1][0].panel].lump == plan.panels[bucket[0].panel].lump;
-      vector<UpdTask> deferred, deferredLate, big, bigDeferred;
+      vector<UpdTask> deferred, deferredLate;
       int32_t nowSegs = 0, nowSeg = -1;  // segments with non-deferred 64x64 tiles in this level
       bool nowPlain = true;              // ... all intra-lump, non-atomic, untouched order
       // how many panels of this level hit each target lump
@@ -654,23 +654,19 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             if (it != lastDeferredLevel.end()) lr.waitDefLevel = std::max(lr.waitDefLevel, it->second);
           }
           bool anyDeferred = false;
-          // large segments go to the 128x128-tile kernel, the rest to the 64x64 one
-          const bool useBig = sd.m >= kBigTileMin && sr.rowsBelow - sd.q0 >= kBigTileMin;
-          const int32_t step = useBig ? 2 * kTile : kTile;
+          const int32_t step = kTile;
           for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += step) {
             const bool defer = sd.outer && cT - sd.q0 >= kOuterWidth;
             for (int32_t rT = cT; rT < sr.rowsBelow; rT += step) {
               const UpdTask t{(int32_t)s, rT, cT, atomic};
               if (defer) {
                 const bool late = cT - sd.q0 >= 2 * kOuterWidth;
-                (useBig ? bigDeferred : (late ? deferredLate : deferred)).push_back(t);
+                (late ? deferredLate : deferred).push_back(t);
                 anyDeferred = true;
-              } else if (useBig) {
-                big.push_back(t);
               } else {
                 plan.updTasks.push_back(t);
               }
-              if (!defer && !useBig) {
+              if (!defer) {
                 if (nowSeg != (int32_t)s) nowSegs++;
                 nowSeg = (int32_t)s;
                 if (sd.kind != kSegIntra || atomic) nowPlain = false;
@@ -708,13 +704,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           plan.updTasks[begin + p] = tmp[chunkStart[x] + k];
         }
       };
-      lr.bigBegin = (int64_t)plan.updTasks.size();
-      plan.updTasks.insert(plan.updTasks.end(), big.begin(), big.end());
-      lr.bigEnd = lr.bigDefBegin = (int64_t)plan.updTasks.size();
-      plan.updTasks.insert(plan.updTasks.end(), bigDeferred.begin(), bigDeferred.end());
-      lr.bigDefEnd = (int64_t)plan.updTasks.size();
-      plan.numLaunches += (lr.bigEnd > lr.bigBegin) + (lr.bigDefEnd > lr.bigDefBegin);
-      if (lr.defEnd > lr.defBegin || lr.bigDefEnd > lr.bigDefBegin) plan.hasDeferred = true;
+      if (lr.defEnd > lr.defBegin) plan.hasDeferred = true;
       if (bucket.size() == 1) {
         lr.directPanel = bucket[0].panel;
         if (nowSegs == 1 && nowPlain) {
@@ -826,7 +816,6 @@ HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly)
       }
       lr.updEnd = (int64_t)plan.updTasks.size();
       lr.defBegin = lr.defMid = lr.defEnd = lr.updEnd;
-      lr.bigBegin = lr.bigEnd = lr.bigDefBegin = lr.bigDefEnd = lr.updEnd;
       plan.levels.push_back(lr);
     }
   }

@@ -24,10 +24,6 @@ constexpr int kPanelWidth = 64;   // max panel width nb (potrf/trsm granularity)
 constexpr int kOuterWidth = 256;  // outer block: panels update only their own outer block right
                                   // away; everything to its right gets ONE rank-256 update
 constexpr int kTile = 64;         // update tile (rows x cols) and trsm row tile
-constexpr int kBigTileMin = 1 << 30;  // segments at least this wide AND tall would use the 128x128
-                                      // kernel; disabled: measured equal rate per tile (35 TF/s at
-                                      // K=256, the fp64 MFMA pipe sustains ~47 TF/s on this chip)
-                                      // and worse load balance than 64x64 tiles
 constexpr int kElimSmallMax = 16; // widest lump handled by the small sparse-elim kernels
 
 struct PanelDesc {
@@ -94,8 +90,6 @@ struct LevelRange {
   // [defBegin, defMid): the deferred tiles in the columns of the outer block AFTER the next one,
   // i.e. the only ones the next block's own update launch must wait for; they run first
   int64_t defMid = 0;
-  // the same two lists for the 128x128-tile kernel (large segments)
-  int64_t bigBegin, bigEnd, bigDefBegin, bigDefEnd;
   // DIRECT chain kernels (hip_kernels.h): set when the level holds one panel; directSeg >= 0 when
   // its non-deferred tiles [updBegin, updEnd) are exactly the tiles of that one intra segment
   int32_t directPanel = -1, directSeg = -1;

@@ -118,13 +118,6 @@ int main(int argc, char** argv) {
   printf("updateTile plain  : %8.1f us  -> %.2f TF/s\n", us, updFlops / us / 1e6);
   us = timeIt([&] { hipk::updateTile<double><<<(unsigned)ut.size(), 256>>>(dsr, dsd, dutA, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
   printf("updateTile atomic : %8.1f us  -> %.2f TF/s\n", us, updFlops / us / 1e6);
-  {
-    std::vector<UpdTask> ub;
-    for (int cT = 0; cT < sd.m; cT += 128) for (int rT = cT; rT < pd.rowsBelow; rT += 128) ub.push_back({0, rT, cT, 0});
-    UpdTask* dub; CK(hipMalloc(&dub, ub.size() * sizeof(UpdTask))); CK(hipMemcpy(dub, ub.data(), ub.size() * sizeof(UpdTask), hipMemcpyHostToDevice));
-    us = timeIt([&] { hipk::updateTileBig<double><<<(unsigned)ub.size(), 256>>>(dsr, dsd, dub, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
-    printf("updateTileBig     : %8.1f us  -> %.2f TF/s  (%zu tiles)\n", us, updFlops / us / 1e6, ub.size());
-  }
   CK(hipDeviceSynchronize());
   return 0;
 }
