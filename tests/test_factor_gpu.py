@@ -275,6 +275,30 @@ def test_lump_widths_around_panel_and_block_boundaries(dtype):
         assert np.linalg.norm(X - want) / np.linalg.norm(want) < (1e-10 if dtype == np.float64 else 1e-4), W
 
 
+@pytest.mark.parametrize("knob", ["BSP_NO_LOOKAHEAD=1", "BSP_DIRECT_CHAIN=0", "BSP_FUSE_POTRF=0",
+                                  "BSP_SPLIT_DIAG=0", "BSP_ELIM_FACTOR_DESC=0"])
+def test_schedule_variants(monkeypatch, knob):
+    """every optimisation of the launch schedule can be switched off (the environment is read
+    when the solver is created); each fallback must still factor correctly"""
+    k, v = knob.split("=")
+    monkeypatch.setenv(k, v)
+    n = 700
+    ss = T.columns_to_structure([set(range(i, n)) for i in range(n)])
+    sol = B.create_solver(B.Settings(), np.ones(n, dtype=np.int64), ss)
+    data = spd_data(sol, 21, beta_factor=1.2)
+    _, A = dense_lower_chol(sol, data)
+    Lg = lower_of(sol, _gpu_factor(sol, data))
+    assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < 1e-10
+    sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=60, num_pts=6000, band=8, seed=5)
+    sol = B.create_solver(B.Settings(), sizes, ss, [0, 6000])
+    data = spd_data(sol, 11, beta_factor=1.2)
+    ref = data.copy()
+    cref.factor(sol.skel(), ref, sol.sparseEliminationRanges())
+    got = _gpu_factor(sol, data)
+    mask = sol.lowerMask()
+    assert np.linalg.norm((got - ref)[mask]) / np.linalg.norm(ref[mask]) < 1e-12
+
+
 def test_wide_dense_lump_residual():
     """one wide supernode (multi-panel, intra-lump trailing updates): north-star residual
     ||L L^T - A|| / ||A|| < 1e-10 in fp64"""
