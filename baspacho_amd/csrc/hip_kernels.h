@@ -6,6 +6,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include <cstdint>
 
 #include "hip_plan.h"
@@ -712,6 +715,15 @@ __device__ long long bspDebugStamps[16];
 // 184 us + 77 us per outer block against ~165 us for the four 64-wide panel steps they would
 // replace -- the serial dependent-latency per 4-column step dominates either way -- so the
 // 64-wide panel chain stays.
+// f(integral_constant<int, I>) for I = BEGIN .. END-1, everything inlined
+template <int BEGIN, int END, typename F>
+__device__ __forceinline__ void staticFor(F& f) {
+  if constexpr (BEGIN < END) {
+    f(std::integral_constant<int, BEGIN>{});
+    staticFor<BEGIN + 1, END>(f);
+  }
+}
+
 struct NoPreUpdate {
   template <typename A>
   __device__ __forceinline__ void operator()(A*) const {}
@@ -780,11 +792,9 @@ __device__ __forceinline__ void potrfTiles(T* A, int nb, int lda, T (*blk)[4], T
   publish(0);
   if (nSteps > 1) publish(1);
   ldsBarrier();
-  // fully unrolled (tile and column-block indices become constants: a rolled loop spends a
-  // quarter of every step in ~25 scalar branches around them)
-#pragma unroll
-  for (int J = 0; J < 4 * NT; J++) {
-    if (J >= nSteps) break;
+  auto step = [&](auto Jc) __attribute__((always_inline)) {
+    const int J = Jc;  // integral_constant: a compile-time constant after inlining
+    if (J >= nSteps) return;
     const int j0 = 4 * J, tjJ = J >> 2;
     T(*raw)[4] = blk + (J % 3) * N;
     // (1) pivot block + own row
@@ -847,7 +857,19 @@ __device__ __forceinline__ void potrfTiles(T* A, int nb, int lda, T (*blk)[4], T
       }
     }
     ldsBarrier();
+  };
+
+  // (compile-time step index: tile and column-block indices are constants -- a rolled loop
+  //  spends a quarter of every step in ~25 scalar branches around them)
+#ifdef BSP_POTRF_PARTIAL_UNROLL  // A/B: let the compiler peel a few steps and loop over the rest
+#pragma unroll
+  for (int Jr = 0; Jr < 4 * NT; Jr++) {
+    if (Jr >= nSteps) break;
+    step(Jr);
   }
+#else
+  staticFor<0, 4 * NT>(step);
+#endif
   BSP_STAMP(2);
 }
 
