@@ -24,10 +24,22 @@ struct DataRef {
   T* const* many;
 };
 
+// Pointers that come out of memory (the batch's pointer array) or out of a select are "generic" to
+// the compiler, and every access through them becomes a FLAT instruction, which counts against the
+// LDS counter as well: each wait for an LDS read then also waits for the global loads in flight
+// (the prefetch of the next K chunk, the operands of the next pairs ...).  The round trip through
+// the global address space tells the compiler where the data lives; accesses become global_*.
+// (a cast to the global address space and back is folded away: the pointers have to KEEP the
+// address-space type down to the access, hence GP<T> throughout the kernels)
 template <typename T>
-__device__ __forceinline__ T* pickData(const DataRef<T>& d) {
-  return d.many ? d.many[blockIdx.y] : d.single;
+using GP = __attribute__((address_space(1))) T*;
+
+template <typename T>
+__device__ __forceinline__ GP<T> pickData(const DataRef<T>& d) {
+  return (GP<T>)(d.many ? d.many[blockIdx.y] : d.single);
 }
+__device__ __forceinline__ void atomicSub(GP<double> p, double v) { unsafeAtomicAdd((double*)p, -v); }
+__device__ __forceinline__ void atomicSub(GP<float> p, float v) { unsafeAtomicAdd((float*)p, -v); }
 
 __device__ __forceinline__ void waveSync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -94,12 +106,12 @@ __global__ __launch_bounds__(256) void elimFactorSmall(SkelDev sk, DataRef<T> dr
   if (l >= lumpEnd) return;
   const int n = (int)(sk.lumpStart[l + 1] - sk.lumpStart[l]);
   if (n > NMAX) return;  // wide lumps of the range go through the panel kernels
-  T* data = pickData(dref);
+  GP<T> data = pickData(dref);
   const int64_t c0 = sk.chainColPtr[l];
   const int64_t nCh = sk.chainColPtr[l + 1] - c0;
   const int64_t diagCh = sk.boardChainColOrd[sk.boardColPtr[l] + 1];
-  T* D = data + sk.chainData[c0];
-  T* B = data + sk.chainData[c0 + diagCh];
+  GP<T> D = data + sk.chainData[c0];
+  GP<T> B = data + sk.chainData[c0 + diagCh];
   const int rowsBelow =
       (int)(sk.chainRowsTillEnd[c0 + nCh - 1] - sk.chainRowsTillEnd[c0 + diagCh - 1]);
   T* S = diagS[wave];
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256) void elimFactorSmall(SkelDev sk, DataRef<T> dr
   }
   // rows below: x * L^T = b  (forward substitution per row)
   for (int r = lane; r < rowsBelow; r += 64) {
-    T* row = B + (int64_t)r * n;
+    GP<T> row = B + (int64_t)r * n;
     T x[NMAX];
 #pragma unroll
     for (int j = 0; j < NMAX; j++) x[j] = j < n ? row[j] : T(0);
@@ -163,8 +175,8 @@ __global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs,
   const ElimLumpDesc ld = descs[idx];
   const int n = ld.n;
   if (n > 4) return;  // (the caller checks the range's maximum width)
-  T* D = pickData(dref) + ld.diagOff;
-  T* B = D + n * n;
+  GP<T> D = pickData(dref) + ld.diagOff;
+  GP<T> B = D + n * n;
   // diagonal block (lower part), padded with the identity
   T a[4][4];
 #pragma unroll
@@ -179,7 +191,7 @@ __global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs,
   T x[4];
   const bool has = lane < ld.rowsBelow;
   {
-    const T* row = B + (int64_t)(has ? lane : 0) * n;
+    GP<const T> row = B + (int64_t)(has ? lane : 0) * n;
 #pragma unroll
     for (int j = 0; j < 4; j++) x[j] = row[min(j, n - 1)];
   }
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs,
   }
   // rows below: x * L^T = b
   for (int r = lane; r < ld.rowsBelow; r += 64) {
-    T* row = B + (int64_t)r * n;
+    GP<T> row = B + (int64_t)r * n;
     if (r != lane) {
 #pragma unroll
       for (int j = 0; j < 4; j++) x[j] = row[min(j, n - 1)];
@@ -250,11 +262,11 @@ __global__ __launch_bounds__(256) void elimUpdate(SkelDev sk, const int32_t* cha
   const int64_t c0 = sk.chainColPtr[l], cEnd = sk.chainColPtr[l + 1];
   const int64_t diagCh = sk.boardChainColOrd[sk.boardColPtr[l] + 1];
   if (c - c0 < diagCh) return;  // diagonal chain: nothing to push
-  T* data = pickData(dref);
+  GP<T> data = pickData(dref);
   const int n = (int)(sk.lumpStart[l + 1] - sk.lumpStart[l]);
   const int64_t si = sk.chainRowSpan[c];
   const int siSize = (int)(sk.spanStart[si + 1] - sk.spanStart[si]);
-  const T* Bi = data + sk.chainData[c];
+  GP<const T> Bi = data + sk.chainData[c];
   const int64_t t = sk.spanToLump[si];
   const int64_t tStride = sk.lumpStart[t + 1] - sk.lumpStart[t];
   const int64_t colOff = sk.spanOffsetInLump[si];
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(256) void elimUpdate(SkelDev sk, const int32_t* cha
   for (int64_t j = c; j < cEnd; j++) {
     const int64_t sj = sk.chainRowSpan[j];
     const int sjSize = (int)(sk.spanStart[sj + 1] - sk.spanStart[sj]);
-    const T* Bj = data + sk.chainData[j];
+    GP<const T> Bj = data + sk.chainData[j];
     int64_t hi = tCount;
     while (hi - lo > 1) {
       int64_t mid = lo + (hi - lo) / 2;
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(256) void elimUpdate(SkelDev sk, const int32_t* cha
         hi = mid;
       }
     }
-    T* tgt = data + sk.chainData[t0 + lo] + colOff;
+    GP<T> tgt = data + sk.chainData[t0 + lo] + colOff;
     const int total = sjSize * siSize;
     for (int e = lane; e < total; e += 64) {
       const int r = e / siSize, q = e - r * siSize;
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, c
   const int idx = blockIdx.x * 4 + wave;
   if (idx >= numItems) return;
   const ElimGatherItem it = items[idx];
-  T* data = pickData(dref);
+  GP<T> data = pickData(dref);
   T* stage = stageAll[wave];
   const int rows = it.rows, cols = it.cols, n = it.n;
   const int total = rows * cols;
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, c
       }
     }
   }
-  T* target = data + it.tgtOff;
+  GP<T> target = data + it.tgtOff;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     if (ok[s]) {
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
   const int idx = blockIdx.x * 4 + wave;
   if (idx >= numItems) return;
   const ElimGatherItem it = items[idx];
-  T* data = pickData(dref);
+  GP<T> data = pickData(dref);
   const int rows = it.rows, cols = it.cols, n = it.n;
   using Acc = typename Mfma<T>::Acc;
   Acc acc = {0, 0, 0, 0};
@@ -490,8 +502,8 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
       }
     }
   }
-  T* target = data + it.tgtOff;
-  T* ptr[4];
+  GP<T> target = data + it.tgtOff;
+  GP<T> ptr[4];
   bool ok[4];
   T old[4];
 #pragma unroll
@@ -538,7 +550,7 @@ __global__ __launch_bounds__(1024) void elimRowMfma(const ElimRowItem* rowItems,
   for (int e = tid; e < it.ldsElems; e += 1024) acc[e] = T(0);
   for (int s = tid; s < nSlots; s += 1024) tab[s] = slots[it.slotBegin + s];
   __syncthreads();
-  T* data = pickData(dref);
+  GP<T> data = pickData(dref);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int rows = it.rows, n = it.n;
@@ -643,7 +655,7 @@ __global__ __launch_bounds__(1024) void elimRowMfma(const ElimRowItem* rowItems,
     const ElimRowSlot sd = tab[lo];
     const int e2 = e - sd.ldsOff, r = e2 / sd.cols, c = e2 - r * sd.cols;
     if (!((sd.flags & 2) && c > r)) {
-      T* p = data + sd.tgtOff + (int64_t)r * sd.tgtStride + c;
+      GP<T> p = data + sd.tgtOff + (int64_t)r * sd.tgtStride + c;
       if (it.shared) {
         atomicSub(p, acc[e]);
       } else {
@@ -664,21 +676,21 @@ __global__ __launch_bounds__(256) void elimGatherTiny(const ElimGatherItem* item
   const int idx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   if (idx >= numItems) return;
   const ElimGatherItem it = items[idx];
-  T* data = pickData(dref);
+  GP<T> data = pickData(dref);
   const int cols = it.cols, n = it.n, total = int(it.rows) * cols;
   const bool live = sub < total;
   const int e = live ? sub : 0;
   const int r = e / cols, q = e - r * cols;
   T acc = T(0);
   for (int p = it.pairBegin; p < it.pairEnd; p++) {
-    const T* Bj = data + offJ[p] + r * n;
-    const T* Bi = data + offI[p] + q * n;
+    GP<const T> Bj = data + offJ[p] + r * n;
+    GP<const T> Bi = data + offI[p] + q * n;
     T d = T(0);
     for (int k = 0; k < n; k++) d += Bj[k] * Bi[k];
     acc += d;
   }
   if (live && !((it.flags & 2) && q > r)) {
-    T* target = data + it.tgtOff + (int64_t)r * it.tgtStride + q;
+    GP<T> target = data + it.tgtOff + (int64_t)r * it.tgtStride + q;
     if (it.flags & 1) {
       atomicSub(target, acc);
     } else {
@@ -733,7 +745,7 @@ struct NoPreUpdate {
 // (updateTileDirectPotrf) applies the pending rank-K update of the block there.
 // blk: 3 x (16 NT) rows of 4 values (ring of column blocks), sol: 16 NT rows of 4 values.
 template <typename T, int NT, typename Pre = NoPreUpdate>
-__device__ __forceinline__ void potrfTiles(T* A, int nb, int lda, T (*blk)[4], T (*sol)[4],
+__device__ __forceinline__ void potrfTiles(GP<T> A, int nb, int lda, T (*blk)[4], T (*sol)[4],
                                            Pre pre = Pre()) {
   // The block lives in MFMA accumulator layout: wave w owns tile row w (16x16 tiles (w,0..w));
   // lane l / register r of tile (ti,tj) hold row 16ti + Mfma::row(l,r), column 16tj + (l&15).
@@ -936,11 +948,11 @@ __device__ __forceinline__ T quadBcastSel(T v, int g) {  // g is a compile-time 
 // and beyond nb, invDiag is zero beyond nb: the body needs no per-lane conditions.
 template <typename T, int NB>
 __device__ __forceinline__ void trsmRows(const T* __restrict__ Ls, const T* __restrict__ invDiag,
-                                         T* P, int lda, int nb, int rows, int tid) {
+                                         GP<T> P, int lda, int nb, int rows, int tid) {
   constexpr int LDL = kPanelWidth + 1, M = NB / 8;
   const int r = tid >> 2, g = tid & 3;
   const bool active = r < rows;
-  T* row = P + (int64_t)(active ? r : 0) * lda;
+  GP<T> row = P + (int64_t)(active ? r : 0) * lda;
   T x[M][2];
 #pragma unroll
   for (int m = 0; m < M; m++) {
@@ -985,10 +997,10 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
   BSP_STAMP(4);
   const TrsmTask task = tasks[blockIdx.x];
   const PanelDesc pd = panels[task.panel];
-  T* data = pickData(dref);
-  const T* A = data + pd.diagOff;
+  GP<T> data = pickData(dref);
+  GP<const T> A = data + pd.diagOff;
   const int nb = pd.nb, lda = pd.lda, tid = threadIdx.x;
-  T* P = data + pd.diagOff + (int64_t)(nb + task.rowTile) * lda;
+  GP<T> P = data + pd.diagOff + (int64_t)(nb + task.rowTile) * lda;
   const int rows = min(kTile, pd.rowsBelow - task.rowTile);
   const int nbPad = nb <= 8 ? 8 : nb <= 16 ? 16 : nb <= 32 ? 32 : 64;
 
@@ -1025,13 +1037,13 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
 
 // direct variant: the row tile is blockIdx.x, the rows are fetched together with L
 template <typename T, int NB>
-__device__ __forceinline__ void trsmDirectBody(const T* A, T* P, int lda, int nb, int rows, T* Ls,
+__device__ __forceinline__ void trsmDirectBody(GP<const T> A, GP<T> P, int lda, int nb, int rows, T* Ls,
                                                T* invDiag) {
   constexpr int LDL = kPanelWidth + 1, M = NB / 8;
   constexpr int NL = (NB * NB + 255) / 256;
   const int tid = threadIdx.x, r = tid >> 2, g = tid & 3;
   const bool active = r < rows;
-  T* row = P + (int64_t)(active ? r : 0) * lda;
+  GP<T> row = P + (int64_t)(active ? r : 0) * lda;
   T x[M][2], v[NL];
 #pragma unroll
   for (int m = 0; m < M; m++) {
@@ -1087,10 +1099,10 @@ __global__ __launch_bounds__(256) void trsmPanelDirect(PanelDesc pd, DataRef<T> 
   __shared__ T Ls[kPanelWidth * LDL];
   __shared__ T invDiag[kPanelWidth];
   __builtin_amdgcn_s_setprio(3);
-  T* data = pickData(dref);
-  const T* A = data + pd.diagOff;
+  GP<T> data = pickData(dref);
+  GP<const T> A = data + pd.diagOff;
   const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
-  T* P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
+  GP<T> P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
   const int rows = min(kTile, pd.rowsBelow - rowTile);
   if (nb <= 8) {
     trsmDirectBody<T, 8>(A, P, lda, nb, rows, Ls, invDiag);
@@ -1133,10 +1145,10 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
   const UpdTask task = tasks[blockIdx.x];
   const SegDesc sd = segs[task.seg];
   const SrcDesc pd = srcs[sd.src];  // (named pd: rowsBelow / nRest / lumpRowBase as for a panel)
-  T* data = pickData(dref);
+  GP<T> data = pickData(dref);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = pd.K, lda = pd.lda;
-  const T* P = data + pd.off;  // first row below the source columns
+  GP<const T> P = data + pd.off;  // first row below the source columns
   const bool diagTile = task.rowTile == task.colTile;
   const int segEnd = sd.q0 + sd.m;
 
@@ -1225,8 +1237,8 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
     // flight together), then subtract and store -- a read-modify-write per element would
     // serialise 16 memory round trips.
     const Acc* accs[4] = {&acc00, &acc01, &acc10, &acc11};
-    T* tbase = altTarget ? altTarget + (int64_t)blockIdx.y * altStride : data;
-    T* ptr[16];
+    GP<T> tbase = altTarget ? (GP<T>)altTarget + (int64_t)blockIdx.y * altStride : data;
+    GP<T> ptr[16];
     bool ok[16];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -1281,7 +1293,7 @@ __device__ __forceinline__ int xcdContiguous(int b, int n) {
 // tile `idx` of the segment in the order: column tiles from sd.q0 on, each with its row tiles
 template <typename T>
 __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const SegDesc& sd, int idx,
-                                                     T* data, T* As, T* Bs) {
+                                                     GP<T> data, T* As, T* Bs) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
   int colTile = sd.q0, rowTile;
   for (;;) {
@@ -1295,7 +1307,7 @@ __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const Se
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = pd.K, lda = pd.lda;
-  const T* P = data + pd.off;
+  GP<const T> P = data + pd.off;
   const bool diagTile = rowTile == colTile;
   const int segEnd = sd.q0 + sd.m;
   const T* Bt = diagTile ? As : Bs;
@@ -1325,7 +1337,7 @@ __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const Se
   };
   fetch(0);
   // old target values (masked-off entries are clamped onto valid ones)
-  T* tgt = data + sd.tgtBase;
+  GP<T> tgt = data + sd.tgtBase;
   T old[16];
 #pragma unroll
   for (int t = 0; t < 4; t++) {
@@ -1408,14 +1420,14 @@ __global__ __launch_bounds__(256) void trsmPanelDirectPlus(PanelDesc pd, SrcDesc
   constexpr int LDL = kPanelWidth + 1, LD = kUpdChunk + 2;
   __shared__ T lds[2 * kTile * LD];  // >= 64 x 65 + 64
   __builtin_amdgcn_s_setprio(3);
-  T* data = pickData(dref);
+  GP<T> data = pickData(dref);
   if (blockIdx.x == gridDim.x - 1) {
     updateTileDirectBody<T>(part, sd, 0, data, lds, lds + kTile * LD);
     return;
   }
-  const T* A = data + pd.diagOff;
+  GP<const T> A = data + pd.diagOff;
   const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
-  T* P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
+  GP<T> P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
   const int rows = min(kTile, pd.rowsBelow - rowTile);
   T* Ls = lds;
   T* invDiag = lds + kPanelWidth * LDL;
@@ -1437,7 +1449,7 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
   constexpr int KC = kUpdChunk, LD = KC + 2;
   __shared__ T As[kTile * LD];
   __shared__ T Bs[kTile * LD];
-  T* data = pickData(dref);
+  GP<T> data = pickData(dref);
   if (blockIdx.x != 0) {
     __builtin_amdgcn_s_setprio(2);
     updateTileDirectBody<T>(pd, sd, 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1), data, As, Bs);
@@ -1448,7 +1460,7 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
   T(*sol)[4] = blk + 3 * kPanelWidth;
   const int K = pd.K - kStart, lda = pd.lda, nb = next.nb;
   // rows of the next panel, source columns from kStart on
-  const T* X = data + pd.off + (int64_t)sd.q0 * lda + kStart;
+  GP<const T> X = data + pd.off + (int64_t)sd.q0 * lda + kStart;
   using Acc = typename Mfma<T>::Acc;
   auto pre = [&](Acc* acc) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
@@ -1530,7 +1542,7 @@ __global__ __launch_bounds__(256) void assembleKernel(SkelDev sk, const int64_t*
                                                       int64_t srcRectWidth, int64_t numBlockRows,
                                                       int64_t numBlockCols) {
   const int64_t r = blockIdx.x;
-  T* data = pickData(dref);
+  GP<T> data = pickData(dref);
   const T* temp = negTemp + (int64_t)blockIdx.y * tempStride;
   const int64_t* cre = sk.chainRowsTillEnd + srcColDataOffset;
   const int64_t* toSpan = sk.chainRowSpan + srcColDataOffset;
@@ -1546,7 +1558,7 @@ __global__ __launch_bounds__(256) void assembleKernel(SkelDev sk, const int64_t*
     int64_t c = 0;
     while (cre[c] - rectRowBegin <= col) c++;
     const int64_t cStart = cre[c - 1] - rectRowBegin;
-    T* dst = data + rOffset + sk.spanOffsetInLump[toSpan[c]] + j * dstStride + (col - cStart);
+    GP<T> dst = data + rOffset + sk.spanOffsetInLump[toSpan[c]] + j * dstStride + (col - cStart);
     *dst += temp[(rBegin + j) * srcRectWidth + col];
   }
 }

@@ -22,12 +22,12 @@ struct SolveRef {
   int64_t ldc;
 };
 template <typename T>
-__device__ __forceinline__ const T* solveMat(const SolveRef<T>& r) {
-  return r.mats ? r.mats[blockIdx.z] : r.mat;
+__device__ __forceinline__ GP<const T> solveMat(const SolveRef<T>& r) {
+  return (GP<const T>)(r.mats ? r.mats[blockIdx.z] : r.mat);
 }
 template <typename T>
-__device__ __forceinline__ T* solveVec(const SolveRef<T>& r) {
-  return (r.vecs ? r.vecs[blockIdx.z] : r.vec) + (int64_t)blockIdx.y * r.ldc;
+__device__ __forceinline__ GP<T> solveVec(const SolveRef<T>& r) {
+  return (GP<T>)(r.vecs ? r.vecs[blockIdx.z] : r.vec) + (int64_t)blockIdx.y * r.ldc;
 }
 
 __device__ __forceinline__ double waveSum(double v) {
@@ -52,12 +52,12 @@ __global__ __launch_bounds__(256) void solveElimSmall(SkelDev sk, SolveRef<T> re
   if (l >= lumpEnd) return;
   const int n = (int)(sk.lumpStart[l + 1] - sk.lumpStart[l]);
   if (n > kElimSmallMax) return;  // wide lumps go through the panel kernels
-  const T* data = solveMat(ref);
-  T* vec = solveVec(ref);
+  GP<const T> data = solveMat(ref);
+  GP<T> vec = solveVec(ref);
   const int64_t c0 = sk.chainColPtr[l], cEnd = sk.chainColPtr[l + 1];
   const int64_t diagCh = sk.boardChainColOrd[sk.boardColPtr[l] + 1];
-  const T* D = data + sk.chainData[c0];
-  T* xl = vec + sk.lumpStart[l];
+  GP<const T> D = data + sk.chainData[c0];
+  GP<T> xl = vec + sk.lumpStart[l];
   T x[kElimSmallMax];
   for (int i = 0; i < n; i++) x[i] = xl[i];
   if (!BACKWARD) {
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void solveElimSmall(SkelDev sk, SolveRef<T> re
     for (int64_t c = c0 + diagCh; c < cEnd; c++) {
       const int64_t span = sk.chainRowSpan[c];
       const int rows = (int)(sk.spanStart[span + 1] - sk.spanStart[span]);
-      const T* B = data + sk.chainData[c];
-      T* y = vec + sk.spanStart[span];
+      GP<const T> B = data + sk.chainData[c];
+      GP<T> y = vec + sk.spanStart[span];
       for (int r = 0; r < rows; r++) {
         T s = T(0);
         for (int k = 0; k < n; k++) s += B[r * n + k] * x[k];
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void solveElimSmall(SkelDev sk, SolveRef<T> re
     for (int64_t c = c0 + diagCh; c < cEnd; c++) {
       const int64_t span = sk.chainRowSpan[c];
       const int rows = (int)(sk.spanStart[span + 1] - sk.spanStart[span]);
-      const T* B = data + sk.chainData[c];
-      const T* y = vec + sk.spanStart[span];
+      GP<const T> B = data + sk.chainData[c];
+      GP<const T> y = vec + sk.spanStart[span];
       for (int r = 0; r < rows; r++) {
         const T yr = y[r];
         for (int k = 0; k < n; k++) x[k] -= B[r * n + k] * yr;
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void solveElimDiagL(SkelDev sk, SolveRef<T> re
   if (l >= lumpEnd) return;
   const int n = (int)(sk.lumpStart[l + 1] - sk.lumpStart[l]);
   if (n > kElimSmallMax) return;
-  const T* D = solveMat(ref) + sk.chainData[sk.chainColPtr[l]];
-  T* xl = solveVec(ref) + sk.lumpStart[l];
+  GP<const T> D = solveMat(ref) + sk.chainData[sk.chainColPtr[l]];
+  GP<T> xl = solveVec(ref) + sk.lumpStart[l];
   T x[kElimSmallMax];
   for (int i = 0; i < n; i++) x[i] = xl[i];
   for (int i = 0; i < n; i++) {
@@ -129,19 +129,19 @@ __global__ __launch_bounds__(256) void solveElimGatherL(const SolveGatherItem* i
                                                         SolveRef<T> ref) {
   __shared__ T part[4];
   const SolveGatherItem it = items[blockIdx.x];
-  const T* data = solveMat(ref);
-  T* vec = solveVec(ref);
+  GP<const T> data = solveMat(ref);
+  GP<T> vec = solveVec(ref);
   const int e = it.entryBegin + (int)threadIdx.x;
   const bool live = e < it.entryEnd;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int n = 0;
-  const T* B = data;
+  GP<const T> B = data;
   T x[kElimSmallMax];
   if (live) {
     const SolveGatherEntry en = entries[e];
     n = en.n;
     B = data + en.dataOff;
-    const T* xl = vec + en.xOff;
+    GP<const T> xl = vec + en.xOff;
     for (int k = 0; k < n; k++) x[k] = xl[k];
   }
   for (int r = 0; r < it.rows; r++) {
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void solveTriPanel(const PanelDesc* panels,
   constexpr int NB = kPanelWidth, LD = NB + 1;
   __shared__ T Ls[NB * LD];
   const PanelDesc pd = panels[levelPanels[blockIdx.x]];
-  const T* A = solveMat(ref) + pd.diagOff;
-  T* x = solveVec(ref) + pd.vecOff;
+  GP<const T> A = solveMat(ref) + pd.diagOff;
+  GP<T> x = solveVec(ref) + pd.vecOff;
   const int nb = pd.nb, lda = pd.lda, tid = threadIdx.x;
   {
     T v[16];
@@ -228,11 +228,11 @@ __global__ __launch_bounds__(256) void solveGemvL(const PanelDesc* panels, const
                                                   const int32_t* rowGlobal, SolveRef<T> ref) {
   const TrsmTask task = tasks[blockIdx.x];
   const PanelDesc pd = panels[task.panel];
-  const T* data = solveMat(ref);
-  T* vec = solveVec(ref);
+  GP<const T> data = solveMat(ref);
+  GP<T> vec = solveVec(ref);
   const int nb = pd.nb, lda = pd.lda, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k0 = (lane & 15) * 4, sub = lane >> 4;
-  const T* P = data + pd.diagOff + (int64_t)nb * lda;
+  GP<const T> P = data + pd.diagOff + (int64_t)nb * lda;
   T xk[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) xk[i] = k0 + i < nb ? vec[pd.vecOff + k0 + i] : T(0);
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void solveGemvL(const PanelDesc* panels, const
 #pragma unroll
   for (int it = 0; it < 4; it++) {
     const int r = wave * 16 + it * 4 + sub;
-    const T* row = P + (int64_t)(task.rowTile + r) * lda + k0;
+    GP<const T> row = P + (int64_t)(task.rowTile + r) * lda + k0;
 #pragma unroll
     for (int i = 0; i < 4; i++) p[it][i] = (r < rows && k0 + i < nb) ? row[i] : T(0);
   }
@@ -265,10 +265,10 @@ __global__ __launch_bounds__(256) void solveGemvLt(const PanelDesc* panels, cons
   __shared__ T part[4][kPanelWidth];
   const TrsmTask task = tasks[blockIdx.x];
   const PanelDesc pd = panels[task.panel];
-  const T* data = solveMat(ref);
-  T* vec = solveVec(ref);
+  GP<const T> data = solveMat(ref);
+  GP<T> vec = solveVec(ref);
   const int nb = pd.nb, lda = pd.lda, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const T* P = data + pd.diagOff + (int64_t)nb * lda;
+  GP<const T> P = data + pd.diagOff + (int64_t)nb * lda;
   const int rows = min(kTile, pd.rowsBelow - task.rowTile);
   T p[16], xq[16];
 #pragma unroll
