@@ -142,6 +142,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_NO_LOOKAHEAD")) lookaheadEnabled = e[0] == '0';
     if (const char* e = std::getenv("BSP_BULK_EXTRA_LDS")) bulkExtraLds = (unsigned)atoi(e);
     if (const char* e = std::getenv("BSP_FUSE_POTRF")) fusePotrf = e[0] != '0';
+    if (const char* e = std::getenv("BSP_BLOCK_SOLVE")) blockSolve = e[0] != '0';
     if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
     if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
@@ -259,6 +260,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   hipStream_t side = nullptr;
   bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
   bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
+  bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
   bool fusePotrf = true;    // next panel's potrf inside the update launch (BSP_FUSE_POTRF=0 disables)
   bool directChain = true;  // descriptor-by-value kernels on one-panel levels (BSP_DIRECT_CHAIN=0 disables)
   vector<hipEvent_t> events;
@@ -675,9 +677,54 @@ struct HipSolveCtx : SolveCtx<T> {
 
   template <bool BACKWARD>
   void denseLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::SolveRef<BT> ref) {
+    static_assert(hipk::kSolveBlock == kOuterWidth, "block solve steps = outer blocks of the plan");
     const int64_t nL = (int64_t)levels.size();
-    for (int64_t k = 0; k < nL; k++) {
-      const LevelRange& lr = levels[BACKWARD ? nL - 1 - k : k];
+    // consecutive one-panel levels that make up one outer block of a wide lump are solved as a
+    // block: 2 launches per 256 columns instead of 8
+    vector<std::pair<int64_t, int64_t>> groups;
+    for (int64_t l = 0; l < nL;) {
+      int64_t e = l + 1;
+      if (sym.blockSolve && levels[l].directPanel >= 0) {
+        const PanelDesc& p0 = plan.host.panels[levels[l].directPanel];
+        const int c0 = p0.lda - p0.nRest - p0.nb;  // column of the panel inside its lump
+        if (c0 % kOuterWidth == 0) {
+          while (e < nL && levels[e].directPanel >= 0) {
+            const PanelDesc& pe = plan.host.panels[levels[e].directPanel];
+            const int ce = pe.lda - pe.nRest - pe.nb;
+            if (pe.lump != p0.lump || ce != c0 + (int)(e - l) * kPanelWidth || ce >= c0 + kOuterWidth) {
+              break;
+            }
+            e++;
+          }
+        }
+      }
+      groups.emplace_back(l, e);
+      l = e;
+    }
+    const int64_t nG = (int64_t)groups.size();
+    for (int64_t gi = 0; gi < nG; gi++) {
+      const auto& grp = groups[BACKWARD ? nG - 1 - gi : gi];
+      if (grp.second - grp.first >= 2) {
+        const PanelDesc& first = plan.host.panels[levels[grp.first].directPanel];
+        const PanelDesc& last = plan.host.panels[levels[grp.second - 1].directPanel];
+        const int w = (int)(grp.second - 1 - grp.first) * kPanelWidth + last.nb;
+        const unsigned nT = (unsigned)((last.rowsBelow + kTile - 1) / kTile);
+        if (!BACKWARD) {
+          hipk::solveTriBlock<BT, false><<<grid(1), 256, 0, sym.stream>>>(first, w, ref);
+          if (nT) {
+            hipk::solveGemvBlockL<BT><<<grid(nT), 256, 0, sym.stream>>>(
+                first, last, w, plan.rowGlobal.as<int32_t>(), ref);
+          }
+        } else {
+          if (nT) {
+            hipk::solveGemvBlockLt<BT><<<grid(nT), 256, 0, sym.stream>>>(
+                first, last, w, plan.rowGlobal.as<int32_t>(), ref);
+          }
+          hipk::solveTriBlock<BT, true><<<grid(1), 256, 0, sym.stream>>>(first, w, ref);
+        }
+        continue;
+      }
+      const LevelRange& lr = levels[grp.first];
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
       if (!nP) continue;

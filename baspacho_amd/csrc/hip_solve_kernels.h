@@ -13,6 +13,8 @@ namespace hipk {
 
 // matrix data and right-hand sides of one launch: a single pair, or one pair per batch entry
 // (blockIdx.z); nRHS columns of a vector are ldc apart (blockIdx.y)
+constexpr int kSolveBlock = 256;  // columns per step of the wide-lump solve (= the factor's outer block)
+
 template <typename T>
 struct SolveRef {
   const T* mat;
@@ -39,6 +41,40 @@ __device__ __forceinline__ float waveSum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+// Sum N per-lane values across the 64 lanes, N sums at once: a butterfly in which every exchange
+// also halves the number of values a lane carries (N/2 + N/4 + ... + 1 + log2(64/N) shuffles
+// instead of 6 N).  The sum of v[u] ends up in the lanes with ((lane >> SHIFT) & (N-1)) == u,
+// SHIFT = 6 - log2(N); returned value = that lane's sum.
+template <typename T>
+__device__ __forceinline__ T waveSum16(T (&v)[16], int lane) {
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+  T a[8], b[4], c[2];
+#pragma unroll
+  for (int j = 0; j < 8; j++) a[j] = (b5 ? v[j + 8] : v[j]) + __shfl_xor(b5 ? v[j] : v[j + 8], 32, 64);
+#pragma unroll
+  for (int j = 0; j < 4; j++) b[j] = (b4 ? a[j + 4] : a[j]) + __shfl_xor(b4 ? a[j] : a[j + 4], 16, 64);
+#pragma unroll
+  for (int j = 0; j < 2; j++) c[j] = (b3 ? b[j + 2] : b[j]) + __shfl_xor(b3 ? b[j] : b[j + 2], 8, 64);
+  T d = (b2 ? c[1] : c[0]) + __shfl_xor(b2 ? c[0] : c[1], 4, 64);
+  d += __shfl_xor(d, 2, 64);
+  d += __shfl_xor(d, 1, 64);
+  return d;  // sum of v[(lane >> 2) & 15]
+}
+template <typename T>
+__device__ __forceinline__ T waveSum8(T (&v)[8], int lane) {
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+  T a[4], b[2];
+#pragma unroll
+  for (int j = 0; j < 4; j++) a[j] = (b5 ? v[j + 4] : v[j]) + __shfl_xor(b5 ? v[j] : v[j + 4], 32, 64);
+#pragma unroll
+  for (int j = 0; j < 2; j++) b[j] = (b4 ? a[j + 2] : a[j]) + __shfl_xor(b4 ? a[j] : a[j + 2], 16, 64);
+  T d = (b3 ? b[1] : b[0]) + __shfl_xor(b3 ? b[0] : b[1], 8, 64);
+  d += __shfl_xor(d, 4, 64);
+  d += __shfl_xor(d, 2, 64);
+  d += __shfl_xor(d, 1, 64);
+  return d;  // sum of v[(lane >> 3) & 7]
 }
 
 // ---- sparse-elimination ranges: one THREAD per (small) lump ---------------------------------
@@ -286,6 +322,178 @@ __global__ __launch_bounds__(256) void solveGemvLt(const PanelDesc* panels, cons
   if (wave == 0 && lane < nb) {
     atomicSub(vec + pd.vecOff + lane, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
   }
+}
+
+// ---- wide lumps: one outer block (up to 256 columns, <= 4 panels) per step ---------------------
+// The chain of a wide lump is one panel per level: four launches of four kernels per 256 columns.
+// These kernels take a whole outer block: K-B1 solves the block's own triangle in one workgroup
+// (x_B stays in LDS across its panels), K-B2 applies the block to the rows below it in one launch.
+// `first` = descriptor of the block's first panel, w = columns of the block.
+template <typename T>
+__device__ __forceinline__ void stageTri64(GP<const T> A, int lda, int nb, T* Ls) {
+  constexpr int NB = kPanelWidth, LD = NB + 1;
+  const int tid = threadIdx.x;
+  T v[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int e = tid + 256 * i, r = e >> 6, c = e & 63;
+    v[i] = (r < nb && c <= r) ? A[(int64_t)r * lda + c] : (r == c ? T(1) : T(0));
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int e = tid + 256 * i, r = e >> 6, c = e & 63;
+    Ls[r * LD + c] = v[i];
+  }
+}
+
+// wave 0: xs[0..nb) <- L^-1 xs (BACKWARD: L^-T), L staged by stageTri64
+template <typename T, bool BACKWARD>
+__device__ __forceinline__ void triSolve64(const T* Ls, T* xs, int nb) {
+  constexpr int NB = kPanelWidth, LD = NB + 1;
+  const int lane = threadIdx.x;
+  if (lane >= 64) return;
+  T xi = lane < nb ? xs[lane] : T(0);
+  const T inv = T(1) / Ls[lane * LD + lane];
+  if (!BACKWARD) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      const T lij = Ls[lane * LD + j];
+      const T xj = laneBcast(xi * inv, j);
+      xi = lane == j ? xj : (lane > j ? xi - lij * xj : xi);
+    }
+  } else {
+#pragma unroll
+    for (int j = NB - 1; j >= 0; j--) {
+      const T lji = Ls[j * LD + lane];
+      const T xj = laneBcast(xi * inv, j);
+      xi = lane == j ? xj : (lane < j ? xi - lji * xj : xi);
+    }
+  }
+  if (lane < nb) xs[lane] = xi;
+}
+
+// K-B1: the block's own triangle, one workgroup (256 threads)
+template <typename T, bool BACKWARD>
+__global__ __launch_bounds__(256) void solveTriBlock(PanelDesc first, int w, SolveRef<T> ref) {
+  constexpr int NB = kPanelWidth, LD = NB + 1;
+  __shared__ T Ls[NB * LD];
+  __shared__ T xs[kSolveBlock];
+  __shared__ T part[4][NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lda = first.lda;
+  GP<const T> A = solveMat(ref) + first.diagOff;  // (c0, c0) of the block
+  GP<T> x = solveVec(ref) + first.vecOff;
+  if (tid < w) xs[tid] = x[tid];
+  const int nq = (w + NB - 1) / NB;
+  if (!BACKWARD) {
+    for (int q = 0; q < nq; q++) {
+      const int c = q * NB, nb = min(NB, w - c);
+      stageTri64<T>(A + (int64_t)c * lda + c, lda, nb, Ls);
+      __syncthreads();
+      triSolve64<T, false>(Ls, xs + c, nb);
+      __syncthreads();
+      // rows of the block below the panel: xs[r] -= L[r, c..c+nb) . xs[c..c+nb)
+      // (wave w takes rows c+nb+w, +4, ...; 16 rows in flight per lane and round trip)
+      const T xk = lane < nb ? xs[c + lane] : T(0);
+      for (int r0 = c + nb + wave; r0 < w; r0 += 64) {
+        T p[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const int r = min(r0 + 4 * u, w - 1);
+          p[u] = lane < nb ? A[(int64_t)r * lda + c + lane] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) p[u] *= xk;
+        const T sres = waveSum16(p, lane);
+        const int ur = (lane >> 2) & 15;
+        if ((lane & 3) == 0 && r0 + 4 * ur < w) xs[r0 + 4 * ur] -= sres;
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int q = nq - 1; q >= 0; q--) {
+      const int c = q * NB, nb = min(NB, w - c);
+      stageTri64<T>(A + (int64_t)c * lda + c, lda, nb, Ls);
+      // xs[c + k] -= sum over the block rows r below the panel of L[r, c + k] * xs[r]
+      T acc = T(0);
+      for (int r0 = c + nb + wave; r0 < w; r0 += 64) {
+        T p[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const int r = min(r0 + 4 * u, w - 1);
+          p[u] = lane < nb ? A[(int64_t)r * lda + c + lane] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc += (r0 + 4 * u < w) ? p[u] * xs[min(r0 + 4 * u, w - 1)] : T(0);
+      }
+      part[wave][lane] = acc;
+      __syncthreads();
+      if (wave == 0 && lane < nb) {
+        xs[c + lane] -= part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+      }
+      __syncthreads();
+      triSolve64<T, true>(Ls, xs + c, nb);
+      __syncthreads();
+    }
+  }
+  if (tid < w) x[tid] = xs[tid];
+}
+
+// K-B2 forward: rows below the block, 64 rows per workgroup: x[target(q)] -= L[row q, block] . x_B
+// (`last` = descriptor of the block's last panel: its below-rows are the block's below-rows)
+template <typename T>
+__global__ __launch_bounds__(256) void solveGemvBlockL(PanelDesc first, PanelDesc last, int w,
+                                                       const int32_t* rowGlobal, SolveRef<T> ref) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lda = first.lda;
+  GP<const T> A = solveMat(ref) + first.diagOff + (int64_t)w * lda;  // first row below, col c0
+  GP<T> vec = solveVec(ref);
+  T xk[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) xk[i] = lane + 64 * i < w ? vec[first.vecOff + lane + 64 * i] : T(0);
+  const int rowTile = blockIdx.x * kTile;
+  const int rows = min(kTile, last.rowsBelow - rowTile);
+  for (int r0 = wave * 16; r0 < wave * 16 + 16; r0 += 8) {
+    T p[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      GP<const T> row = A + (int64_t)(rowTile + min(r0 + u, rows - 1)) * lda;
+#pragma unroll
+      for (int i = 0; i < 4; i++) p[u][i] = lane + 64 * i < w ? row[lane + 64 * i] : T(0);
+    }
+    T d[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      d[u] = p[u][0] * xk[0] + p[u][1] * xk[1] + p[u][2] * xk[2] + p[u][3] * xk[3];
+    }
+    const T sres = waveSum8(d, lane);
+    const int ur = (lane >> 3) & 7;
+    if ((lane & 7) == 0 && r0 + ur < rows) {
+      atomicSub(vec + solveTargetRow(last, rowGlobal, rowTile + r0 + ur), sres);
+    }
+  }
+}
+
+// K-B2 backward: x_B[k] -= sum over a 64-row tile of L[row q, c0 + k] * x[target(q)]; thread = k
+template <typename T>
+__global__ __launch_bounds__(256) void solveGemvBlockLt(PanelDesc first, PanelDesc last, int w,
+                                                        const int32_t* rowGlobal, SolveRef<T> ref) {
+  __shared__ T xq[kTile];
+  const int tid = threadIdx.x, lda = first.lda;
+  GP<const T> A = solveMat(ref) + first.diagOff + (int64_t)w * lda;
+  GP<T> vec = solveVec(ref);
+  const int rowTile = blockIdx.x * kTile;
+  const int rows = min(kTile, last.rowsBelow - rowTile);
+  if (tid < kTile) xq[tid] = tid < rows ? vec[solveTargetRow(last, rowGlobal, rowTile + tid)] : T(0);
+  __syncthreads();
+  T acc = T(0);
+  const int k = min(tid, w - 1);
+  for (int r0 = 0; r0 < rows; r0 += 16) {
+    T p[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) p[u] = A[(int64_t)(rowTile + min(r0 + u, rows - 1)) * lda + k];
+#pragma unroll
+    for (int u = 0; u < 16; u++) acc += (r0 + u < rows) ? p[u] * xq[min(r0 + u, kTile - 1)] : T(0);
+  }
+  if (tid < w) atomicSub(vec + first.vecOff + tid, acc);
 }
 
 }  // namespace hipk
