@@ -66,13 +66,17 @@ struct DevPlan {
   // forward-solve gather lists, built on the first solve that needs them
   bool solveGatherReady = false;
   SolveGatherPlan solveGather;
-  DevBuf solveEntries, solveItems;
+  DevBuf solveEntries, solveItems, solveLumpBlocks, solveLumpDescs;
   void ensureSolveGather(const CoalescedBlockMatrixSkel& skel) {
     if (solveGatherReady) return;
     solveGather = buildSolveGather(skel, host);
     solveEntries.upload(solveGather.entries);
     solveItems.upload(solveGather.items);
+    solveLumpBlocks.upload(solveGather.lumpBlocks);
+    solveLumpDescs.upload(solveGather.lumpDescs);
     vector<SolveGatherEntry>().swap(solveGather.entries);
+    vector<SolveLumpBlock>().swap(solveGather.lumpBlocks);
+    vector<SolveLumpDesc>().swap(solveGather.lumpDescs);
     solveGatherReady = true;
   }
   void upload() {
@@ -651,11 +655,19 @@ struct HipSolveCtx : SolveCtx<T> {
     if (nLumps <= 0) return;
     auto small = [&] {
       const dim3 gL = grid((unsigned)((nLumps + 255) / 256));
+      plan.ensureSolveGather(sym.skel);
       if (BACKWARD) {
-        hipk::solveElimSmall<BT, true><<<gL, 256, 0, sym.stream>>>(sk, ref, er.lumpBegin, er.lumpEnd);
+        if (er.maxWidth <= 4) {
+          const int64_t d0 = plan.solveGather.rangeLumpDesc[&er - plan.host.elimRanges.data()];
+          hipk::solveElimLumpsLt<BT><<<grid((unsigned)((nLumps + 15) / 16)), 256, 0, sym.stream>>>(
+              plan.solveLumpDescs.as<SolveLumpDesc>() + d0, plan.solveLumpBlocks.as<SolveLumpBlock>(),
+              ref, (int)nLumps);
+        } else {
+          hipk::solveElimSmall<BT, true><<<gL, 256, 0, sym.stream>>>(sk, ref, er.lumpBegin,
+                                                                    er.lumpEnd);
+        }
         return;
       }
-      plan.ensureSolveGather(sym.skel);
       const auto items = plan.solveGather.rangeItems[&er - plan.host.elimRanges.data()];
       hipk::solveElimDiagL<BT><<<gL, 256, 0, sym.stream>>>(sk, ref, er.lumpBegin, er.lumpEnd);
       if (items.second > items.first) {

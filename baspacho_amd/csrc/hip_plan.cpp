@@ -852,13 +852,37 @@ SolveGatherPlan buildSolveGather(const CoalescedBlockMatrixSkel& sk, const HipPl
     });
     for (int64_t s = 0; s < nSpans; s++) {
       for (int64_t b = count[s]; b < count[s + 1]; b += 256) {
-        out.items.push_back({(int32_t)(entryBase + b),
-                             (int32_t)(entryBase + std::min(b + 256, count[s + 1])),
+        const int64_t bEnd = std::min(b + 256, count[s + 1]);
+        int32_t maxN = 0;
+        for (int64_t q = b; q < bEnd; q++) maxN = std::max(maxN, out.entries[entryBase + q].n);
+        out.items.push_back({(int32_t)(entryBase + b), (int32_t)(entryBase + bEnd),
                              (int32_t)sk.spanStart[s],
-                             (int32_t)(sk.spanStart[s + 1] - sk.spanStart[s])});
+                             (int32_t)(sk.spanStart[s + 1] - sk.spanStart[s]), maxN, 0});
       }
     }
     out.rangeItems.emplace_back(itemBegin, (int64_t)out.items.size());
+    // lump-major lists for the backward pass
+    out.rangeLumpDesc.push_back((int64_t)out.lumpDescs.size());
+    for (int64_t l = er.lumpBegin; l < er.lumpEnd; l++) {
+      const int64_t n = sk.lumpStart[l + 1] - sk.lumpStart[l];
+      const int64_t c0 = sk.chainColPtr[l], cEnd = sk.chainColPtr[l + 1];
+      const int64_t diagCh = sk.boardChainColOrd[sk.boardColPtr[l] + 1];
+      SolveLumpDesc d{};
+      d.diagOff = sk.chainData[c0];
+      d.blockBegin = (int32_t)out.lumpBlocks.size();
+      if (n <= kElimSmallMax) {
+        for (int64_t c = c0 + diagCh; c < cEnd; c++) {
+          const int64_t span = sk.chainRowSpan[c];
+          out.lumpBlocks.push_back({sk.chainData[c], (int32_t)sk.spanStart[span],
+                                    (int32_t)(sk.spanStart[span + 1] - sk.spanStart[span])});
+        }
+      }
+      d.blockEnd = (int32_t)out.lumpBlocks.size();
+      d.xOff = (int32_t)sk.lumpStart[l];
+      d.n = (int32_t)n;
+      out.lumpDescs.push_back(d);
+    }
+    BASPACHO_CHECK_LT((int64_t)out.lumpBlocks.size(), (int64_t)1 << 31);
   }
   return out;
 }

@@ -235,11 +235,28 @@ struct SolveGatherEntry {
 struct SolveGatherItem {
   int32_t entryBegin, entryEnd;  // <= 256 entries
   int32_t rowStart, rows;        // target span in the vector
+  int32_t maxN, pad;             // widest source lump among the entries
+};
+// Backward solve over a range of <= 4-wide eliminated lumps (K-S3): the same blocks in their
+// natural (lump-major) order, with the position of their rows in the vector, so that the kernel
+// needs no skeleton lookups
+struct SolveLumpBlock {
+  int64_t dataOff;  // data offset of the block (rows x n, row-major)
+  int32_t yOff;     // first row of the block's span in the vector
+  int32_t rows;
+};
+struct SolveLumpDesc {
+  int64_t diagOff;              // data offset of the n x n diagonal block
+  int32_t blockBegin, blockEnd; // into the SolveLumpBlock list
+  int32_t xOff, n;              // position in the vector, width
 };
 struct SolveGatherPlan {
   std::vector<SolveGatherEntry> entries;
   std::vector<SolveGatherItem> items;
   std::vector<std::pair<int64_t, int64_t>> rangeItems;  // item range of every elimination range
+  std::vector<SolveLumpBlock> lumpBlocks;
+  std::vector<SolveLumpDesc> lumpDescs;                  // one per lump of every range, in order
+  std::vector<int64_t> rangeLumpDesc;                    // first SolveLumpDesc of every range
 };
 SolveGatherPlan buildSolveGather(const CoalescedBlockMatrixSkel& skel, const HipPlanHost& plan);
 

@@ -163,13 +163,54 @@ template <typename T>
 __global__ __launch_bounds__(256) void solveElimGatherL(const SolveGatherItem* items,
                                                         const SolveGatherEntry* entries,
                                                         SolveRef<T> ref) {
-  __shared__ T part[4];
+  __shared__ T part[4][16];
   const SolveGatherItem it = items[blockIdx.x];
   GP<const T> data = solveMat(ref);
   GP<T> vec = solveVec(ref);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (it.rows <= 16 && it.maxN <= 4) {
+    // matrix-core path: per block ONE 8-byte load per lane -- lane (i, k) = (lane & 15, lane >> 4)
+    // fetches B[i][k], the lanes together read the contiguous block -- and one v_mfma 16x16x4
+    // whose B operand carries x_lump in column 0; the sum over the wave's blocks stays in the
+    // accumulator (the thread-per-block loop below re-reads every cache line n x rows times)
+    using Acc = typename Mfma<T>::Acc;
+    constexpr int U = 8;
+    const int li = lane & 15, lk = lane >> 4;
+    Acc acc = {0, 0, 0, 0};
+    const int e0 = it.entryBegin + 64 * wave;
+    const int cnt = min(64, it.entryEnd - e0);
+    SolveGatherEntry en = {0, 0, 0};
+    if (lane < cnt) en = entries[e0 + lane];
+    const int offLo = (int)(uint32_t)en.dataOff, offHi = (int)(en.dataOff >> 32);
+    for (int t0 = 0; t0 < cnt; t0 += U) {
+      T a[U], b[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = min(t0 + u, cnt - 1);
+        const int64_t off = ((int64_t)__builtin_amdgcn_readlane(offHi, t) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane(offLo, t);
+        const int xo = __builtin_amdgcn_readlane(en.xOff, t);
+        const int n = __builtin_amdgcn_readlane(en.n, t);
+        const bool okA = li < it.rows && lk < n, okB = li == 0 && lk < n;
+        a[u] = okA ? data[off + li * n + lk] : T(0);
+        b[u] = okB ? vec[xo + lk] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (t0 + u < cnt) acc = Mfma<T>::run(a[u], b[u], acc);  // wave-uniform
+      }
+    }
+    if (li == 0) {  // column 0 of the product: rows Mfma::row(lane, g)
+#pragma unroll
+      for (int g = 0; g < 4; g++) part[wave][Mfma<T>::row(lane, g)] = acc[g];
+    }
+    __syncthreads();
+    const int r = threadIdx.x;
+    if (r < it.rows) atomicSub(vec + it.rowStart + r, part[0][r] + part[1][r] + part[2][r] + part[3][r]);
+    return;
+  }
   const int e = it.entryBegin + (int)threadIdx.x;
   const bool live = e < it.entryEnd;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int n = 0;
   GP<const T> B = data;
   T x[kElimSmallMax];
@@ -184,11 +225,66 @@ __global__ __launch_bounds__(256) void solveElimGatherL(const SolveGatherItem* i
     T s = T(0);
     for (int k = 0; k < n; k++) s += B[r * n + k] * x[k];
     s = waveSum(s);
-    if (lane == 0) part[wave] = s;
+    if (lane == 0) part[wave][0] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicSub(vec + it.rowStart + r, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) {
+      atomicSub(vec + it.rowStart + r, part[0][0] + part[1][0] + part[2][0] + part[3][0]);
+    }
     __syncthreads();
   }
+}
+
+// K-S3: backward pass over a range of <= 4-wide lumps: x_l <- L_ll^-T (x_l - sum_blocks B^T y).
+// 16 lanes per lump (four lumps per wave): lane (k, ip) = (sub & 3, sub >> 2) walks rows
+// ip, ip+4, ... of every block and column k, so that the 16 lanes read 12 consecutive values per
+// step; the blocks come from a lump-major descriptor list (no skeleton lookups: thread-per-lump
+// K-S0 chases five dependent index loads per block and touches every cache line rows x n times).
+template <typename T>
+__global__ __launch_bounds__(256) void solveElimLumpsLt(const SolveLumpDesc* descs,
+                                                        const SolveLumpBlock* blocks,
+                                                        SolveRef<T> ref, int numLumps) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, k = sub & 3, ip = sub >> 2;
+  const int idx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  if (idx >= numLumps) return;
+  const SolveLumpDesc ld = descs[idx];
+  const int n = ld.n;
+  if (n > 4) return;  // (wider lumps of the range: panel kernels)
+  GP<const T> data = solveMat(ref);
+  GP<T> vec = solveVec(ref);
+  const bool kOk = k < n;
+  T acc = T(0);
+  for (int e = ld.blockBegin; e < ld.blockEnd; e++) {
+    const SolveLumpBlock b = blocks[e];
+    for (int i0 = 0; i0 < b.rows; i0 += 8) {
+      const int ia = i0 + ip, ib = i0 + 4 + ip;
+      const bool oa = kOk && ia < b.rows, ob = kOk && ib < b.rows;
+      const T va = oa ? data[b.dataOff + ia * n + k] : T(0);
+      const T vb = ob ? data[b.dataOff + ib * n + k] : T(0);
+      const T ya = oa ? vec[b.yOff + ia] : T(0);
+      const T yb = ob ? vec[b.yOff + ib] : T(0);
+      acc += va * ya + vb * yb;
+    }
+  }
+  acc += __shfl_xor(acc, 4, 64);
+  acc += __shfl_xor(acc, 8, 64);  // every lane: the sum for its column k
+  // back substitution with the upper triangle L^T, redundantly in every lane of the group
+  T x[4], d[4][4];
+  const int grp = lane & 48;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const T xj = j < n ? vec[ld.xOff + j] : T(0);
+    x[j] = xj - __shfl(acc, grp + j, 64);
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[i][j] = (i < n && j <= i) ? data[ld.diagOff + i * n + j] : (i == j ? T(1) : T(0));
+  }
+#pragma unroll
+  for (int j = 3; j >= 0; j--) {
+    T sres = x[j];
+#pragma unroll
+    for (int i = j + 1; i < 4; i++) sres -= d[i][j] * x[i];
+    x[j] = sres / d[j][j];
+  }
+  if (ip == 0 && kOk) vec[ld.xOff + k] = k == 0 ? x[0] : k == 1 ? x[1] : k == 2 ? x[2] : x[3];
 }
 
 // ---- dense panels ----------------------------------------------------------------------------
