@@ -493,11 +493,11 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
           a[u] = data[oj + eA];
           b[u] = data[oi + eB];
         }
+        // (no branch per pair: pairs past the end of the list multiply zeros)
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          if (t0 + u < cnt) {  // wave-uniform
-            acc = Mfma<T>::run(okA ? a[u] : T(0), okB ? b[u] : T(0), acc);
-          }
+          const bool live = t0 + u < cnt;
+          acc = Mfma<T>::run((okA && live) ? a[u] : T(0), okB ? b[u] : T(0), acc);
         }
       }
     }
