@@ -63,6 +63,7 @@ struct DevPlan {
   DevBuf panels, srcs, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
       updTasks, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc,
       elimPairSlot, elimRows, elimRowSlots;
+  int64_t numUpdTasks = 0;
   // forward-solve gather lists, built on the first solve that needs them
   bool solveGatherReady = false;
   SolveGatherPlan solveGather;
@@ -99,6 +100,27 @@ struct DevPlan {
     elimItems.upload(host.elimItems);
     elimPairOffJ.upload(host.elimPairOffJ);
     elimPairOffI.upload(host.elimPairOffI);
+    // the launch code only needs the descriptors it passes by value and the level / range
+    // tables: release the host copies of everything that now lives on the device (BAL-871:
+    // 0.3 GB of pair offsets and task lists)
+    numUpdTasks = (int64_t)host.updTasks.size();
+    auto drop = [](auto& v) { std::decay_t<decltype(v)>().swap(v); };
+    drop(host.chainOffTab);
+    drop(host.rowChain);
+    drop(host.rowLocal);
+    drop(host.rowColOff);
+    drop(host.rowGlobal);
+    drop(host.levelPanels);
+    drop(host.trsmTasks);
+    drop(host.updTasks);
+    drop(host.elimChainLump);
+    drop(host.elimLumpDesc);
+    drop(host.elimPairSlot);
+    drop(host.elimRows);
+    drop(host.elimRowSlots);
+    drop(host.elimItems);
+    drop(host.elimPairOffJ);
+    drop(host.elimPairOffI);
   }
 };
 
@@ -570,7 +592,7 @@ struct HipNumericCtx : NumericCtx<T> {
     sym.gemmCalls++;
     // temp := -(P P^T) on the lower trapezoid (the strictly upper part of the leading m x m block
     // "doesn't matter", MatOps.h:129); assemble() adds it
-    launchUpdate(plan, 0, (int64_t)plan.host.updTasks.size(), makeRef(const_cast<T*>(data)),
+    launchUpdate(plan, 0, plan.numUpdTasks, makeRef(const_cast<T*>(data)),
                  sym.stream, temp.as<BT>() ? const_cast<BT*>(temp.as<BT>()) : nullptr, tempBufSize);
     hipCHECK(hipGetLastError());
   }
