@@ -417,10 +417,17 @@ struct HipNumericCtx : NumericCtx<T> {
         }
         sideUsed = true;
       }
-      if (!lookahead && lr.defEnd > lr.defBegin) {
-        timer.begin(kProfUpdate);
-        launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.stream);
-        timer.end();
+      if (!lookahead) {  // (the same two launches as the lookahead schedule, on the main stream)
+        if (lr.defMid > lr.defBegin) {
+          timer.begin(kProfUpdate);
+          launchUpdate(plan, lr.defBegin, lr.defMid, ref, sym.stream);
+          timer.end();
+        }
+        if (lr.defEnd > lr.defMid) {
+          timer.begin(kProfUpdate);
+          launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.stream);
+          timer.end();
+        }
       }
     }
     if (sideUsed) {  // join: everything on the side stream happens-before what follows
