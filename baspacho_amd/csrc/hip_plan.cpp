@@ -4,7 +4,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <iostream>
+#include <atomic>
 #include <map>
+#include <thread>
 
 namespace BaSpaCho {
 
@@ -32,6 +34,32 @@ LumpCols lumpCols(const CoalescedBlockMatrixSkel& sk, int64_t l) {
 // (column l, chains i<=j) pair, bucket by target chain, order by (target span, source width) and
 // cut into work items.  Falls back (useGather=false -> atomic scatter kernel) when offsets do not
 // fit 32 bits or a target block is larger than a wave handles.
+// sort every bucket [ptr[c], ptr[c+1]) of `v` with `less`, buckets dealt to a few host threads
+// (the pair lists of a bundle-adjustment problem hold tens of millions of entries)
+template <typename V, typename Less>
+void sortBuckets(V& v, const std::vector<int64_t>& ptr, Less less) {
+  const int64_t nB = (int64_t)ptr.size() - 1;
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (hw == 1 || v.size() < ((size_t)1 << 16)) {
+    for (int64_t c = 0; c < nB; c++) std::sort(v.begin() + ptr[c], v.begin() + ptr[c + 1], less);
+    return;
+  }
+  std::atomic<int64_t> next{0};
+  auto work = [&] {
+    for (;;) {
+      const int64_t c0 = next.fetch_add(8);
+      if (c0 >= nB) return;
+      for (int64_t c = c0; c < std::min(nB, c0 + 8); c++) {
+        if (ptr[c + 1] > ptr[c]) std::sort(v.begin() + ptr[c], v.begin() + ptr[c + 1], less);
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < hw; t++) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+}
+
 void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, ElimRangePlan& er) {
   er.useGather = false;
   if (sk.dataSize() >= (int64_t(1) << 32)) return;
@@ -120,6 +148,9 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
     double targetElems = 0;
     int32_t maxLds = 0, maxSlots = 0;
     vector<int32_t> sis;
+    sortBuckets(sorted, bucketPtr, [](const Pair& x, const Pair& y) {
+      return x.offJ != y.offJ ? x.offJ < y.offJ : x.si < y.si;
+    });
     for (int64_t c = 0; c < nChainsTot && ok; c++) {
       const int64_t b = bucketPtr[c], e = bucketPtr[c + 1];
       if (b == e) continue;
@@ -130,9 +161,6 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
         ok = false;
         break;
       }
-      std::sort(sorted.begin() + b, sorted.begin() + e, [](const Pair& x, const Pair& y) {
-        return x.offJ != y.offJ ? x.offJ < y.offJ : x.si < y.si;
-      });
       sis.clear();
       for (int64_t k = b; k < e; k++) sis.push_back(sorted[k].si);
       std::sort(sis.begin(), sis.end());
@@ -247,12 +275,13 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   er.itemBegin = (int64_t)plan.elimItems.size();
   vector<int64_t> itemRowTag;  // target chain of every emitted item
   vector<int32_t> itemChunk;   // source-data chunk of every emitted item
+  sortBuckets(sorted, bucketPtr, [](const Pair& x, const Pair& y) {
+    return x.si != y.si ? x.si < y.si : x.width < y.width;
+  });
+  lap("sort pairs");
   for (int64_t c = 0; c < nChainsTot; c++) {
     const int64_t b = bucketPtr[c], e = bucketPtr[c + 1];
     if (b == e) continue;
-    std::sort(sorted.begin() + b, sorted.begin() + e, [](const Pair& x, const Pair& y) {
-      return x.si != y.si ? x.si < y.si : x.width < y.width;
-    });
     const int64_t sj = sk.chainRowSpan[c];
     const int64_t rows = sk.spanStart[sj + 1] - sk.spanStart[sj];
     int64_t q = b;
