@@ -446,7 +446,9 @@ struct HipNumericCtx : NumericCtx<T> {
     const unsigned gF = (unsigned)((nLumps + 3) / 4);
     timer.begin(kProfElimFactor);
     if (er.maxWidth <= 4 && sym.elimFactorDesc) {
-      hipk::elimFactorTiny<BT><<<dim3(gF, gy), 256, 0, sym.stream>>>(
+      const int64_t perWg = 4 * hipk::kTinyPerWave;
+      hipk::elimFactorTiny<BT><<<dim3((unsigned)((nLumps + perWg - 1) / perWg), gy), 256, 0,
+                                sym.stream>>>(
           plan.elimLumpDesc.as<ElimLumpDesc>() + er.descBegin, ref, (int)nLumps);
     } else if (er.maxWidth <= 4) {
       hipk::elimFactorSmall<BT, 4><<<dim3(gF, gy), 256, 0, sym.stream>>>(sk, ref, er.lumpBegin,

@@ -166,11 +166,15 @@ __global__ __launch_bounds__(256) void elimFactorSmall(SkelDev sk, DataRef<T> dr
 // lane's row in flight together; the n x n Cholesky runs redundantly in every lane's registers
 // (hardware rsq + Newton, no LDS, no wave synchronisation, no division).  K1 spends ~7 dependent
 // memory round trips per wave and is latency bound at 2 TB/s.
+constexpr int kTinyPerWave = 4, kTinyPasses = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs, DataRef<T> dref,
                                                       int numLumps) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * 4 + wave;
+  // kTinyPerWave lumps per wave (64 / kTinyPerWave lanes each), kTinyPasses rows per lane in
+  // flight: the kernel is bound by the bytes in flight per wave slot, not by bandwidth
+  constexpr int G = 64 / kTinyPerWave, NPASS = kTinyPasses;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & (G - 1);
+  const int idx = (blockIdx.x * 4 + wave) * kTinyPerWave + lane / G;
   if (idx >= numLumps) return;
   const ElimLumpDesc ld = descs[idx];
   const int n = ld.n;
@@ -187,13 +191,14 @@ __global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs,
       a[i][j] = (i < n && j < n) ? v : (i == j ? T(1) : T(0));
     }
   }
-  // first pass of rows of this lane
-  T x[4];
-  const bool has = lane < ld.rowsBelow;
-  {
-    GP<const T> row = B + (int64_t)(has ? lane : 0) * n;
+  // the first passes of rows of this lane (rows sub, sub + G, ...)
+  T x[NPASS][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) x[j] = row[min(j, n - 1)];
+  for (int p = 0; p < NPASS; p++) {
+    const int r = sub + G * p;
+    GP<const T> row = B + (int64_t)(r < ld.rowsBelow ? r : 0) * n;
+#pragma unroll
+    for (int j = 0; j < 4; j++) x[p][j] = row[min(j, n - 1)];
   }
   // Cholesky in registers: l[i][j], inv[j] = 1 / l[j][j]
   T inv[4];
@@ -212,31 +217,40 @@ __global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs,
       a[i][j] = s * inv[j];
     }
   }
-  // write the factor of the diagonal block: lane e holds entry e = i * n + j
+  // write the factor of the diagonal block: lane e of the half holds entry e = i * n + j
 #pragma unroll
   for (int i = 0; i < 4; i++) {
 #pragma unroll
     for (int j = 0; j <= i; j++) {
-      if (i < n && lane == i * n + j) D[i * n + j] = a[i][j];
+      if (i < n && sub == i * n + j) D[i * n + j] = a[i][j];
     }
   }
   // rows below: x * L^T = b
-  for (int r = lane; r < ld.rowsBelow; r += 64) {
-    GP<T> row = B + (int64_t)r * n;
-    if (r != lane) {
+  for (int r0 = sub; r0 < ld.rowsBelow; r0 += G * NPASS) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) x[j] = row[min(j, n - 1)];
-    }
+    for (int p = 0; p < NPASS; p++) {
+      const int r = r0 + G * p;
+      if (r >= ld.rowsBelow) continue;
+      GP<T> row = B + (int64_t)r * n;
+      T y[4];
+      if (r0 == sub) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      T s = x[j];
+        for (int j = 0; j < 4; j++) y[j] = x[p][j];
+      } else {
 #pragma unroll
-      for (int i = 0; i < j; i++) s -= x[i] * a[j][i];
-      x[j] = s * inv[j];
-    }
+        for (int j = 0; j < 4; j++) y[j] = row[min(j, n - 1)];
+      }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (j < n) row[j] = x[j];
+      for (int j = 0; j < 4; j++) {
+        T s = y[j];
+#pragma unroll
+        for (int i = 0; i < j; i++) s -= y[i] * a[j][i];
+        y[j] = s * inv[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (j < n) row[j] = y[j];
+      }
     }
   }
 }
