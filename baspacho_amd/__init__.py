@@ -359,6 +359,22 @@ class Solver:
     def solveLtFrom(self, mat, span_index, vec, stride=None, nRHS=1):
         self._solve_partial(3, mat, span_index, vec, stride, nRHS)
 
+    def addMvFrom(self, mat, span_index, vec_in, in_stride, vec_out, out_stride, nRHS=1, alpha=1.0):
+        """Solver::addMvFrom: out += alpha * A * in on the block from span_index on"""
+        self._check_data(mat)
+        sfx = _suffix(mat)
+        a = ctypes.c_double(alpha) if sfx == "f64" else ctypes.c_float(alpha)
+        _check(getattr(self._lib, "bsp_add_mv_from_" + sfx)(
+            self._h, ctypes.c_void_p(_ptr_of(mat)), ctypes.c_int64(span_index),
+            ctypes.c_void_p(_ptr_of(vec_in)), ctypes.c_int64(in_stride),
+            ctypes.c_void_p(_ptr_of(vec_out)), ctypes.c_int64(out_stride), ctypes.c_int32(nRHS), a))
+
+    def pseudoFactorFrom(self, data, span_index):
+        """Solver::pseudoFactorFrom: per-span diagonal Cholesky + division of the rows below"""
+        self._check_data(data)
+        _check(getattr(self._lib, "bsp_pseudo_factor_from_" + _suffix(data))(
+            self._h, ctypes.c_void_p(_ptr_of(data)), ctypes.c_int64(span_index)))
+
     # ---- measurement --------------------------------------------------------------------
     def factorFlops(self):
         return float(self._lib.bsp_factor_flops(self._h))

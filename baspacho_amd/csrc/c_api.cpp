@@ -317,6 +317,31 @@ int bsp_solve_partial_f32(bsp_solver* s, const float* m, float* v, int64_t strid
   BSP_CATCH
 }
 
+int bsp_add_mv_from_f64(bsp_solver* s, const double* m, int64_t span, const double* in,
+                        int64_t in_stride, double* out, int64_t out_stride, int32_t nrhs,
+                        double alpha) {
+  BSP_TRY
+  s->solver->addMvFrom(m, span, in, in_stride, out, out_stride, nrhs, alpha);
+  BSP_CATCH
+}
+int bsp_add_mv_from_f32(bsp_solver* s, const float* m, int64_t span, const float* in,
+                        int64_t in_stride, float* out, int64_t out_stride, int32_t nrhs,
+                        float alpha) {
+  BSP_TRY
+  s->solver->addMvFrom(m, span, in, in_stride, out, out_stride, nrhs, alpha);
+  BSP_CATCH
+}
+int bsp_pseudo_factor_from_f64(bsp_solver* s, double* d, int64_t span) {
+  BSP_TRY
+  s->solver->pseudoFactorFrom(d, span);
+  BSP_CATCH
+}
+int bsp_pseudo_factor_from_f32(bsp_solver* s, float* d, int64_t span) {
+  BSP_TRY
+  s->solver->pseudoFactorFrom(d, span);
+  BSP_CATCH
+}
+
 // batched solve: which = 0 solve, 1 solveL, 2 solveLt
 template <typename T>
 static void solveBatched(bsp_solver* s, const T* const* mats, T* const* vecs, int32_t batch,

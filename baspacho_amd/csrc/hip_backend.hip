@@ -623,9 +623,18 @@ struct HipNumericCtx : NumericCtx<T> {
     hipCHECK(hipGetLastError());
   }
 
-  virtual void pseudoFactorSpans(T*, int64_t, int64_t) override {
-    throw std::runtime_error("HIP backend: pseudoFactorSpans is not on the factor() path and is "
-                             "not available (SURVEY.md section 8f)");
+  virtual void pseudoFactorSpans(T* data, int64_t spanBegin, int64_t spanEnd) override {
+    if (spanEnd <= spanBegin) return;
+    for (int64_t s = spanBegin; s < spanEnd; s++) {
+      if (sym.skel.spanStart[s + 1] - sym.skel.spanStart[s] > kElimSmallMax) {
+        throw std::runtime_error("HIP backend: pseudoFactorSpans supports spans of up to " +
+                                 std::to_string(kElimSmallMax) + " columns");
+      }
+    }
+    hipk::pseudoFactorSpansKernel<BT><<<dim3((unsigned)((spanEnd - spanBegin + 3) / 4),
+                                             (unsigned)batchSize), 256, 0, sym.stream>>>(
+        sym.skelDev(), makeRef(data), spanBegin, spanEnd);
+    hipCHECK(hipGetLastError());
   }
 
   HipSymbolicCtx& sym;
@@ -815,6 +824,36 @@ struct HipSolveCtx : SolveCtx<T> {
     hipCHECK(hipGetLastError());
   }
 
+  virtual void addMvRange(const T* data, int64_t startLump, int64_t upToLump, const T* in,
+                          int64_t inStride, T* out, int64_t outStride, BaseType<T> alpha) override {
+    addMvImpl(data, startLump, upToLump, in, inStride, out, outStride, alpha);
+  }
+  // (single-matrix types only; the batch types have no addMvFrom in the reference either)
+  void addMvImpl(const BT* data, int64_t startLump, int64_t upToLump, const BT* in,
+                 int64_t inStride, BT* out, int64_t outStride, BT alpha) {
+    const CoalescedBlockMatrixSkel& sk = sym.skel;
+    vector<int64_t> tiles;
+    for (int64_t l = startLump; l < upToLump; l++) {
+      const int64_t c0 = sk.chainColPtr[l], nCh = sk.chainColPtr[l + 1] - c0;
+      const int64_t rows = sk.chainRowsTillEnd[c0 + nCh - 1];
+      for (int64_t r = 0; r < rows; r += kTile) {
+        tiles.push_back(l);
+        tiles.push_back(r);
+      }
+    }
+    if (tiles.empty()) return;
+    addMvTiles.upload(tiles);
+    hipk::addMvKernel<BT><<<dim3((unsigned)(tiles.size() / 2), (unsigned)nRHS), 256, 0,
+                            sym.stream>>>(sym.skelDev(), addMvTiles.as<int64_t>(), data, in,
+                                          inStride, out, outStride, alpha);
+    hipCHECK(hipGetLastError());
+  }
+  template <typename V>
+  void addMvImpl(const vector<V*>*, int64_t, int64_t, const vector<V*>*, int64_t, vector<V*>*,
+                 int64_t, V) {
+    throw std::runtime_error("HIP backend: addMvFrom is defined for single matrices only");
+  }
+
   [[noreturn]] static void perOp(const char* what) {
     throw std::runtime_error(std::string("HIP backend: per-op ") + what +
                              " is not exposed; use solve()/solveL()/solveLt() (fused path)");
@@ -831,7 +870,7 @@ struct HipSolveCtx : SolveCtx<T> {
 
   HipSymbolicCtx& sym;
   int nRHS, batch;
-  DevBuf devMats, devVecs;
+  DevBuf devMats, devVecs, addMvTiles;
 };
 
 template <>

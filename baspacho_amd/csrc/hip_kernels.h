@@ -1538,6 +1538,78 @@ __global__ __launch_bounds__(256) void mfmaF64Probe(double* out, int iters) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K8  pseudo-factor of spans (NumericCtx::pseudoFactorSpans, MatOps.h:117; factor_spans_kernel,
+// MatOpsCuda.cu:188-233; CPU: factorSpan, MatOpsCpuBase.h:185-210): for every span s of the range,
+// in-place Cholesky of its diagonal block and  rows_below <- rows_below * L_ss^-T  on the span's
+// columns (the rest of its lump's diagonal block and every chain row below).  One wave per span
+// (spans are parameter blocks: a few columns), the block in LDS, lanes over the rows below.
+// Not on the factor() path: block-Jacobi / Gauss-Seidel preconditioners use it.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pseudoFactorSpansKernel(SkelDev sk, DataRef<T> dref,
+                                                               int64_t spanBegin, int64_t spanEnd) {
+  constexpr int NMAX = kElimSmallMax, LD = NMAX + 1;
+  __shared__ T diagS[4][NMAX * LD];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t s = spanBegin + (int64_t)blockIdx.x * 4 + wave;
+  if (s >= spanEnd) return;
+  const int64_t lump = sk.spanToLump[s];
+  const int n = (int)(sk.spanStart[s + 1] - sk.spanStart[s]);
+  const int64_t off = sk.spanOffsetInLump[s];
+  int64_t first = s;  // first span of the lump
+  while (sk.spanOffsetInLump[first] != 0) first--;
+  const int64_t idxInLump = s - first;
+  const int64_t lda = sk.lumpStart[lump + 1] - sk.lumpStart[lump];
+  const int64_t c0 = sk.chainColPtr[lump], nCh = sk.chainColPtr[lump + 1] - c0;
+  GP<T> data = pickData(dref);
+  GP<T> D = data + sk.chainData[c0 + idxInLump] + off;
+  GP<T> B = data + sk.chainData[c0 + idxInLump + 1] + off;
+  const int64_t rowsBelow = sk.chainRowsTillEnd[c0 + nCh - 1] - sk.chainRowsTillEnd[c0 + idxInLump];
+  T* S = diagS[wave];
+  for (int e = lane; e < n * n; e += 64) {
+    const int i = e / n, j = e - i * n;
+    S[i * LD + j] = D[(int64_t)i * lda + j];
+  }
+  waveSync();
+  for (int j = 0; j < n; j++) {
+    const T d = sqrt(S[j * LD + j]);
+    waveSync();
+    if (lane == 0) S[j * LD + j] = d;
+    if (lane > j && lane < n) S[lane * LD + j] /= d;
+    waveSync();
+    const int rem = n - j - 1;
+    for (int e = lane; e < rem * rem; e += 64) {
+      const int a = e / rem, b = e - a * rem;
+      if (b <= a) S[(j + 1 + a) * LD + (j + 1 + b)] -= S[(j + 1 + a) * LD + j] * S[(j + 1 + b) * LD + j];
+    }
+    waveSync();
+  }
+  for (int e = lane; e < n * n; e += 64) {
+    const int i = e / n, j = e - i * n;
+    if (j <= i) D[(int64_t)i * lda + j] = S[i * LD + j];
+  }
+  for (int64_t r = lane; r < rowsBelow; r += 64) {
+    GP<T> row = B + r * lda;
+    T x[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; j++) x[j] = j < n ? row[j] : T(0);
+#pragma unroll
+    for (int j = 0; j < NMAX; j++) {
+      if (j < n) {
+        T sres = x[j];
+#pragma unroll
+        for (int i = 0; i < j; i++) sres -= x[i] * S[j * LD + i];
+        x[j] = sres / S[j * LD + j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NMAX; j++) {
+      if (j < n) row[j] = x[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Per-op boundary (NumericCtx::prepareAssemble / assemble, MatOps.h:132-135).  The fused path never
 // uses these; they let the reference's own driver loop (Solver.cpp:198-218) run on this backend.
 // ------------------------------------------------------------------------------------------

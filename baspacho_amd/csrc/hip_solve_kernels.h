@@ -592,5 +592,55 @@ __global__ __launch_bounds__(256) void solveGemvBlockLt(PanelDesc first, PanelDe
   if (tid < w) atomicSub(vec + first.vecOff + tid, acc);
 }
 
+// ---- Solver::addMvFrom (Solver.cpp:400-449): out += alpha * A * in on the trailing block from a
+// lump on, A symmetric with its lower blocks in skeleton layout.  One workgroup per (lump, 64 rows
+// of its column): a wave per row, lanes over the lump's columns; a row adds  A[r,:] . in[cols]
+// to out[r] and  A[r,j] * in[r]  to out[col j] (strictly-lower part inside the diagonal block).
+// Replaces the symm / gemv / assembleVec / assembleVecT / gemvT sequence of the reference.
+template <typename T>
+__global__ __launch_bounds__(256) void addMvKernel(SkelDev sk, const int64_t* lumpRowTile,
+                                                   const T* mat, const T* in, int64_t inStride,
+                                                   T* out, int64_t outStride, T alpha) {
+  // lumpRowTile: pairs (lump, first row of the tile within the lump column)
+  const int64_t lump = lumpRowTile[2 * blockIdx.x], r0 = lumpRowTile[2 * blockIdx.x + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t ls = sk.lumpStart[lump], n = sk.lumpStart[lump + 1] - ls;
+  const int64_t c0 = sk.chainColPtr[lump], nCh = sk.chainColPtr[lump + 1] - c0;
+  const int64_t totalRows = sk.chainRowsTillEnd[c0 + nCh - 1];
+  const T* A = mat + sk.chainData[c0];
+  const T* x = in + (int64_t)blockIdx.y * inStride;
+  T* y = out + (int64_t)blockIdx.y * outStride;
+  for (int64_t r = r0 + wave; r < min(r0 + (int64_t)kTile, totalRows); r += 4) {
+    // global row index of row r of the column: inside the diagonal block, or through the chains
+    int64_t gr;
+    if (r < n) {
+      gr = ls + r;
+    } else {
+      int64_t lo = 0, hi = nCh;  // chainRowsTillEnd[c] > r  -> chain holding row r
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sk.chainRowsTillEnd[c0 + mid - 1] <= r) {
+          lo = mid;
+        } else {
+          hi = mid;
+        }
+      }
+      const int64_t span = sk.chainRowSpan[c0 + lo];
+      gr = sk.spanStart[span] + (r - sk.chainRowsTillEnd[c0 + lo - 1]);
+    }
+    const T xr = x[gr];
+    T dot = T(0);
+    for (int64_t j = lane; j < n; j += 64) {
+      const bool inDiag = r < n;
+      if (inDiag && j > r) continue;  // upper part of the diagonal block: not stored
+      const T a = A[r * n + j];
+      dot += a * x[ls + j];
+      if (!(inDiag && j == r)) unsafeAtomicAdd(y + ls + j, alpha * a * xr);
+    }
+    dot = waveSum(dot);
+    if (lane == 0) unsafeAtomicAdd(y + gr, alpha * dot);
+  }
+}
+
 }  // namespace hipk
 }  // namespace BaSpaCho

@@ -204,6 +204,13 @@ struct SolveCtx : SolveCtxBase {
                             int64_t /*ldc*/) {
     throw std::runtime_error("solveLtRange: not supported by this backend");
   }
+  // extension (fused Solver::addMvFrom): out += alpha * A * in for the symmetric trailing block
+  // made of the lump columns [startLump, upToLump)
+  virtual void addMvRange(const T*, int64_t /*startLump*/, int64_t /*upToLump*/, const T* /*in*/,
+                          int64_t /*inStride*/, T* /*out*/, int64_t /*outStride*/,
+                          BaseType<T> /*alpha*/) {
+    throw std::runtime_error("addMvRange: not supported by this backend");
+  }
 };
 
 template <typename T>

@@ -402,6 +402,34 @@ void Solver::resetStats() {
   symCtx->asmblStat.reset();
 }
 
+template <typename T>
+void Solver::addMvFrom(const T* matData, int64_t spanIndex, const T* inVecData, int64_t inStride,
+                       T* outVecData, int64_t outStride, int nRHS, BaseType<T> alpha) const {
+  SolveCtxPtr<T> slvCtx = symCtx->createSolveCtx<T>(nRHS, matData);
+  BASPACHO_CHECK_GE(spanIndex, 0);
+  BASPACHO_CHECK_LT(spanIndex, (int64_t)factorSkel.spanOffsetInLump.size());
+  BASPACHO_CHECK_EQ(factorSkel.spanOffsetInLump[spanIndex], 0);
+  const int64_t startLump = factorSkel.spanToLump[spanIndex];
+  const int64_t upToLump = (int64_t)factorSkel.lumpStart.size() - 1;
+  // (the reference's symm / gemv / assembleVec sequence, Solver.cpp:419-448, is one fused
+  //  device kernel here)
+  slvCtx->addMvRange(matData, startLump, upToLump, inVecData, inStride, outVecData, outStride,
+                     alpha);
+}
+
+template <typename T>
+void Solver::pseudoFactorFrom(T* data, int64_t spanIndex, bool /*verbose*/) const {
+  NumericCtxPtr<T> numCtx = symCtx->createNumericCtx<T>(maxElimTempSize, data);
+  numCtx->pseudoFactorSpans(data, spanIndex, factorSkel.numSpans());
+}
+
+template void Solver::addMvFrom<double>(const double*, int64_t, const double*, int64_t, double*,
+                                        int64_t, int, double) const;
+template void Solver::addMvFrom<float>(const float*, int64_t, const float*, int64_t, float*,
+                                       int64_t, int, float) const;
+template void Solver::pseudoFactorFrom<double>(double*, int64_t, bool) const;
+template void Solver::pseudoFactorFrom<float>(float*, int64_t, bool) const;
+
 #define BSP_INSTANTIATE(T)                                                                     \
   template void Solver::factor<T>(T*, bool) const;                                             \
   template void Solver::factorUpTo<T>(T*, int64_t, bool) const;                                \

@@ -61,6 +61,16 @@ class Solver {
   template <typename T>
   void solveLtFrom(const T* data, int64_t spanIndex, T* vecData, int64_t stride, int nRHS) const;
 
+  // out += alpha * A * in on the (un-factored) block from spanIndex on   (Solver.h:89-91)
+  template <typename T>
+  void addMvFrom(const T* matData, int64_t spanIndex, const T* inVecData, int64_t inStride,
+                 T* outVecData, int64_t outStride, int nRHS, BaseType<T> alpha = 1.0) const;
+
+  // pseudo-factor: Cholesky of the diagonal block of every span from spanIndex on, rows below
+  // divided by it   (Solver.h:92-94; preconditioners of the PCG example)
+  template <typename T>
+  void pseudoFactorFrom(T* data, int64_t spanIndex, bool verbose = false) const;
+
   int64_t order() const { return factorSkel.order(); }
   int64_t dataSize() const { return factorSkel.dataSize(); }
   int64_t canFactorUpToSpan() const { return canFactorUpTo; }

@@ -155,6 +155,18 @@ int bsp_solve_partial_f64(bsp_solver* s, const double* dev_mat, double* dev_vec,
                           int32_t nrhs, int32_t which, int64_t span_index);
 int bsp_solve_partial_f32(bsp_solver* s, const float* dev_mat, float* dev_vec, int64_t stride,
                           int32_t nrhs, int32_t which, int64_t span_index);
+/* Solver::addMvFrom  Solver.h:89-91: out += alpha * A * in on the symmetric block from span_index
+   (a lump boundary) to the end; vectors hold `order` rows, column-major, nRHS columns */
+int bsp_add_mv_from_f64(bsp_solver* s, const double* dev_mat, int64_t span_index,
+                        const double* dev_in, int64_t in_stride, double* dev_out,
+                        int64_t out_stride, int32_t nrhs, double alpha);
+int bsp_add_mv_from_f32(bsp_solver* s, const float* dev_mat, int64_t span_index, const float* dev_in,
+                        int64_t in_stride, float* dev_out, int64_t out_stride, int32_t nrhs,
+                        float alpha);
+/* Solver::pseudoFactorFrom  Solver.h:92-94: Cholesky of the diagonal block of every span from
+   span_index on, the rows below it divided by the factor (spans of up to 16 columns) */
+int bsp_pseudo_factor_from_f64(bsp_solver* s, double* dev_data, int64_t span_index);
+int bsp_pseudo_factor_from_f32(bsp_solver* s, float* dev_data, int64_t span_index);
 /* Solver::solve<std::vector<T*>> etc. (Solver.h:64-73 with the batch types of MatOps.h:38-42):
    `batch` factored matrices of the same structure and one block of right-hand sides each
    (host arrays of device pointers).  which: 0 = solve, 1 = solveL, 2 = solveLt */

@@ -152,6 +152,50 @@ def test_partial_solves(dtype):
             assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, ("LtFrom", i, j)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pseudo_factor_and_add_mv(dtype):
+    """PartialFactorSolveTest.cpp:296-395: pseudoFactorFrom(0) against the dense per-span
+    computation, addMvFrom(span) against the dense symmetric product on the trailing block"""
+    for i in range(6):
+        sol, _, _ = solver_random(57 + i, size=215, fill=0.03, elim=(0, 150), psize_seed=47,
+                                  pmin=2, pmax=3)
+        sk = sol.skel()
+        n = sol.order()
+        data = spd_data(sol, 9 + i, beta_factor=2.0, dtype=dtype)
+        tol = 1e-9 if dtype == np.float64 else 2e-5
+        # ---- pseudo-factor of every span
+        want = sol.densify(data.astype(np.float64), fill_upper_half=False)
+        ss_ = sk["spanStart"]
+        for j in range(sol.numSpans()):
+            a, b = int(ss_[j]), int(ss_[j + 1])
+            Ld = np.linalg.cholesky(want[a:b, a:b])
+            want[a:b, a:b] = Ld
+            want[b:, a:b] = np.linalg.solve(Ld, want[b:, a:b].T).T
+        d = to_dev(data)
+        sol.pseudoFactorFrom(d, 0)
+        got = lower_of(sol, d.cpu().numpy())
+        want = np.tril(want)
+        # (only blocks present in the skeleton exist in `got`; the dense computation fills none in)
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < tol, ("pseudo", i)
+        # ---- addMvFrom on the trailing block
+        ranges = sol.sparseEliminationRanges()
+        dense_from = int(ranges[-1]) if len(ranges) else 0
+        lump = dense_from + (7 * i) % max(1, sol.numLumps() - dense_from)
+        span = int(sk["lumpToSpan"][lump])
+        bar = int(ss_[span])
+        A = sol.densify(data.astype(np.float64), fill_upper_half=True)
+        nrhs = 3
+        vin = T.random_data(n * nrhs, -1.0, 1.0, 49 + i)
+        vout = T.random_data(n * nrhs, -1.0, 1.0, 149 + i)
+        ref = vout.reshape(nrhs, n).T.copy()
+        ref[bar:] += 0.75 * (A[bar:, bar:] @ vin.reshape(nrhs, n).T[bar:])
+        dm = to_dev(data)
+        di, do = to_dev(vin.astype(dtype)), to_dev(vout.astype(dtype))
+        sol.addMvFrom(dm, span, di, n, do, n, nrhs, 0.75)
+        got = do.cpu().numpy().astype(np.float64).reshape(nrhs, n).T
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, ("addMv", i)
+
+
 def test_solve_l_then_lt_equals_solve_with_stride():
     """solveL followed by solveLt == solve; leading dimension larger than the order"""
     sol, _, _ = solver_random(63, fill=0.03, elim=(0, 60), ranges=[0, 60])
