@@ -257,6 +257,15 @@ class Solver:
                                                ctypes.byref(st)))
         return off.value, st.value
 
+    def diagBlockOffsetOfSpan(self, span):
+        """(offset, stride) of the diagonal block of a SPAN (internal order), from the skeleton:
+        CoalescedAccessor::diagBlockOffset (Accessor.h:75-85)"""
+        sk = self.skel()
+        lump = int(sk["spanToLump"][span])
+        idx = span - int(sk["lumpToSpan"][lump])
+        off = int(sk["chainData"][int(sk["chainColPtr"][lump]) + idx]) + int(sk["spanOffsetInLump"][span])
+        return off, int(sk["lumpStart"][lump + 1] - sk["lumpStart"][lump])
+
     def deviceAccessor(self):
         """8 device addresses (spanStart, spanToLump, lumpStart, spanOffsetInLump, chainColPtr,
         chainRowSpan, chainData, permutation) usable from a caller's HIP kernel"""

@@ -196,6 +196,44 @@ def test_pseudo_factor_and_add_mv(dtype):
         assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, ("addMv", i)
 
 
+@pytest.mark.parametrize("precond", ["lowerprec", "jacobi", "identity"])
+def test_pcg_on_schur_complement(precond):
+    """mixed direct / iterative solve as examples/Optimizer.h:710-747: factorUpTo(span), reduce the
+    right-hand side, PCG on the Schur complement with the preconditioners of
+    examples/Preconditioner.h, back-substitute; against the direct solve"""
+    import torch
+    from baspacho_amd import pcg
+    sol, _, _ = solver_random(63, size=215, fill=0.03, elim=(0, 150), psize_seed=47, pmin=2, pmax=3)
+    sk = sol.skel()
+    ranges = sol.sparseEliminationRanges()
+    dense_from = int(ranges[-1]) if len(ranges) else 0
+    lump = dense_from + (sol.numLumps() - dense_from) // 3
+    span = int(sk["lumpToSpan"][lump])
+    n = sol.order()
+    bar = int(sk["spanStart"][span])
+    data = spd_data(sol, 9, beta_factor=2.0)
+    A = sol.densify(data, fill_upper_half=True)
+    b = T.random_data(n, -1.0, 1.0, 49)
+    want = np.linalg.solve(A, b)
+    d = to_dev(data)
+    sol.factorUpTo(d, span)                      # Schur complement in the bottom-right blocks
+    v = to_dev(b.copy())
+    sol.solveLUpTo(d, span, v, n, 1)             # reduced right-hand side in v[bar:]
+    op = pcg.TrailingOperator(sol, d, span)
+    M = {"lowerprec": lambda: pcg.LowerPrecSolvePrecond(sol, d, span),
+         "jacobi": lambda: pcg.BlockJacobiPrecond(sol, d, span),
+         "identity": lambda: pcg.IdentityPrecond()}[precond]()
+    x_tail = torch.zeros(n - bar, dtype=torch.float64, device=v.device)
+    iters, res = pcg.PCG(M, op, 1e-12, 400).solve(x_tail, v[bar:].clone())
+    assert res <= 1e-12, (precond, iters, res)
+    if precond == "lowerprec":
+        assert iters <= 4, iters                 # a single-precision factor is nearly exact
+    v[bar:] = x_tail
+    sol.solveLtUpTo(d, span, v, n, 1)            # back-substitution through the factored part
+    got = v.cpu().numpy()
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-9, precond
+
+
 def test_solve_l_then_lt_equals_solve_with_stride():
     """solveL followed by solveLt == solve; leading dimension larger than the order"""
     sol, _, _ = solver_random(63, fill=0.03, elim=(0, 60), ranges=[0, 60])
