@@ -263,7 +263,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 from oracle import cref
-                cores = os.cpu_count() or 1
+                # small problems run slower on a wide BLAS team (per-call fork/join on tiny fronts):
+                # about one thread per 0.5 GF of work, all cores for the headline workload
+                cores = max(1, min(os.cpu_count() or 1, int(flops / 0.5e9)))
                 _, blas_desc = cref.blas_lib(cores)
                 hostA = host.copy()
                 skh = cref.SkelHandle(sol.skel())
