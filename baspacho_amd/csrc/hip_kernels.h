@@ -324,6 +324,8 @@ struct Mfma<double> {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+  // inverse of (q, reg) -> row: the m with row(16 q + *, reg) == m has 4 q + reg == colOfRow(m)
+  static __device__ __forceinline__ int colOfRow(int m) { return 4 * (m & 3) + (m >> 2); }
 };
 template <>
 struct Mfma<float> {
@@ -332,6 +334,7 @@ struct Mfma<float> {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+  static __device__ __forceinline__ int colOfRow(int m) { return m; }
 };
 
 
@@ -1002,53 +1005,6 @@ __device__ __forceinline__ void trsmRows(const T* __restrict__ Ls, const T* __re
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const TrsmTask* tasks,
-                                                 DataRef<T> dref) {
-  constexpr int LDL = kPanelWidth + 1;
-  __shared__ T Ls[kPanelWidth * LDL];
-  __shared__ T invDiag[kPanelWidth];
-  BSP_STAMP(4);
-  const TrsmTask task = tasks[blockIdx.x];
-  const PanelDesc pd = panels[task.panel];
-  GP<T> data = pickData(dref);
-  GP<const T> A = data + pd.diagOff;
-  const int nb = pd.nb, lda = pd.lda, tid = threadIdx.x;
-  GP<T> P = data + pd.diagOff + (int64_t)(nb + task.rowTile) * lda;
-  const int rows = min(kTile, pd.rowsBelow - task.rowTile);
-  const int nbPad = nb <= 8 ? 8 : nb <= 16 ? 16 : nb <= 32 ? 32 : 64;
-
-  // lane = column, wave w takes rows w, w+4, ...; all loads are issued before the first LDS write
-  // (addresses clamped, values masked): zero above the diagonal and in the padding
-  {
-    const int j = tid & 63, w = tid >> 6;
-    T v[16];
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const int i = min(w + 4 * it, nb - 1);
-      v[it] = A[(int64_t)i * lda + min(j, i)];
-    }
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const int i = w + 4 * it;
-      if (i < nbPad && j < nbPad) Ls[i * LDL + j] = (i < nb && j <= i) ? v[it] : T(0);
-    }
-  }
-  if (tid < kPanelWidth) invDiag[tid] = tid < nb ? T(1) / A[(int64_t)tid * lda + tid] : T(0);
-  __syncthreads();
-  BSP_STAMP(5);
-  if (nb <= 8) {
-    trsmRows<T, 8>(Ls, invDiag, P, lda, nb, rows, tid);
-  } else if (nb <= 16) {
-    trsmRows<T, 16>(Ls, invDiag, P, lda, nb, rows, tid);
-  } else if (nb <= 32) {
-    trsmRows<T, 32>(Ls, invDiag, P, lda, nb, rows, tid);
-  } else {
-    trsmRows<T, 64>(Ls, invDiag, P, lda, nb, rows, tid);
-  }
-  BSP_STAMP(6);
-}
-
 // direct variant: the row tile is blockIdx.x, the rows are fetched together with L
 template <typename T, int NB>
 __device__ __forceinline__ void trsmDirectBody(GP<const T> A, GP<T> P, int lda, int nb, int rows, T* Ls,
@@ -1107,17 +1063,138 @@ __device__ __forceinline__ void trsmDirectBody(GP<const T> A, GP<T> P, int lda, 
   }
 }
 
+
+// MFMA form of the panel trsm for one tile of 64 rows:  X L^T = B, solved transposed,
+//   X_j^T = Dinv_j (B_j^T - sum_{l<j} L_jl X_l^T)     (16x16 blocks, Dinv_j = L_jj^-1)
+// Wave w owns rows 16w..16w+15 of the tile, entirely in registers: lane (q, n) = (lane/16,
+// lane%16) holds, for row n, the columns 16j + 4q + r (j, r < 4) -- chosen so that accumulator
+// register r of a finished block IS the B operand of K-chunk r of the next product (the A
+// operand, read from LDS, is indexed to match through Mfma::colOfRow): no shuffles, no LDS round
+// trip for X, 40 MFMAs per wave in a dependent chain of 4 x 8.  The four 16x16 inverses are
+// computed once per workgroup (wave j inverts block j, lane c < 16 solves column c in registers);
+// the solve through inverted 16x16 diagonal blocks is the standard GPU formulation (error grows
+// with the condition of a 16x16 block of L, not of the panel).
+// Ls: 64 x kTrsmLd (lower triangle of L, identity beyond nb), Dv: 64 x kTrsmLdInv.
+constexpr int kTrsmLd = 66, kTrsmLdInv = 18;
+constexpr int kTrsmLdsElems = kPanelWidth * (kTrsmLd + kTrsmLdInv);
+template <typename T>
+__device__ __forceinline__ T readLaneT(T v, int srcLane);
+template <>
+__device__ __forceinline__ double readLaneT<double>(double v, int srcLane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+  return __hiloint2double(hi, lo);
+}
+template <>
+__device__ __forceinline__ float readLaneT<float>(float v, int srcLane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srcLane));
+}
+
+template <typename T>
+__device__ __forceinline__ void trsmTileMfma(GP<const T> A, GP<T> P, int lda, int nb, int rows,
+                                             T* Ls, T* Dv) {
+  constexpr int LDT = kTrsmLd, LDV = kTrsmLdInv, N = kPanelWidth;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, q = lane >> 4;
+  const bool active = 16 * w + n < rows;
+  GP<T> row = P + (int64_t)(active ? 16 * w + n : 0) * lda;
+  using Acc = typename Mfma<T>::Acc;
+  Acc x[4];
+  T v[16];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[j][r] = row[min(16 * j + 4 * q + r, nb - 1)];
+  }
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const int e = tid + 256 * it, i = min(e / N, nb - 1), jj = e % N;
+    v[it] = A[(int64_t)i * lda + min(jj, i)];
+  }
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const int e = tid + 256 * it, i = e / N, jj = e % N;
+    Ls[i * LDT + jj] = (i < nb && jj <= i) ? v[it] : ((i >= nb && i == jj) ? T(1) : T(0));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[j][r] = (active && 16 * j + 4 * q + r < nb) ? x[j][r] : T(0);
+  }
+  __syncthreads();
+  {  // wave w inverts diagonal block w: lane c solves L y = e_c, right-looking, in registers
+    const T* Lb = Ls + (16 * w) * LDT + 16 * w;
+    const T rd = T(1) / Lb[n * LDT + n];
+    T y[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) y[i] = (i == n) ? T(1) : T(0);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      y[i] *= readLaneT(rd, i);
+#pragma unroll
+      for (int k = i + 1; k < 16; k++) y[k] -= Lb[k * LDT + i] * y[i];
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) Dv[(16 * w + i) * LDV + n] = y[i];
+    }
+  }
+  __syncthreads();
+  const int pm = Mfma<T>::colOfRow(n);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (16 * j < nb) {
+#pragma unroll
+      for (int l = 0; l < j; l++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          x[j] = Mfma<T>::run(-Ls[(16 * j + pm) * LDT + 16 * l + 4 * q + r], x[l][r], x[j]);
+        }
+      }
+      Acc y = {0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        y = Mfma<T>::run(Dv[(16 * j + pm) * LDV + 4 * q + r], x[j][r], y);
+      }
+      x[j] = y;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int col = 16 * j + 4 * q + r;
+      if (active && col < nb) row[col] = x[j][r];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const TrsmTask* tasks,
+                                                 DataRef<T> dref) {
+  __shared__ T lds[kTrsmLdsElems];
+  BSP_STAMP(4);
+  const TrsmTask task = tasks[blockIdx.x];
+  const PanelDesc pd = panels[task.panel];
+  GP<T> data = pickData(dref);
+  const int nb = pd.nb, lda = pd.lda;
+  GP<T> P = data + pd.diagOff + (int64_t)(nb + task.rowTile) * lda;
+  const int rows = min(kTile, pd.rowsBelow - task.rowTile);
+  trsmTileMfma<T>(data + pd.diagOff, P, lda, nb, rows, lds, lds + kPanelWidth * kTrsmLd);
+  BSP_STAMP(6);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void trsmPanelDirect(PanelDesc pd, DataRef<T> dref) {
-  constexpr int LDL = kPanelWidth + 1;
-  __shared__ T Ls[kPanelWidth * LDL];
-  __shared__ T invDiag[kPanelWidth];
+  __shared__ T lds[kTrsmLdsElems];
   __builtin_amdgcn_s_setprio(3);
   GP<T> data = pickData(dref);
   GP<const T> A = data + pd.diagOff;
   const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
   GP<T> P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
   const int rows = min(kTile, pd.rowsBelow - rowTile);
+#ifdef BSP_TRSM_VALU  // A/B: thread-level forward substitution
+  T* Ls = lds;
+  T* invDiag = lds + kPanelWidth * (kPanelWidth + 1);
   if (nb <= 8) {
     trsmDirectBody<T, 8>(A, P, lda, nb, rows, Ls, invDiag);
   } else if (nb <= 16) {
@@ -1127,6 +1204,9 @@ __global__ __launch_bounds__(256) void trsmPanelDirect(PanelDesc pd, DataRef<T> 
   } else {
     trsmDirectBody<T, 64>(A, P, lda, nb, rows, Ls, invDiag);
   }
+#else
+  trsmTileMfma<T>(A, P, lda, nb, rows, lds, lds + kPanelWidth * kTrsmLd);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1431,8 +1511,9 @@ __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, 
 template <typename T>
 __global__ __launch_bounds__(256) void trsmPanelDirectPlus(PanelDesc pd, SrcDesc part, SegDesc sd,
                                                            DataRef<T> dref) {
-  constexpr int LDL = kPanelWidth + 1, LD = kUpdChunk + 2;
-  __shared__ T lds[2 * kTile * LD];  // >= 64 x 65 + 64
+  constexpr int LD = kUpdChunk + 2;
+  static_assert(kTrsmLdsElems >= 2 * kTile * LD, "LDS of the tile update fits the trsm's");
+  __shared__ T lds[kTrsmLdsElems];
   __builtin_amdgcn_s_setprio(3);
   GP<T> data = pickData(dref);
   if (blockIdx.x == gridDim.x - 1) {
@@ -1443,8 +1524,9 @@ __global__ __launch_bounds__(256) void trsmPanelDirectPlus(PanelDesc pd, SrcDesc
   const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
   GP<T> P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
   const int rows = min(kTile, pd.rowsBelow - rowTile);
+#ifdef BSP_TRSM_VALU
   T* Ls = lds;
-  T* invDiag = lds + kPanelWidth * LDL;
+  T* invDiag = lds + kPanelWidth * (kPanelWidth + 1);
   if (nb <= 8) {
     trsmDirectBody<T, 8>(A, P, lda, nb, rows, Ls, invDiag);
   } else if (nb <= 16) {
@@ -1454,6 +1536,9 @@ __global__ __launch_bounds__(256) void trsmPanelDirectPlus(PanelDesc pd, SrcDesc
   } else {
     trsmDirectBody<T, 64>(A, P, lda, nb, rows, Ls, invDiag);
   }
+#else
+  trsmTileMfma<T>(A, P, lda, nb, rows, lds, lds + kPanelWidth * kTrsmLd);
+#endif
 }
 
 template <typename T>
