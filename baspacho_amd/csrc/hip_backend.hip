@@ -172,6 +172,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
     if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
+    if (const char* e = std::getenv("BSP_MERGED_CHAIN")) mergedChain = e[0] != '0';
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -288,6 +289,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
   bool fusePotrf = true;    // next panel's potrf inside the update launch (BSP_FUSE_POTRF=0 disables)
+  bool mergedChain = true;  // trsm + update (+ next potrf) of an intra-block step in one launch (BSP_MERGED_CHAIN=0 disables)
   bool directChain = true;  // descriptor-by-value kernels on one-panel levels (BSP_DIRECT_CHAIN=0 disables)
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
@@ -330,18 +332,37 @@ struct HipNumericCtx : NumericCtx<T> {
     vector<hipEvent_t> defDone(levels.size(), nullptr);
     bool potrfFused = false;  // this level's potrf ran inside the previous level's update launch
     bool sideUsed = false;
+    // inverted diagonal blocks of the chain panels: written by a panel's potrf, read by its trsm
+    // (two slots per matrix, alternating from panel to panel)
+    dinvScratch.resize((size_t)batchSize * hipk::kDinvBatchStride * sizeof(BT));
+    BT* dinvBase = const_cast<BT*>(dinvScratch.as<BT>());
+    int dinvSlot = 0;  // slot of the current level's panel
+    // staging buffer of the chain (chainStep): unsolved rows of the current / next panel
+    const int64_t rawSlot = plan.host.maxChainRows * kTile;
+    BT* rawBase = nullptr;
+    if (rawSlot > 0 && sym.mergedChain) {
+      rawScratch.resize((size_t)batchSize * 2 * rawSlot * sizeof(BT));
+      rawBase = const_cast<BT*>(rawScratch.as<BT>());
+    }
+    bool rawValid = false;  // the previous level staged this level's panel rows
     for (size_t li = 0; li < levels.size(); li++) {
       const LevelRange& lr = levels[li];
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
       const bool direct = sym.directChain && lr.directPanel >= 0;
+      const int slot = dinvSlot;
+      dinvSlot ^= 1;
+      BT* dinvCur = dinvBase + slot * hipk::kDinvSlot;
+      BT* dinvNext = dinvBase + (slot ^ 1) * hipk::kDinvSlot;
+      BT* rawCur = rawBase ? rawBase + slot * rawSlot : nullptr;
+      BT* rawNext = rawBase ? rawBase + (slot ^ 1) * rawSlot : nullptr;
       if (potrfFused) {
         potrfFused = false;
       } else if (nP) {
         timer.begin(kProfPotrf);
         if (direct) {
           hipk::potrfPanelDirect<BT><<<dim3(1, gy.y), 256, 0, sym.stream>>>(
-              plan.host.panels[lr.directPanel], ref);
+              plan.host.panels[lr.directPanel], ref, dinvCur);
         } else {
           hipk::potrfPanel<BT><<<dim3(nP, gy.y), 256, 0, sym.stream>>>(
               plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, ref);
@@ -354,20 +375,30 @@ struct HipNumericCtx : NumericCtx<T> {
                         li + 1 < levels.size() && levels[li + 1].directPanel >= 0 &&
                         lr.updEnd > lr.updBegin;
       const int splitK = (fuse && sym.splitDiag && nT) ? lr.splitK : 0;
+      const bool directUpd = direct && lr.directSeg >= 0 && lr.updEnd > lr.updBegin;
+      // does this level's update stage the next panel's rows?
+      const bool stage = rawBase && directUpd && lr.rawNext && li + 1 < levels.size() &&
+                         levels[li + 1].directPanel >= 0;
+      const PanelDesc nextPanel = (stage || fuse) ? plan.host.panels[levels[li + 1].directPanel]
+                                                  : PanelDesc{};
+      // one launch for trsm + update (+ next potrf): intra-block step whose rows were staged
+      const bool merged = rawValid && directUpd && nT && !plan.host.segs[lr.directSeg].outer &&
+                          plan.host.srcs[plan.host.segs[lr.directSeg].src].K ==
+                              plan.host.panels[lr.directPanel].nb;
       if (splitK && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
         hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
       }
-      if (nT) {
+      if (nT && !merged) {
         timer.begin(kProfTrsm);
         if (splitK) {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
           SrcDesc part = plan.host.srcs[sd.src];
           part.K = splitK;
           hipk::trsmPanelDirectPlus<BT><<<dim3(nT + 1, gy.y), 256, 0, sym.stream>>>(
-              plan.host.panels[lr.directPanel], part, sd, ref);
+              plan.host.panels[lr.directPanel], part, sd, ref, dinvCur);
         } else if (direct) {
           hipk::trsmPanelDirect<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
-              plan.host.panels[lr.directPanel], ref);
+              plan.host.panels[lr.directPanel], ref, dinvCur);
         } else {
           hipk::trsmPanel<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
               plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin, ref);
@@ -380,23 +411,29 @@ struct HipNumericCtx : NumericCtx<T> {
       const int64_t updBegin = lr.updBegin;
       if (lr.updEnd > updBegin) {
         timer.begin(direct && lr.directSeg >= 0 ? kProfChainUpdate : kProfUpdate);
-        if (fuse) {
+        const unsigned nUpd = (unsigned)(lr.updEnd - updBegin);
+        if (merged) {
+          hipk::chainStep<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
+              plan.host.panels[lr.directPanel], plan.host.segs[lr.directSeg], (int)nUpd, nextPanel,
+              fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext);
+          potrfFused = fuse;
+        } else if (fuse) {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
-          hipk::updateTileDirectPotrf<BT><<<dim3((unsigned)(lr.updEnd - updBegin), gy.y), 256, 0,
-                                          sym.stream>>>(
-              plan.host.srcs[sd.src], sd, (int)(lr.updEnd - updBegin),
-              plan.host.panels[levels[li + 1].directPanel], ref, splitK);
+          hipk::updateTileDirectPotrf<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
+              plan.host.srcs[sd.src], sd, (int)nUpd, nextPanel, ref, splitK, dinvNext,
+              stage ? rawNext : nullptr, 2 * rawSlot);
           potrfFused = true;
         } else if (direct && lr.directSeg >= 0) {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
-          hipk::updateTileDirect<BT><<<dim3((unsigned)(lr.updEnd - updBegin), gy.y), 256, 0,
-                                     sym.stream>>>(plan.host.srcs[sd.src], sd,
-                                                   (int)(lr.updEnd - updBegin), ref);
+          hipk::updateTileDirect<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
+              plan.host.srcs[sd.src], sd, (int)nUpd, ref, stage ? rawNext : nullptr, nextPanel.nb,
+              2 * rawSlot);
         } else {
           launchUpdate(plan, updBegin, lr.updEnd, ref, sym.stream);
         }
         timer.end();
       }
+      rawValid = stage;
       const bool anyDef = lr.defEnd > lr.defBegin;
       if (lookahead && anyDef) {
         // Fork AFTER the level's own update launch: those "now" tiles (the next outer block's
@@ -640,7 +677,7 @@ struct HipNumericCtx : NumericCtx<T> {
   HipSymbolicCtx& sym;
   int batchSize;
   int64_t tempBufSize = 0;
-  DevBuf devPtrs, temp, spanToChainOffset;
+  DevBuf devPtrs, temp, spanToChainOffset, dinvScratch, rawScratch;
   vector<std::unique_ptr<DevPlan>> opPlans;
 };
 

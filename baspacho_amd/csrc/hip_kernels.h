@@ -761,9 +761,44 @@ struct NoPreUpdate {
 // `pre(acc)` runs between the load of the block and the factorization: the fused kernel
 // (updateTileDirectPotrf) applies the pending rank-K update of the block there.
 // blk: 3 x (16 NT) rows of 4 values (ring of column blocks), sol: 16 NT rows of 4 values.
+// Ld / dinvOut (both or neither): the four 16x16 diagonal blocks of L are also collected in LDS
+// (Ld: 16 NT rows of kInvLd values, row i = its own block's 16 columns) and, after the last step,
+// wave w inverts block w and writes it to dinvOut[w][16][16] -- the trsm of this panel then
+// multiplies by the inverses (trsmStages) instead of substituting.
+constexpr int kInvLd = 17;
+constexpr int kDinvSlot = 4 * 16 * 16;        // one panel's inverted diagonal blocks
+constexpr int kDinvBatchStride = 2 * kDinvSlot;  // two slots (alternating panels) per matrix
+template <typename T>
+__device__ __forceinline__ T readLaneT(T v, int srcLane);
+template <>
+__device__ __forceinline__ double readLaneT<double>(double v, int srcLane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+  return __hiloint2double(hi, lo);
+}
+template <>
+__device__ __forceinline__ float readLaneT<float>(float v, int srcLane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srcLane));
+}
+// lane n (= lane % 16, every group of 16 lanes does the same work) solves L y = e_n for the 16x16
+// lower-triangular block at Lb (row stride ldl), right-looking, in registers: y = column n of L^-1
+template <typename T>
+__device__ __forceinline__ void invertColumn16(const T* Lb, int ldl, int n, T (&y)[16]) {
+  const T rd = T(1) / Lb[n * ldl + n];
+#pragma unroll
+  for (int i = 0; i < 16; i++) y[i] = (i == n) ? T(1) : T(0);
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    y[i] *= readLaneT(rd, i);
+#pragma unroll
+    for (int k = i + 1; k < 16; k++) y[k] -= Lb[k * ldl + i] * y[i];
+  }
+}
+
 template <typename T, int NT, typename Pre = NoPreUpdate>
 __device__ __forceinline__ void potrfTiles(GP<T> A, int nb, int lda, T (*blk)[4], T (*sol)[4],
-                                           Pre pre = Pre()) {
+                                           Pre pre = Pre(), T* Ld = nullptr,
+                                           GP<T> dinvOut = nullptr) {
   // The block lives in MFMA accumulator layout: wave w owns tile row w (16x16 tiles (w,0..w));
   // lane l / register r of tile (ti,tj) hold row 16ti + Mfma::row(l,r), column 16tj + (l&15).
   // One step per 4-column pivot block.  The serial path of a step touches only LDS and the
@@ -818,6 +853,13 @@ __device__ __forceinline__ void potrfTiles(GP<T> A, int nb, int lda, T (*blk)[4]
       }
     }
   };
+  if (Ld) {  // identity beyond nb, zero above the diagonal; the steps fill in the rest
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int col = 4 * g + c;
+      Ld[i * kInvLd + col] = (i >= nb && (i & 15) == col) ? T(1) : T(0);
+    }
+  }
   publish(0);
   if (nSteps > 1) publish(1);
   ldsBarrier();
@@ -864,7 +906,11 @@ __device__ __forceinline__ void potrfTiles(GP<T> A, int nb, int lda, T (*blk)[4]
       const T lrow1 = di == 1 ? l11 : di == 2 ? l21 : l31;
       const T lrow2 = di == 2 ? l22 : l32;
       const T inPiv = g == 0 ? lrow0 : g == 1 ? lrow1 : g == 2 ? lrow2 : l33;
-      if (i < nb && j0 + g < nb && di >= g) A[(int64_t)i * lda + j0 + g] = below ? solved : inPiv;
+      if (i < nb && j0 + g < nb && di >= g) {
+        const T fin = below ? solved : inPiv;
+        A[(int64_t)i * lda + j0 + g] = fin;
+        if (Ld && (i >> 4) == tjJ) Ld[i * kInvLd + ((j0 + g) & 15)] = fin;
+      }
     }
     ldsBarrier();
     // (2) bring the next two column blocks up to date, rank-4 update of every live tile
@@ -900,6 +946,14 @@ __device__ __forceinline__ void potrfTiles(GP<T> A, int nb, int lda, T (*blk)[4]
   staticFor<0, 4 * NT>(step);
 #endif
   BSP_STAMP(2);
+  if (Ld) {  // (the last step ended with a barrier)
+    T y[16];
+    invertColumn16(Ld + 16 * w * kInvLd, kInvLd, li, y);
+    if (lane < 16) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) dinvOut[(16 * w + r) * 16 + li] = y[r];
+    }
+  }
 }
 
 template <typename T>
@@ -920,12 +974,15 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
 // bulk update saturates the memory system beside it), so each kernel is cut to one load round
 // trip plus the store.
 template <typename T>
-__global__ __launch_bounds__(256) void potrfPanelDirect(PanelDesc pd, DataRef<T> dref) {
+__global__ __launch_bounds__(256) void potrfPanelDirect(PanelDesc pd, DataRef<T> dref,
+                                                        T* dinvOut) {
   __shared__ T blk[3 * kPanelWidth][4];
   __shared__ T sol[kPanelWidth][4];
+  __shared__ T Ld[kPanelWidth * kInvLd];
   __builtin_amdgcn_s_setprio(3);
   BSP_STAMP(0);
-  potrfTiles<T, 4>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, blk, sol);
+  potrfTiles<T, 4>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, blk, sol, NoPreUpdate(), Ld,
+                   (GP<T>)dinvOut + (size_t)blockIdx.y * kDinvBatchStride);
   BSP_STAMP(3);
 }
 
@@ -935,135 +992,6 @@ __global__ __launch_bounds__(256) void potrfPanelDirect(PanelDesc pd, DataRef<T>
 // that both the coalesced fill and the per-lane column walk are bank-conflict free).
 // Replaces cublas?trsm LEFT/UPPER/OP_C (MatOpsCuda.cu:550-566, 757-781).
 // ------------------------------------------------------------------------------------------
-// broadcast the value held by lane G of every quad (lanes 4q..4q+3) to the whole quad: one DPP
-// move per 32-bit half (quad_perm [G,G,G,G]) instead of a ds_bpermute round trip through LDS
-template <int G>
-__device__ __forceinline__ double quadBcast(double v) {
-  constexpr int ctrl = G | (G << 2) | (G << 4) | (G << 6);
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-template <int G>
-__device__ __forceinline__ float quadBcast(float v) {
-  constexpr int ctrl = G | (G << 2) | (G << 4) | (G << 6);
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true));
-}
-template <typename T>
-__device__ __forceinline__ T quadBcastSel(T v, int g) {  // g is a compile-time value after unrolling
-  switch (g) {
-    case 0: return quadBcast<0>(v);
-    case 1: return quadBcast<1>(v);
-    case 2: return quadBcast<2>(v);
-    default: return quadBcast<3>(v);
-  }
-}
-
-// body for panels of width <= NB (NB in {8,16,32,64}); thread (r,g) = (tid/4, tid%4) owns the
-// entries k = 8*m + 2*g + h (m < NB/8, h < 2) of row r in registers; the pivot value x_j is
-// broadcast inside the quad with a shuffle, L(k,j) comes from LDS.  Ls is zero above the diagonal
-// and beyond nb, invDiag is zero beyond nb: the body needs no per-lane conditions.
-template <typename T, int NB>
-__device__ __forceinline__ void trsmRows(const T* __restrict__ Ls, const T* __restrict__ invDiag,
-                                         GP<T> P, int lda, int nb, int rows, int tid) {
-  constexpr int LDL = kPanelWidth + 1, M = NB / 8;
-  const int r = tid >> 2, g = tid & 3;
-  const bool active = r < rows;
-  GP<T> row = P + (int64_t)(active ? r : 0) * lda;
-  T x[M][2];
-#pragma unroll
-  for (int m = 0; m < M; m++) {
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int k = 8 * m + 2 * g + h;
-      const T v = row[min(k, nb - 1)];
-      x[m][h] = (active && k < nb) ? v : T(0);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NB; j++) {
-    const int mj = j >> 3, gj = (j >> 1) & 3, hj = j & 1;
-    T xj = x[mj][hj] * invDiag[j];
-    xj = quadBcastSel(xj, gj);
-#pragma unroll
-    for (int m = mj; m < M; m++) {
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int k = 8 * m + 2 * g + h;
-        x[m][h] -= xj * Ls[k * LDL + j];  // zero for k < j; the k == j entry is overwritten below
-      }
-    }
-    x[mj][hj] = (g == gj) ? xj : x[mj][hj];
-  }
-#pragma unroll
-  for (int m = 0; m < M; m++) {
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int k = 8 * m + 2 * g + h;
-      if (active && k < nb) row[k] = x[m][h];
-    }
-  }
-}
-
-// direct variant: the row tile is blockIdx.x, the rows are fetched together with L
-template <typename T, int NB>
-__device__ __forceinline__ void trsmDirectBody(GP<const T> A, GP<T> P, int lda, int nb, int rows, T* Ls,
-                                               T* invDiag) {
-  constexpr int LDL = kPanelWidth + 1, M = NB / 8;
-  constexpr int NL = (NB * NB + 255) / 256;
-  const int tid = threadIdx.x, r = tid >> 2, g = tid & 3;
-  const bool active = r < rows;
-  GP<T> row = P + (int64_t)(active ? r : 0) * lda;
-  T x[M][2], v[NL];
-#pragma unroll
-  for (int m = 0; m < M; m++) {
-#pragma unroll
-    for (int h = 0; h < 2; h++) x[m][h] = row[min(8 * m + 2 * g + h, nb - 1)];
-  }
-#pragma unroll
-  for (int it = 0; it < NL; it++) {
-    const int e = tid + 256 * it, i = min(e / NB, nb - 1), j = e % NB;
-    v[it] = A[(int64_t)i * lda + min(j, i)];
-  }
-  const T d = A[(int64_t)min(tid, nb - 1) * (lda + 1)];
-#pragma unroll
-  for (int it = 0; it < NL; it++) {
-    const int e = tid + 256 * it, i = e / NB, j = e % NB;
-    if (e < NB * NB) Ls[i * LDL + j] = (i < nb && j <= i) ? v[it] : T(0);
-  }
-  if (tid < NB) invDiag[tid] = tid < nb ? T(1) / d : T(0);
-#pragma unroll
-  for (int m = 0; m < M; m++) {
-#pragma unroll
-    for (int h = 0; h < 2; h++) x[m][h] = (active && 8 * m + 2 * g + h < nb) ? x[m][h] : T(0);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < NB; j++) {
-    const int mj = j >> 3, gj = (j >> 1) & 3, hj = j & 1;
-    T xj = x[mj][hj] * invDiag[j];
-    xj = quadBcastSel(xj, gj);
-#pragma unroll
-    for (int m = mj; m < M; m++) {
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int k = 8 * m + 2 * g + h;
-        x[m][h] -= xj * Ls[k * LDL + j];
-      }
-    }
-    x[mj][hj] = (g == gj) ? xj : x[mj][hj];
-  }
-#pragma unroll
-  for (int m = 0; m < M; m++) {
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int k = 8 * m + 2 * g + h;
-      if (active && k < nb) row[k] = x[m][h];
-    }
-  }
-}
-
-
 // MFMA form of the panel trsm for one tile of 64 rows:  X L^T = B, solved transposed,
 //   X_j^T = Dinv_j (B_j^T - sum_{l<j} L_jl X_l^T)     (16x16 blocks, Dinv_j = L_jj^-1)
 // Wave w owns rows 16w..16w+15 of the tile, entirely in registers: lane (q, n) = (lane/16,
@@ -1077,19 +1005,6 @@ __device__ __forceinline__ void trsmDirectBody(GP<const T> A, GP<T> P, int lda, 
 // Ls: 64 x kTrsmLd (lower triangle of L, identity beyond nb), Dv: 64 x kTrsmLdInv.
 constexpr int kTrsmLd = 66, kTrsmLdInv = 18;
 constexpr int kTrsmLdsElems = kPanelWidth * (kTrsmLd + kTrsmLdInv);
-template <typename T>
-__device__ __forceinline__ T readLaneT(T v, int srcLane);
-template <>
-__device__ __forceinline__ double readLaneT<double>(double v, int srcLane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
-  return __hiloint2double(hi, lo);
-}
-template <>
-__device__ __forceinline__ float readLaneT<float>(float v, int srcLane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srcLane));
-}
-
 template <typename T>
 __device__ __forceinline__ void trsmTileMfma(GP<const T> A, GP<T> P, int lda, int nb, int rows,
                                              T* Ls, T* Dv) {
@@ -1121,18 +1036,9 @@ __device__ __forceinline__ void trsmTileMfma(GP<const T> A, GP<T> P, int lda, in
     for (int r = 0; r < 4; r++) x[j][r] = (active && 16 * j + 4 * q + r < nb) ? x[j][r] : T(0);
   }
   __syncthreads();
-  {  // wave w inverts diagonal block w: lane c solves L y = e_c, right-looking, in registers
-    const T* Lb = Ls + (16 * w) * LDT + 16 * w;
-    const T rd = T(1) / Lb[n * LDT + n];
+  {  // wave w inverts diagonal block w
     T y[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) y[i] = (i == n) ? T(1) : T(0);
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      y[i] *= readLaneT(rd, i);
-#pragma unroll
-      for (int k = i + 1; k < 16; k++) y[k] -= Lb[k * LDT + i] * y[i];
-    }
+    invertColumn16(Ls + (16 * w) * LDT + 16 * w, LDT, n, y);
     if (lane < 16) {
 #pragma unroll
       for (int i = 0; i < 16; i++) Dv[(16 * w + i) * LDV + n] = y[i];
@@ -1168,6 +1074,129 @@ __device__ __forceinline__ void trsmTileMfma(GP<const T> A, GP<T> P, int lda, in
   }
 }
 
+// Register-only form for the chain (single-panel levels): the inverses of the diagonal blocks
+// come from the panel's potrf (dinv[4][16][16]), the off-diagonal blocks of L straight from the
+// matrix; every operand is loaded in MFMA A-operand layout, no LDS, no barrier.
+template <typename T>
+struct TrsmOps {
+  T L[6][4];  // -(L_jl), (j,l) = (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)
+  T D[4][4];  // Dinv_j
+};
+template <typename T>
+__device__ __forceinline__ void trsmLoadOps(GP<const T> A, GP<const T> dinv, int lda, int nb,
+                                            int lane, TrsmOps<T>& o) {
+  const int pm = Mfma<T>::colOfRow(lane & 15), q = lane >> 4;
+#pragma unroll
+  for (int j = 1; j < 4; j++) {
+#pragma unroll
+    for (int l = 0; l < j; l++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        o.L[j * (j - 1) / 2 + l][r] = A[(int64_t)min(16 * j + pm, nb - 1) * lda + 16 * l + 4 * q + r];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) o.D[j][r] = dinv[(16 * j + pm) * 16 + 4 * q + r];
+  }
+}
+template <typename T>
+__device__ __forceinline__ void trsmMaskOps(int nb, int lane, TrsmOps<T>& o) {
+  const int pm = Mfma<T>::colOfRow(lane & 15);
+#pragma unroll
+  for (int j = 1; j < 4; j++) {
+#pragma unroll
+    for (int l = 0; l < j; l++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        T& v = o.L[j * (j - 1) / 2 + l][r];
+        v = (16 * j + pm < nb) ? -v : T(0);
+      }
+    }
+  }
+}
+// x: rows of the tile in the layout of trsmTileMfma (lane (q, n): row n, columns 16j + 4q + r)
+template <typename T>
+__device__ __forceinline__ void trsmLoadRows(GP<const T> row, int nb, int lane,
+                                             typename Mfma<T>::Acc (&x)[4]) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[j][r] = row[min(16 * j + 4 * q + r, nb - 1)];
+  }
+}
+template <typename T>
+__device__ __forceinline__ void trsmMaskRows(bool active, int nb, int lane,
+                                             typename Mfma<T>::Acc (&x)[4]) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[j][r] = (active && 16 * j + 4 * q + r < nb) ? x[j][r] : T(0);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void trsmStoreRows(GP<T> row, bool active, int nb, int lane,
+                                              const typename Mfma<T>::Acc (&x)[4]) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int col = 16 * j + 4 * q + r;
+      if (active && col < nb) row[col] = x[j][r];
+    }
+  }
+}
+// PAIR: two independent row sets go through the stages together (twice the MFMA parallelism, and
+// the operands of a stage die after it)
+template <typename T, bool PAIR = false>
+__device__ __forceinline__ void trsmStages(const TrsmOps<T>& o, int nb,
+                                           typename Mfma<T>::Acc (&x)[4],
+                                           typename Mfma<T>::Acc* x2 = nullptr) {
+  using Acc = typename Mfma<T>::Acc;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (16 * j < nb) {
+#pragma unroll
+      for (int l = 0; l < j; l++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          x[j] = Mfma<T>::run(o.L[j * (j - 1) / 2 + l][r], x[l][r], x[j]);
+          if (PAIR) x2[j] = Mfma<T>::run(o.L[j * (j - 1) / 2 + l][r], x2[l][r], x2[j]);
+        }
+      }
+      Acc y = {0, 0, 0, 0}, y2 = {0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        y = Mfma<T>::run(o.D[j][r], x[j][r], y);
+        if (PAIR) y2 = Mfma<T>::run(o.D[j][r], x2[j][r], y2);
+      }
+      x[j] = y;
+      if (PAIR) x2[j] = y2;
+    }
+  }
+}
+// one tile of 64 rows: wave w takes rows 16w..16w+15
+template <typename T>
+__device__ __forceinline__ void trsmTileRegs(GP<const T> A, GP<const T> dinv, GP<T> P, int lda,
+                                             int nb, int rows) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15;
+  const bool active = 16 * w + n < rows;
+  GP<T> row = P + (int64_t)(active ? 16 * w + n : 0) * lda;
+  typename Mfma<T>::Acc x[4];
+  TrsmOps<T> o;
+  trsmLoadRows<T>(row, nb, lane, x);
+  trsmLoadOps<T>(A, dinv, lda, nb, lane, o);
+  trsmMaskRows<T>(active, nb, lane, x);
+  trsmMaskOps<T>(nb, lane, o);
+  trsmStages<T>(o, nb, x);
+  trsmStoreRows<T>(row, active, nb, lane, x);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const TrsmTask* tasks,
                                                  DataRef<T> dref) {
@@ -1184,29 +1213,14 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void trsmPanelDirect(PanelDesc pd, DataRef<T> dref) {
-  __shared__ T lds[kTrsmLdsElems];
+__global__ __launch_bounds__(256) void trsmPanelDirect(PanelDesc pd, DataRef<T> dref,
+                                                       const T* dinv) {
   __builtin_amdgcn_s_setprio(3);
   GP<T> data = pickData(dref);
-  GP<const T> A = data + pd.diagOff;
   const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
   GP<T> P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
-  const int rows = min(kTile, pd.rowsBelow - rowTile);
-#ifdef BSP_TRSM_VALU  // A/B: thread-level forward substitution
-  T* Ls = lds;
-  T* invDiag = lds + kPanelWidth * (kPanelWidth + 1);
-  if (nb <= 8) {
-    trsmDirectBody<T, 8>(A, P, lda, nb, rows, Ls, invDiag);
-  } else if (nb <= 16) {
-    trsmDirectBody<T, 16>(A, P, lda, nb, rows, Ls, invDiag);
-  } else if (nb <= 32) {
-    trsmDirectBody<T, 32>(A, P, lda, nb, rows, Ls, invDiag);
-  } else {
-    trsmDirectBody<T, 64>(A, P, lda, nb, rows, Ls, invDiag);
-  }
-#else
-  trsmTileMfma<T>(A, P, lda, nb, rows, lds, lds + kPanelWidth * kTrsmLd);
-#endif
+  trsmTileRegs<T>(data + pd.diagOff, (GP<const T>)dinv + (size_t)blockIdx.y * kDinvBatchStride, P,
+                  lda, nb, min(kTile, pd.rowsBelow - rowTile));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1387,7 +1401,8 @@ __device__ __forceinline__ int xcdContiguous(int b, int n) {
 // tile `idx` of the segment in the order: column tiles from sd.q0 on, each with its row tiles
 template <typename T>
 __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const SegDesc& sd, int idx,
-                                                     GP<T> data, T* As, T* Bs) {
+                                                     GP<T> data, T* As, T* Bs,
+                                                     GP<T> rawOut = nullptr, int nbNext = 0) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
   int colTile = sd.q0, rowTile;
   for (;;) {
@@ -1482,7 +1497,12 @@ __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const Se
       for (int reg = 0; reg < 4; reg++) {
         const int qr = rowTile + wr + (t >> 1) * 16 + Mfma<T>::row(lane, reg);
         if (qc < segEnd && qr < pd.rowsBelow && qr >= qc && qr >= sd.rowMin) {
-          tgt[(int64_t)qr * sd.tgtStride + qc] = old[t * 4 + reg] - (*accs[t])[reg];
+          const T val = old[t * 4 + reg] - (*accs[t])[reg];
+          tgt[(int64_t)qr * sd.tgtStride + qc] = val;
+          // rows below the next panel's diagonal block, also to the chain's staging buffer
+          if (rawOut && colTile == 0 && qc < nbNext && qr >= nbNext) {
+            rawOut[(int64_t)(qr - nbNext) * kTile + qc] = val;
+          }
         }
       }
     }
@@ -1491,12 +1511,14 @@ __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const Se
 
 template <typename T>
 __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, int nTasks,
-                                                        DataRef<T> dref) {
+                                                        DataRef<T> dref, T* rawOut, int nbNext,
+                                                        int64_t rawStride) {
   constexpr int LD = kUpdChunk + 2;
   __shared__ T As[kTile * LD];
   __shared__ T Bs[kTile * LD];
   __builtin_amdgcn_s_setprio(2);
-  updateTileDirectBody<T>(pd, sd, xcdContiguous(blockIdx.x, nTasks), pickData(dref), As, Bs);
+  updateTileDirectBody<T>(pd, sd, xcdContiguous(blockIdx.x, nTasks), pickData(dref), As, Bs,
+                          rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr, nbNext);
 }
 
 // K5f  the same launch with the NEXT panel's potrf fused in.  Tile 0 of the segment is the next
@@ -1510,53 +1532,41 @@ __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, 
 // starts at source column part.K (kStart) instead of summing all 256 columns on its own.
 template <typename T>
 __global__ __launch_bounds__(256) void trsmPanelDirectPlus(PanelDesc pd, SrcDesc part, SegDesc sd,
-                                                           DataRef<T> dref) {
+                                                           DataRef<T> dref, const T* dinv) {
   constexpr int LD = kUpdChunk + 2;
-  static_assert(kTrsmLdsElems >= 2 * kTile * LD, "LDS of the tile update fits the trsm's");
-  __shared__ T lds[kTrsmLdsElems];
+  __shared__ T lds[2 * kTile * LD];
   __builtin_amdgcn_s_setprio(3);
   GP<T> data = pickData(dref);
   if (blockIdx.x == gridDim.x - 1) {
     updateTileDirectBody<T>(part, sd, 0, data, lds, lds + kTile * LD);
     return;
   }
-  GP<const T> A = data + pd.diagOff;
   const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
   GP<T> P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
-  const int rows = min(kTile, pd.rowsBelow - rowTile);
-#ifdef BSP_TRSM_VALU
-  T* Ls = lds;
-  T* invDiag = lds + kPanelWidth * (kPanelWidth + 1);
-  if (nb <= 8) {
-    trsmDirectBody<T, 8>(A, P, lda, nb, rows, Ls, invDiag);
-  } else if (nb <= 16) {
-    trsmDirectBody<T, 16>(A, P, lda, nb, rows, Ls, invDiag);
-  } else if (nb <= 32) {
-    trsmDirectBody<T, 32>(A, P, lda, nb, rows, Ls, invDiag);
-  } else {
-    trsmDirectBody<T, 64>(A, P, lda, nb, rows, Ls, invDiag);
-  }
-#else
-  trsmTileMfma<T>(A, P, lda, nb, rows, lds, lds + kPanelWidth * kTrsmLd);
-#endif
+  trsmTileRegs<T>(data + pd.diagOff, (GP<const T>)dinv + (size_t)blockIdx.y * kDinvBatchStride, P,
+                  lda, nb, min(kTile, pd.rowsBelow - rowTile));
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc sd, int nTasks,
                                                              PanelDesc next, DataRef<T> dref,
-                                                             int kStart) {
+                                                             int kStart, T* dinvOut, T* rawOut,
+                                                             int64_t rawStride) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
   __shared__ T As[kTile * LD];
   __shared__ T Bs[kTile * LD];
   GP<T> data = pickData(dref);
   if (blockIdx.x != 0) {
     __builtin_amdgcn_s_setprio(2);
-    updateTileDirectBody<T>(pd, sd, 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1), data, As, Bs);
+    updateTileDirectBody<T>(pd, sd, 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1), data, As, Bs,
+                            rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr, next.nb);
     return;
   }
   __builtin_amdgcn_s_setprio(3);
   T(*blk)[4] = reinterpret_cast<T(*)[4]>(Bs);
   T(*sol)[4] = blk + 3 * kPanelWidth;
+  T* Ld = Bs + 4 * kPanelWidth * 4;
+  static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd <= kTile * LD, "potrf LDS fits in Bs");
   const int K = pd.K - kStart, lda = pd.lda, nb = next.nb;
   // rows of the next panel, source columns from kStart on
   GP<const T> X = data + pd.off + (int64_t)sd.q0 * lda + kStart;
@@ -1599,8 +1609,179 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
     }
   };
   BSP_STAMP(0);
-  potrfTiles<T, 4>(data + next.diagOff, nb, next.lda, blk, sol, pre);
+  potrfTiles<T, 4>(data + next.diagOff, nb, next.lda, blk, sol, pre, Ld,
+                   (GP<T>)dinvOut + (size_t)blockIdx.y * kDinvBatchStride);
   BSP_STAMP(3);
+}
+
+// ------------------------------------------------------------------------------------------
+// K6  one launch per chain step inside an outer block: trsm of the panel + rank-nb update of the
+// rest of the block's columns (+ the next panel's potrf), replacing the trsm launch AND the update
+// launch of the step.  Workgroup = one 64x64 target tile (i, j) of the segment:
+//   * it solves its OWN copies of the panel rows it needs -- X_i (tile rows) and X_j (tile
+//     columns) -- with the register-only MFMA trsm (40 MFMAs per wave each), reading the unsolved
+//     rows from the chain's staging buffer `rawIn` (64 values per row, written by the previous
+//     step's update next to its in-place store): the matrix itself cannot be the source, because
+//     the workgroups of column tile 0 store X_i in place while others still need row tile i raw;
+//   * X_j goes through LDS once (XB); X_i stays in registers: in the layout of trsmStages it IS
+//     the MFMA A operand of the tile product, and XB rows read as 4 consecutive values are the B
+//     operand.  Wave w owns target rows 16w..16w+15 x 64 columns (4 MFMA tiles, K = 64: 64 MFMAs);
+//   * column tile 0 is the next panel: its tiles are also written to `rawOut` for the next step;
+//   * fuse: workgroup 0 (tile (0,0) = the next panel's diagonal block) continues into the potrf.
+// ------------------------------------------------------------------------------------------
+constexpr int kXbLd = kTile + 2;
+
+// rows ri (tile rows) and rj (tile columns, unless the tile is diagonal) of the staged panel ->
+// X_i in registers, X_j in XB (X_i itself for a diagonal tile), X_i stored in place when asked,
+// and the tile product D[t] = X_i (X_j rows 16t..16t+15)^T  (diagonal tile: t <= w only)
+template <typename T>
+struct ChainTile {
+  using Acc = typename Mfma<T>::Acc;
+  Acc xi[4], xj[4];
+  TrsmOps<T> o;
+  bool actI, actJ, diagTile;
+  __device__ __forceinline__ void load(GP<const T> rawIn, GP<const T> Lkk, GP<const T> dinv, int lda,
+                                       int nb, int ri, int rj, int rowsBelow, int segEnd,
+                                       bool diag) {
+    const int lane = threadIdx.x & 63;
+    diagTile = diag;
+    actI = ri < rowsBelow;
+    actJ = rj < segEnd;
+    // (staging rows are 64 values long whatever nb is: no clamping of the column index)
+    trsmLoadRows<T>(rawIn + (int64_t)(actI ? ri : 0) * kTile, kTile, lane, xi);
+    if (!diagTile) trsmLoadRows<T>(rawIn + (int64_t)(actJ ? rj : 0) * kTile, kTile, lane, xj);
+    trsmLoadOps<T>(Lkk, dinv, lda, nb, lane, o);
+  }
+  __device__ __forceinline__ void solve(int nb, T* XB, GP<T> storeRow /* or null */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    trsmMaskRows<T>(actI, nb, lane, xi);
+    trsmMaskOps<T>(nb, lane, o);
+    if (!diagTile) {
+      trsmMaskRows<T>(actJ, nb, lane, xj);
+      trsmStages<T>(o, nb, xj);
+    }
+    trsmStages<T>(o, nb, xi);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        XB[(16 * w + n) * kXbLd + 16 * j + 4 * q + r] = diagTile ? xi[j][r] : xj[j][r];
+      }
+    }
+    if (storeRow) trsmStoreRows<T>(storeRow, actI, nb, lane, xi);
+    ldsBarrier();
+  }
+  __device__ __forceinline__ void multiply(const T* XB, Acc (&D)[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      D[t] = Acc{0, 0, 0, 0};
+      if (!diagTile || t <= w) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            D[t] = Mfma<T>::run(xi[j][r], XB[(16 * t + n) * kXbLd + 16 * j + 4 * q + r], D[t]);
+          }
+        }
+      }
+      // (keeps the 16 LDS reads of the next column group from being hoisted above this one:
+      //  all 64 in flight at once cost 128 registers)
+      asm volatile("" ::: "memory");
+    }
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void chainStep(
+    PanelDesc pd, SegDesc sd, int nTasks, PanelDesc next, int fuse, DataRef<T> dref,
+    const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase) {
+  __shared__ T XB[kTile * kXbLd];
+  static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd <= kTile * kXbLd, "potrf LDS fits in XB");
+  using Acc = typename Mfma<T>::Acc;
+  GP<T> data = pickData(dref);
+  GP<const T> rawIn = (GP<const T>)rawInBase + blockIdx.y * rawStride;
+  GP<const T> dinv = (GP<const T>)dinvInBase + (size_t)blockIdx.y * kDinvBatchStride;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15;
+  const int nb = pd.nb, lda = pd.lda, rowsBelow = pd.rowsBelow, segEnd = sd.q0 + sd.m;
+  GP<const T> Lkk = data + pd.diagOff;
+  GP<T> P = data + pd.diagOff + (int64_t)nb * lda;  // the panel's rows below, in place
+
+  if (fuse && blockIdx.x == 0) {
+    // tile (0,0) = the next panel's diagonal block: update it inside the potrf and factor it
+    __builtin_amdgcn_s_setprio(3);
+    T(*blk)[4] = reinterpret_cast<T(*)[4]>(XB);
+    T(*sol)[4] = blk + 3 * kPanelWidth;
+    T* Ld = XB + 4 * kPanelWidth * 4;
+    ChainTile<T> ct;
+    const int ri = 16 * w + n;
+    ct.load(rawIn, Lkk, dinv, lda, nb, ri, ri, rowsBelow, segEnd, true);
+    auto pre = [&](Acc* acc) {
+      ct.solve(nb, XB, P + (int64_t)ri * lda);
+      Acc D[4];
+      ct.multiply(XB, D);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (t <= w) acc[t] -= D[t];
+      }
+      ldsBarrier();  // XB is about to become the potrf's blk / sol / Ld
+    };
+    BSP_STAMP(0);
+    potrfTiles<T, 4>(data + next.diagOff, next.nb, next.lda, blk, sol, pre, Ld,
+                     (GP<T>)dinvOutBase + (size_t)blockIdx.y * kDinvBatchStride);
+    BSP_STAMP(3);
+    return;
+  }
+
+  __builtin_amdgcn_s_setprio(2);
+  int idx = fuse ? 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1) : xcdContiguous(blockIdx.x, nTasks);
+  int colTile = sd.q0, rowTile;
+  for (;;) {
+    const int cnt = (rowsBelow - colTile + kTile - 1) / kTile;
+    if (idx < cnt) {
+      rowTile = colTile + kTile * idx;
+      break;
+    }
+    idx -= cnt;
+    colTile += kTile;
+  }
+  const int ri = rowTile + 16 * w + n, rj = colTile + 16 * w + n;
+  ChainTile<T> ct;
+  ct.load(rawIn, Lkk, dinv, lda, nb, ri, rj, rowsBelow, segEnd, rowTile == colTile);
+  // (column tile q0 covers every row tile once: its workgroups store X_i in place)
+  ct.solve(nb, XB, colTile == sd.q0 ? P + (int64_t)(ct.actI ? ri : 0) * lda : nullptr);
+  // (the old target values are fetched after the solve: these tiles are not on the critical path
+  //  -- the potrf workgroup is -- and the registers are needed for the trsm operands)
+  GP<T> tgt = data + sd.tgtBase;
+  T old[16];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int qc = min(colTile + 16 * t + n, segEnd - 1);
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      const int qr = min(rowTile + 16 * w + Mfma<T>::row(lane, reg), rowsBelow - 1);
+      old[t * 4 + reg] = tgt[(int64_t)qr * sd.tgtStride + qc];
+    }
+  }
+  Acc D[4];
+  ct.multiply(XB, D);
+  GP<T> rawOut = (GP<T>)rawOutBase + blockIdx.y * rawStride;
+  const int nbNext = next.nb;
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int qc = colTile + 16 * t + n;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      const int qr = rowTile + 16 * w + Mfma<T>::row(lane, reg);
+      if (qc < segEnd && qr < rowsBelow && qr >= qc && qr >= sd.rowMin) {
+        const T val = old[t * 4 + reg] - D[t][reg];
+        tgt[(int64_t)qr * sd.tgtStride + qc] = val;
+        if (rawOutBase && colTile == 0 && qc < nbNext && qr >= nbNext) {
+          rawOut[(int64_t)(qr - nbNext) * kTile + qc] = val;
+        }
+      }
+    }
+  }
 }
 
 // (A 128x128-tile variant of K5 -- 4x4 MFMA tiles per wave, 70 KB LDS, 2 workgroups per CU -- was

@@ -426,6 +426,11 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
   const int64_t nLumps = sk.numLumps();
   const int64_t denseFrom = elimRangesIn.empty() ? 0 : elimRangesIn.back();
   BASPACHO_CHECK_LT(sk.order(), (int64_t)INT32_MAX);
+  // lookahead schedule (addPanels): assumed rate of the bulk update beside the chain, and the share
+  // of the next block's estimated chain time handed to the side stream as optional work
+  constexpr double kBulkFlopsPerUs = 33e6;
+  double bulkAhead = 0.6;
+  if (const char* e = std::getenv("BSP_BULK_AHEAD")) bulkAhead = std::atof(e);
 
   vector<vector<PanelBuild>> levelBuckets;       // dense levels
   auto bucketAt = [](vector<vector<PanelBuild>>& buckets, size_t lvl) -> vector<PanelBuild>& {
@@ -444,6 +449,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                        const vector<SegDesc>& boardSegTemplates) {
     int32_t count = 0;
     const int64_t n = g.width;
+    vector<int64_t> pendingFrom;  // per column block of this lump (lookahead schedule, see below)
     for (int64_t blockStart = 0; blockStart < n; blockStart += kOuterWidth) {
       const int64_t blockEnd = std::min<int64_t>(n, blockStart + kOuterWidth);
       for (int64_t c0 = blockStart; c0 < blockEnd; c0 += kPanelWidth, count++) {
@@ -493,16 +499,69 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             plan.srcs.push_back(sr);
             const int32_t srcIdx = (int32_t)plan.srcs.size() - 1;
             if (sr.nRest > 0) {
+              // "now": the next outer block's columns, by this block alone (rank-256), on the
+              // execution stream
               SegDesc s{};
               s.src = srcIdx;
               s.kind = kSegIntra;
               s.outer = 1;
               s.lump = (int32_t)l;
               s.q0 = 0;
-              s.m = sr.nRest;
+              s.m = (int32_t)std::min<int64_t>(sr.nRest, kOuterWidth);
               s.tgtBase = g.diagOff + blockEnd * n + blockEnd;
               s.tgtStride = (int32_t)n;
               plan.segs.push_back(s);
+              // Columns further right go to the lookahead (side) stream, in DEADLINE order rather
+              // than source order: a column block c only has to be up to date when block c-1's
+              // "now" update reaches it, so what this block (and earlier ones) still owe to c is
+              // applied as late as the side stream's load allows -- and then in ONE pass over
+              // all pending source blocks (rank 256 x pending: the target tile is read and
+              // written once).  pendingFrom[c] = first source block not yet applied to c.
+              //   * first launch (outer = 2): c = b + 2, the columns the next block's "now" update
+              //     touches (the execution stream waits for this launch);
+              //   * optional (outer = 3): c = b + 3, b + 4 ... while the estimated time stays
+              //     within the next block's chain (plan-time estimate; events enforce order).
+              const int64_t b = blockStart / kOuterWidth;
+              const int64_t numBlocks = (n + kOuterWidth - 1) / kOuterWidth;
+              if ((int64_t)pendingFrom.size() < numBlocks) pendingFrom.assign(numBlocks, 0);
+              auto unitFlops = [&](int64_t c) {
+                const double m = double(std::min<int64_t>(kOuterWidth, n - c * kOuterWidth));
+                const double R = double(n - c * kOuterWidth + g.rowsBelow);
+                return 2.0 * double(blockEnd - pendingFrom[c] * kOuterWidth) * (m * R - m * (m - 1) / 2);
+              };
+              // one unit per pending source block (rank 256 each: tiles of one launch then take
+              // about the same time -- a single pass of rank 256 x pending would leave the launch
+              // waiting for its few longest tiles); several units on one target in one launch
+              // accumulate with atomics (sd.pad = 1)
+              auto pushUnit = [&](int64_t c, int32_t outerKind) {
+                const int32_t multi = pendingFrom[c] < b ? 1 : 0;
+                for (int64_t sb = pendingFrom[c]; sb <= b; sb++) {
+                  SrcDesc fs = sr;
+                  fs.off = g.diagOff + blockEnd * n + sb * kOuterWidth;
+                  fs.K = (int32_t)(std::min<int64_t>(blockEnd, (sb + 1) * kOuterWidth) - sb * kOuterWidth);
+                  plan.srcs.push_back(fs);
+                  SegDesc u = s;
+                  u.src = (int32_t)plan.srcs.size() - 1;
+                  u.outer = outerKind;
+                  u.q0 = (int32_t)(c * kOuterWidth - blockEnd);
+                  u.m = (int32_t)std::min<int64_t>(kOuterWidth, n - c * kOuterWidth);
+                  u.pad = multi;
+                  plan.segs.push_back(u);
+                }
+                pendingFrom[c] = b + 1;
+              };
+              double budgetUs = bulkAhead * (118.0 + 0.012 * double(sr.rowsBelow));
+              // (topping the first launch up to a full round of workgroups with the nearest
+              //  optional targets was measured slower: the execution stream waits on it)
+              int64_t c = b + 2;
+              if (c < numBlocks) {
+                budgetUs -= unitFlops(c) / kBulkFlopsPerUs;
+                pushUnit(c++, 2);
+              }
+              for (; c < numBlocks && budgetUs > 0; c++) {
+                budgetUs -= unitFlops(c) / kBulkFlopsPerUs;
+                pushUnit(c, 3);
+              }
             }
             if (withBoards) {
               for (SegDesc s : boardSegTemplates) {
@@ -675,8 +734,8 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         for (int64_t s = panelSegBegin[pb.panel]; s < panelSegEnd[pb.panel]; s++) {
           const SegDesc& sd = plan.segs[s];
           const SrcDesc& sr = plan.srcs[sd.src];
-          const int32_t atomic = sd.kind == kSegBoard && hits[sd.tgtBase] > 1 ? 1 : 0;
-          if (sd.outer) {
+          const int32_t atomic = (sd.kind == kSegBoard && hits[sd.tgtBase] > 1) || sd.pad ? 1 : 0;
+          if (sd.outer == 1) {
             // this block-wide update touches columns that the previous block's deferred tiles
             // of the same lump also touch: they must have completed
             auto it = lastDeferredLevel.find(sd.lump);
@@ -685,11 +744,11 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           bool anyDeferred = false;
           const int32_t step = kTile;
           for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += step) {
-            const bool defer = sd.outer && cT - sd.q0 >= kOuterWidth;
+            const bool defer = sd.outer >= 2;  // lookahead units: every tile goes to the side stream
             for (int32_t rT = cT; rT < sr.rowsBelow; rT += step) {
               const UpdTask t{(int32_t)s, rT, cT, atomic};
               if (defer) {
-                const bool late = cT - sd.q0 >= 2 * kOuterWidth;
+                const bool late = sd.outer == 3;
                 (late ? deferredLate : deferred).push_back(t);
                 anyDeferred = true;
               } else {
@@ -748,6 +807,11 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           const SegDesc& sd = plan.segs[lr.directSeg];
           const PanelDesc& next = plan.panels[buckets[bi + 1][0].panel];
           // (a narrower next panel does not fill tile 0: its rows below the panel would be missed)
+          if (sd.q0 == 0 && sd.rowMin == 0 && sd.tgtBase == next.diagOff &&
+              sd.tgtStride == next.lda) {
+            lr.rawNext = 1;
+            plan.maxChainRows = std::max<int64_t>(plan.maxChainRows, next.rowsBelow);
+          }
           if (sd.q0 == 0 && sd.rowMin == 0 && sd.tgtBase == next.diagOff && next.nb == kTile &&
               sd.tgtStride == next.lda && lr.updEnd - lr.updBegin >= 2) {
             lr.fuseNext = 1;

@@ -102,6 +102,10 @@ struct LevelRange {
   // level's trsm launch, so that the potrf workgroup of the update launch only applies the
   // columns of the last panel
   int32_t splitK = 0;
+  // rawNext: the column block of the NEXT level's (single) panel below its diagonal block is
+  // written by this level's direct update launch alone, which then also stores it to the chain's
+  // staging buffer (chainStep reads the unsolved panel rows from there)
+  int32_t rawNext = 0;
   int64_t waitDefLevel;          // index (within the same level list) of the level whose deferred
                                  // tiles must be complete before this level's update launch; -1
 };
@@ -209,6 +213,7 @@ struct HipPlanHost {
   double elimColElems = 0;   // numeric elements of the sparse-eliminated columns
   int64_t numLaunches = 0;
   int64_t maxPanelsInLevel = 0;
+  int64_t maxChainRows = 0;  // max rows below a panel whose level sets rawNext (staging buffer rows)
   bool hasDeferred = false;  // some level carries lookahead (deferred) tiles
 };
 
