@@ -44,7 +44,8 @@ class _CPlanStats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in
                 ["flops", "upd_elems", "upd_flops", "elim_pair_elems", "elim_pair_flops",
                  "elim_col_elems", "upd_flops_direct", "elim_pair_operand_elems",
-                 "elim_target_elems", "trsm_flops", "potrf_flops"]] + \
+                 "elim_target_elems", "trsm_flops", "potrf_flops", "trsm_flops_merged",
+                 "potrf_flops_fused"]] + \
                [(n, ctypes.c_int64) for n in
                 ["num_launches", "num_levels", "num_panels", "num_segs", "num_upd_tasks",
                  "num_trsm_tasks", "chain_tab_entries", "max_panels_in_level",

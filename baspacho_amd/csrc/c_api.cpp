@@ -388,6 +388,8 @@ int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out) {
   out->elim_target_elems = p.elimTargetElems;
   out->trsm_flops = p.trsmFlops;
   out->potrf_flops = p.potrfFlops;
+  out->trsm_flops_merged = p.trsmFlopsMerged;
+  out->potrf_flops_fused = p.potrfFlopsFused;
   out->num_launches = p.numLaunches;
   out->num_levels = p.numLevels;
   out->num_panels = p.numPanels;

@@ -26,7 +26,7 @@ struct HipKernelProfile {
 struct HipPlanStats {
   double flops = 0, updElems = 0, updFlops = 0, elimPairElems = 0, elimPairFlops = 0,
          elimColElems = 0, updFlopsDirect = 0, elimPairOperandElems = 0, elimTargetElems = 0,
-         trsmFlops = 0, potrfFlops = 0;
+         trsmFlops = 0, potrfFlops = 0, trsmFlopsMerged = 0, potrfFlopsFused = 0;
   int64_t numLaunches = 0, numLevels = 0, numPanels = 0, numSegs = 0, numUpdTasks = 0,
           numTrsmTasks = 0, chainTabEntries = 0, maxPanelsInLevel = 0, numAtomicUpdTasks = 0;
 };

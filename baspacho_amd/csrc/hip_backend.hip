@@ -1026,6 +1026,8 @@ HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t up
   s.elimTargetElems = p.elimTargetElems;
   s.trsmFlops = p.trsmFlops;
   s.potrfFlops = p.potrfFlops;
+  s.trsmFlopsMerged = p.trsmFlopsMerged;
+  s.potrfFlopsFused = p.potrfFlopsFused;
   s.numLaunches = p.numLaunches;
   s.numLevels = (int64_t)p.levels.size();
   s.numPanels = (int64_t)p.panels.size();

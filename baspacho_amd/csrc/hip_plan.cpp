@@ -829,6 +829,26 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                           (lr.defEnd > lr.defBegin);
       out.push_back(lr);
     }
+    // which trsm / potrf run inside another launch (measurement only)
+    for (size_t li = 0; li < out.size(); li++) {
+      const LevelRange& lr = out[li];
+      const bool directUpd = lr.directPanel >= 0 && lr.directSeg >= 0 && lr.updEnd > lr.updBegin;
+      const bool nextDirect = li + 1 < out.size() && out[li + 1].directPanel >= 0;
+      if (directUpd && lr.fuseNext && nextDirect) {
+        const double nb = plan.panels[out[li + 1].directPanel].nb;
+        plan.potrfFlopsFused += nb * nb * nb / 3.0;
+      }
+      if (li > 0 && directUpd && lr.trsmEnd > lr.trsmBegin) {
+        const LevelRange& pr = out[li - 1];
+        const bool staged = pr.directPanel >= 0 && pr.directSeg >= 0 && pr.updEnd > pr.updBegin &&
+                            pr.rawNext;
+        const SegDesc& sd = plan.segs[lr.directSeg];
+        const PanelDesc& pd = plan.panels[lr.directPanel];
+        if (staged && !sd.outer && plan.srcs[sd.src].K == pd.nb) {
+          plan.trsmFlopsMerged += double(pd.rowsBelow) * pd.nb * pd.nb;
+        }
+      }
+    }
   };
   for (size_t r = 0; r < plan.elimRanges.size(); r++) {
     emitLevels(elimBigBuckets[r], plan.elimRanges[r].bigLevels);

@@ -199,6 +199,9 @@ struct HipPlanHost {
 
   double updFlopsDirect = 0, elimPairOperandElems = 0, elimTargetElems = 0, trsmFlops = 0,
          potrfFlops = 0;  // part of updFlops launched through the direct chain kernels
+  // of trsmFlops / potrfFlops: the part done inside chainStep launches / inside the previous
+  // level's update launch (same decisions as launchLevels with the default switches)
+  double trsmFlopsMerged = 0, potrfFlopsFused = 0;
   std::vector<int32_t> levelPanels;
   std::vector<TrsmTask> trsmTasks;
   std::vector<UpdTask> updTasks;

@@ -189,12 +189,15 @@ def main():
             pair_src_bytes = 8.0 * 2.0 * st["elim_pair_operand_elems"]
             work_of = {
                 "update": ("updateTile<%s>" % DT, "mfma", st["upd_flops"] - st["upd_flops_direct"]),
-                "chain_update": ("updateTileDirectPotrf<%s>" % DT, "mfma", st["upd_flops_direct"]),
+                # (one-panel levels: update tiles + the next panel's potrf, and inside an outer block
+                #  also the panel's trsm, in one launch)
+                "chain_update": ("chainStep|updateTileDirectPotrf<%s>" % DT, "mfma",
+                                 st["upd_flops_direct"] + st["trsm_flops_merged"] + st["potrf_flops_fused"]),
                 "elim_update": ("elimGatherMfma<%s>" % DT, "hbm",
                                 pair_src_bytes + 16.0 * st["elim_target_elems"]),
                 "elim_factor": ("elimFactorTiny|elimFactorSmall<%s>" % DT, "hbm", 16.0 * st["elim_col_elems"]),
-                "trsm": ("trsmPanel<%s>" % DT, "mfma", st["trsm_flops"]),
-                "potrf": ("potrfPanel<%s>" % DT, "mfma", st["potrf_flops"]),
+                "trsm": ("trsmPanel<%s>" % DT, "mfma", st["trsm_flops"] - st["trsm_flops_merged"]),
+                "potrf": ("potrfPanel<%s>" % DT, "mfma", st["potrf_flops"] - st["potrf_flops_fused"]),
             }
             # dominant class = largest event time; classes within 5 % of it count as tied and the
             # one carrying more of the algorithmic work wins (all classes are in kernel_rates)

@@ -184,7 +184,9 @@ typedef struct bsp_plan_stats {
       upd_flops_direct,        /* part of upd_flops launched by the one-panel-level kernels */
       elim_pair_operand_elems, /* values of both source blocks, summed over the pairs */
       elim_target_elems,       /* distinct target elements of the sparse-elimination update */
-      trsm_flops, potrf_flops; /* dense panels: rowsBelow*nb^2 and nb^3/3 */
+      trsm_flops, potrf_flops, /* dense panels: rowsBelow*nb^2 and nb^3/3 */
+      trsm_flops_merged,       /* ... of which inside chain-step launches (trsm + update + potrf) */
+      potrf_flops_fused;       /* ... of which inside the previous level's update launch */
   int64_t num_launches, num_levels, num_panels, num_segs, num_upd_tasks, num_trsm_tasks,
       chain_tab_entries, max_panels_in_level, num_atomic_upd_tasks;
 } bsp_plan_stats;
