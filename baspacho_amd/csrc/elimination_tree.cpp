@@ -1,6 +1,7 @@
 #include "elimination_tree.h"
 
 #include <algorithm>
+#include <cmath>
 #include <queue>
 
 #include "bsp_utils.h"
@@ -142,6 +143,18 @@ void EliminationTree::computeMerges() {
            sygeCosts[node].c1 * size + asmblCosts[node].c0 + asmblCosts[node].c1 * merged;
   };
 
+  // Extension for the level-scheduled backend (no counterpart in EliminationTree.cpp): a node
+  // that is the ONLY child of its parent runs strictly before it, one level (potrf -> trsm ->
+  // update, ~20 us of launches and dependent round trips) per 64-column panel, with nothing else
+  // of that subtree to overlap; merging such a pair saves the levels the panel count drops by.
+  // Siblings share their levels, so the term is not charged for them.
+  constexpr double kChainLevelCost = 2.0e-5, kPanel = 64.0;
+  vector<int64_t> childCount(n, 0);
+  for (int64_t k = 0; k < n; k++) {
+    if (parent[k] >= 0) childCount[parent[k]]++;
+  }
+  auto levelsOf = [&](double size) { return std::ceil(size / kPanel); };
+
   using Cand = std::tuple<double, int64_t, int64_t>;  // (score, child, parent)
   std::priority_queue<Cand> queue;
   for (int64_t k = n - 1; k >= 0; k--) {
@@ -168,9 +181,12 @@ void EliminationTree::computeMerges() {
     const double sp = double(nodeSize[p]), rp = double(nodeRows[p]);
     const double tSeparate = nodeTime(k, sk, rk, double(numMergedNodes[k])) +
                              nodeTime(p, sp, rp, double(numMergedNodes[p]));
-    const double tMerged =
-        nodeTime(p, sp + sk, rp, double(numMergedNodes[k] + numMergedNodes[p]));
+    double tMerged = nodeTime(p, sp + sk, rp, double(numMergedNodes[k] + numMergedNodes[p]));
+    if (childCount[p] == 1) {
+      tMerged -= kChainLevelCost * (levelsOf(sk) + levelsOf(sp) - levelsOf(sk + sp));
+    }
     if (!(tMerged < tSeparate)) continue;
+    childCount[p] += childCount[k] - 1;
 
     const int64_t oldSizeP = nodeSize[p], oldMergedP = numMergedNodes[p];
     mergeWith[k] = p;
