@@ -385,8 +385,10 @@ struct HipNumericCtx : NumericCtx<T> {
       const bool merged = rawValid && directUpd && nT && !plan.host.segs[lr.directSeg].outer &&
                           plan.host.srcs[plan.host.segs[lr.directSeg].src].K ==
                               plan.host.panels[lr.directPanel].nb;
+      bool waitedDef = false;
       if (splitK && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
         hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
+        waitedDef = true;
       }
       if (nT && !merged) {
         timer.begin(kProfTrsm);
@@ -405,7 +407,8 @@ struct HipNumericCtx : NumericCtx<T> {
         }
         timer.end();
       }
-      if (lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
+      // (a second wait on the same event would still cost a ~6 us bubble between the launches)
+      if (!waitedDef && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
         hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
       }
       const int64_t updBegin = lr.updBegin;
