@@ -61,9 +61,10 @@ struct DevBuf {
 struct DevPlan {
   HipPlanHost host;
   DevBuf panels, srcs, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
-      updTasks, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc,
+      updTasks, updTasksFat, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc,
       elimPairSlot, elimRows, elimRowSlots;
   int64_t numUpdTasks = 0;
+  vector<int64_t> slowPrefix;  // tasks [0, i) that updateTileBulk cannot take
   // forward-solve gather lists, built on the first solve that needs them
   bool solveGatherReady = false;
   SolveGatherPlan solveGather;
@@ -92,6 +93,31 @@ struct DevPlan {
     levelPanels.upload(host.levelPanels);
     trsmTasks.upload(host.trsmTasks);
     updTasks.upload(host.updTasks);
+    {
+      vector<UpdTaskFat> fat(host.updTasks.size());
+      slowPrefix.assign(host.updTasks.size() + 1, 0);
+      for (size_t i = 0; i < host.updTasks.size(); i++) {
+        const UpdTask& t = host.updTasks[i];
+        const SegDesc& sd = host.segs[t.seg];
+        const SrcDesc& sr = host.srcs[sd.src];
+        UpdTaskFat& f = fat[i];
+        f.srcOff = sr.off;
+        f.tgtBase = sd.tgtBase;
+        f.lda = sr.lda;
+        f.K = sr.K;
+        f.rowsBelow = sr.rowsBelow;
+        f.segEnd = sd.q0 + sd.m;
+        f.rowTile = t.rowTile;
+        f.colTile = t.colTile;
+        f.tgtStride = sd.tgtStride;
+        f.rowMin = sd.rowMin;
+        f.atomic = t.atomic;
+        f.fast = sd.kind == kSegIntra && sr.K > 0 && sr.K % hipk::kUpdChunk == 0;
+        f.pad0 = f.pad1 = 0;
+        slowPrefix[i + 1] = slowPrefix[i] + (f.fast ? 0 : 1);
+      }
+      updTasksFat.upload(fat);
+    }
     elimChainLump.upload(host.elimChainLump);
     elimLumpDesc.upload(host.elimLumpDesc);
     elimPairSlot.upload(host.elimPairSlot);
@@ -173,6 +199,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
     if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
     if (const char* e = std::getenv("BSP_MERGED_CHAIN")) mergedChain = e[0] != '0';
+    if (const char* e = std::getenv("BSP_BULK_KERNEL")) bulkKernel = e[0] != '0';
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -289,6 +316,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
   bool fusePotrf = true;    // next panel's potrf inside the update launch (BSP_FUSE_POTRF=0 disables)
+  bool bulkKernel = true;   // self-contained tasks + 16-byte staging for plain intra-lump tiles (BSP_BULK_KERNEL=0: table-driven updateTile)
   bool mergedChain = true;  // trsm + update (+ next potrf) of an intra-block step in one launch (BSP_MERGED_CHAIN=0 disables)
   bool directChain = true;  // descriptor-by-value kernels on one-panel levels (BSP_DIRECT_CHAIN=0 disables)
   vector<hipEvent_t> events;
@@ -317,6 +345,15 @@ struct HipNumericCtx : NumericCtx<T> {
   void launchUpdate(DevPlan& plan, int64_t begin, int64_t end, hipk::DataRef<BT> ref,
                     hipStream_t stream, BT* altTarget = nullptr, int64_t altStride = 0,
                     unsigned extraLds = 0) {
+    if (sym.bulkKernel && altTarget == nullptr && end < (int64_t)plan.slowPrefix.size() &&
+        plan.slowPrefix[end] == plan.slowPrefix[begin]) {
+      // (32 KB of static LDS instead of updateTile's 34.8: 3 KB more padding keeps it at three
+      //  workgroups per CU next to a chain workgroup)
+      const unsigned pad = extraLds ? extraLds + 3072 : 0;
+      hipk::updateTileBulk<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, pad,
+                                stream>>>(plan.updTasksFat.as<UpdTaskFat>() + begin, ref);
+      return;
+    }
     hipk::updateTile<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, extraLds, stream>>>(
         plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(), plan.updTasks.as<UpdTask>() + begin,
         plan.chainOffTab.as<int64_t>(), plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(),

@@ -1294,41 +1294,52 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
   // every wave runs its 2x2 MFMA tiles over the chunk.
   constexpr int RSTEP = 256 / KC, NIT = kTile / RSTEP;
   const int sk = tid % KC, sr = tid / KC;
+  // the next chunk is fetched (into registers) while the current one is multiplied: a chunk's
+  // loads miss L2 four times out of ten beside the other tiles and take microseconds
+  T va[NIT], vb[NIT];
+  auto fetch = [&](int kBase) {
+    const int kcl = min(kBase + sk, K - 1);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int qa = min(task.rowTile + sr + RSTEP * it, pd.rowsBelow - 1);
+      va[it] = P[(int64_t)qa * lda + kcl];
+    }
+    if (!diagTile) {
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int qb = min(task.colTile + sr + RSTEP * it, segEnd - 1);
+        vb[it] = P[(int64_t)qb * lda + kcl];
+      }
+    }
+  };
+#ifdef BSP_BULK_PREFETCH
+  fetch(0);
+#endif
   for (int kBase = 0; kBase < K; kBase += KC) {
     const int kc = min(KC, K - kBase);
     const int kPad = (kc + 3) & ~3;
-    {
-      const int kcl = kBase + min(sk, kc - 1);
-      T va[NIT], vb[NIT];
+#ifndef BSP_BULK_PREFETCH
+    fetch(kBase);
+#endif
+    if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int qa = min(task.rowTile + sr + RSTEP * it, pd.rowsBelow - 1);
-        va[it] = P[(int64_t)qa * lda + kcl];
-      }
-      if (!diagTile) {
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-          const int qb = min(task.colTile + sr + RSTEP * it, segEnd - 1);
-          vb[it] = P[(int64_t)qb * lda + kcl];
-        }
-      }
-      if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
+    for (int it = 0; it < NIT; it++) {
+      const int r = sr + RSTEP * it;
+      As[r * LD + sk] = (sk < kc && task.rowTile + r < pd.rowsBelow) ? va[it] : T(0);
+    }
+    if (!diagTile) {
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
         const int r = sr + RSTEP * it;
-        As[r * LD + sk] = (sk < kc && task.rowTile + r < pd.rowsBelow) ? va[it] : T(0);
-      }
-      if (!diagTile) {
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-          const int r = sr + RSTEP * it;
-          Bs[r * LD + sk] = (sk < kc && task.colTile + r < segEnd) ? vb[it] : T(0);
-        }
+        Bs[r * LD + sk] = (sk < kc && task.colTile + r < segEnd) ? vb[it] : T(0);
       }
     }
     __syncthreads();
+#ifdef BSP_BULK_PREFETCH
+    if (kBase + KC < K) fetch(kBase + KC);
+#endif
     if (!skipUpper) {
-      for (int k0 = 0; k0 < kPad; k0 += 4) {
+      auto kstep = [&](int k0) __attribute__((always_inline)) {
         const T a0 = As[(wr + li) * LD + k0 + lk];
         const T a1 = As[(wr + 16 + li) * LD + k0 + lk];
         const T b0 = Bt[(wc + li) * LD + k0 + lk];
@@ -1337,6 +1348,15 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
         acc01 = Mfma<T>::run(a0, b1, acc01);
         acc10 = Mfma<T>::run(a1, b0, acc10);
         acc11 = Mfma<T>::run(a1, b1, acc11);
+      };
+#ifdef BSP_BULK_UNROLL
+      if (kPad == KC) {
+#pragma unroll
+        for (int k0 = 0; k0 < KC; k0 += 4) kstep(k0);
+      } else
+#endif
+      {
+        for (int k0 = 0; k0 < kPad; k0 += 4) kstep(k0);
       }
     }
   }
@@ -1379,6 +1399,131 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
           if (ok[t * 4 + reg]) *ptr[t * 4 + reg] = old[t * 4 + reg] - (*accs[t])[reg];
+        }
+      }
+    }
+  }
+}
+
+// K5b  the bulk of the bulk: plain intra-lump tiles whose source width is a multiple of the K
+// chunk (every lookahead unit, rank 256).  Against updateTile:
+//   * the task is self-contained: one uniform 64-byte load instead of the task -> segment ->
+//     source chain of dependent loads, no row / column tables in LDS;
+//   * operands go straight from global memory to LDS (global_load_lds_dwordx4: lane t of a wave
+//     lands at base + 16 t bytes, so one wave instruction fills 4 rows of 32 doubles / 8 rows of
+//     32 floats): no staging registers, no LDS stores, no masking -- rows beyond the end are
+//     clamped onto valid ones, their products only reach entries the scatter masks off;
+//   * rows are unpadded in LDS; instead the 16-byte slot index of a row is XOR-swizzled with the
+//     row (fp64: slot ^ (r & 15), fp32: slot ^ ((r >> 1) & 7)), which keeps the MFMA operand
+//     fetch (lane (li, lk) reads [li][k0 + lk]) at the two-lanes-per-8-bytes minimum;
+//   * the old target values are requested before the K loop.
+// tools/tile_update_probe.hip has the structure study: MFMA + LDS-read loop alone 66-71 TF/s at
+// 3-4 workgroups per CU, register staging 55-60, direct-to-LDS 61-65, + read-modify-write of the
+// target ~ -15 %.
+template <typename T>
+struct BulkSwizzle {
+  static constexpr int E = 16 / (int)sizeof(T);  // elements per 16-byte slot
+  static __device__ __forceinline__ int key(int r) { return sizeof(T) == 8 ? (r & 15) : ((r >> 1) & 7); }
+  // element offset of (row r, column k) inside an unpadded [64][kUpdChunk] operand
+  static __device__ __forceinline__ int at(int r, int k) {
+    return r * kUpdChunk + E * ((k / E) ^ key(r)) + (k % E);
+  }
+};
+template <typename T>
+__global__ __launch_bounds__(256) void updateTileBulk(const UpdTaskFat* tasks, DataRef<T> dref) {
+  constexpr int KC = kUpdChunk, E = BulkSwizzle<T>::E, SLOTS = KC / E, RPI = 64 / SLOTS;
+  constexpr int NI = kTile / (4 * RPI);  // wave instructions per operand and wave
+  typedef __attribute__((address_space(1))) const void* GV;
+  typedef __attribute__((address_space(3))) void* LV;
+  __shared__ __attribute__((aligned(16))) T As[kTile * KC];
+  __shared__ __attribute__((aligned(16))) T Bs[kTile * KC];
+  const UpdTaskFat t = tasks[blockIdx.x];
+  GP<T> data = pickData(dref);
+  GP<const T> P = data + t.srcOff;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = t.K, lda = t.lda;
+  const bool diagTile = t.rowTile == t.colTile;
+  const T* Bt = diagTile ? As : Bs;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  const int li = lane & 15, lk = lane >> 4;
+  using Acc = typename Mfma<T>::Acc;
+  Acc acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+  const bool skipUpper = diagTile && wr < wc;
+
+  // wave w, instruction it: rows RPI * (4 it + w) .. + RPI - 1; lane -> (row, slot)
+  GP<const T> srcA[NI], srcB[NI];
+#pragma unroll
+  for (int it = 0; it < NI; it++) {
+    const int r = RPI * (4 * it + wave) + lane / SLOTS;
+    const int slot = (lane % SLOTS) ^ BulkSwizzle<T>::key(r);
+    srcA[it] = P + (int64_t)min(t.rowTile + r, t.rowsBelow - 1) * lda + E * slot;
+    srcB[it] = P + (int64_t)min(t.colTile + r, t.segEnd - 1) * lda + E * slot;
+  }
+  // old target values (masked-off entries are clamped onto valid ones)
+  GP<T> tgt = data + t.tgtBase;
+  T old[16];
+  if (!t.atomic) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int qc = min(t.colTile + wc + (q & 1) * 16 + li, t.segEnd - 1);
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int qr = min(t.rowTile + wr + (q >> 1) * 16 + Mfma<T>::row(lane, reg), t.rowsBelow - 1);
+        old[q * 4 + reg] = tgt[(int64_t)qr * t.tgtStride + qc];
+      }
+    }
+  }
+  const int oa0 = BulkSwizzle<T>::at(wr + li, lk), oa1 = BulkSwizzle<T>::at(wr + 16 + li, lk);
+  const int ob0 = BulkSwizzle<T>::at(wc + li, lk), ob1 = BulkSwizzle<T>::at(wc + 16 + li, lk);
+  const int ka0 = BulkSwizzle<T>::key(wr + li), ka1 = BulkSwizzle<T>::key(wr + 16 + li);
+  const int kb0 = BulkSwizzle<T>::key(wc + li), kb1 = BulkSwizzle<T>::key(wc + 16 + li);
+  for (int kBase = 0; kBase < K; kBase += KC) {
+    if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
+#pragma unroll
+    for (int it = 0; it < NI; it++) {
+      __builtin_amdgcn_global_load_lds((GV)(srcA[it] + kBase), (LV)(As + RPI * (4 * it + wave) * KC),
+                                       16, 0, 0);
+    }
+    if (!diagTile) {
+#pragma unroll
+      for (int it = 0; it < NI; it++) {
+        __builtin_amdgcn_global_load_lds((GV)(srcB[it] + kBase),
+                                         (LV)(Bs + RPI * (4 * it + wave) * KC), 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!skipUpper) {
+#pragma unroll
+      for (int k0 = 0; k0 < KC; k0 += 4) {
+        // (row r, column k0 + lk): slot (k0 + lk) / E moves by k0 / E under the XOR key
+        const int s = k0 / E;
+        const T a0 = As[oa0 + E * (((lk / E + s) ^ ka0) - ((lk / E) ^ ka0))];
+        const T a1 = As[oa1 + E * (((lk / E + s) ^ ka1) - ((lk / E) ^ ka1))];
+        const T b0 = Bt[ob0 + E * (((lk / E + s) ^ kb0) - ((lk / E) ^ kb0))];
+        const T b1 = Bt[ob1 + E * (((lk / E + s) ^ kb1) - ((lk / E) ^ kb1))];
+        acc00 = Mfma<T>::run(a0, b0, acc00);
+        acc01 = Mfma<T>::run(a0, b1, acc01);
+        acc10 = Mfma<T>::run(a1, b0, acc10);
+        acc11 = Mfma<T>::run(a1, b1, acc11);
+      }
+    }
+  }
+  if (!skipUpper) {
+    const Acc* accs[4] = {&acc00, &acc01, &acc10, &acc11};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int qc = t.colTile + wc + (q & 1) * 16 + li;
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int qr = t.rowTile + wr + (q >> 1) * 16 + Mfma<T>::row(lane, reg);
+        if (qc < t.segEnd && qr < t.rowsBelow && qr >= qc && qr >= t.rowMin) {
+          GP<T> p = tgt + (int64_t)qr * t.tgtStride + qc;
+          if (t.atomic) {
+            atomicSub(p, (*accs[q])[reg]);
+          } else {
+            *p = old[q * 4 + reg] - (*accs[q])[reg];
+          }
         }
       }
     }
@@ -1791,16 +1936,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Measurement helper: sustained rate of back-to-back independent v_mfma_f64_16x16x4_f64 (4
 // accumulators per wave).  bench.py reports it next to the datasheet peak.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mfmaF64Probe(double* out, int iters) {
-  double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+__global__ void mfmaF64Probe(double* out, int iters) {
+  // (no __launch_bounds__(256): with it hipcc puts the accumulators in AGPRs but keeps the
+  //  loop-carried values in VGPRs and copies them over and back around the MFMAs of every
+  //  iteration -- 64 moves per 4 MFMAs, which measured 44 TFLOP/s instead of 77)
+  double4_t c[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) c[k] = double4_t{0, 0, 0, 0};
   const double a = threadIdx.x * 1e-3, b = threadIdx.x * 2e-3;
   for (int i = 0; i < iters; i++) {
-    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
-    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
-    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) c[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[k], 0, 0, 0);
   }
-  out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) s += c[k][k];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
 // ------------------------------------------------------------------------------------------

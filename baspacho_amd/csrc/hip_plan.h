@@ -73,6 +73,18 @@ struct UpdTask {
   int32_t atomic;   // 1: several panels of this level hit the same target lump
 };
 
+// Self-contained form of an UpdTask of an intra-lump segment whose source width is a multiple of
+// the K chunk (every lookahead unit is): what updateTileBulk needs in ONE uniform 64-byte load
+// instead of the task -> segment -> source chain of three dependent ones.  Built at upload time.
+struct UpdTaskFat {
+  int64_t srcOff;   // SrcDesc::off
+  int64_t tgtBase;  // SegDesc::tgtBase
+  int32_t lda, K, rowsBelow, segEnd;
+  int32_t rowTile, colTile, tgtStride, rowMin;
+  int32_t atomic, fast, pad0, pad1;  // fast = 0: not eligible (board segment / ragged K)
+};
+static_assert(sizeof(UpdTaskFat) == 64, "one scalar load");
+
 struct TrsmTask {
   int32_t panel;
   int32_t rowTile;
