@@ -1429,16 +1429,15 @@ struct BulkSwizzle {
     return r * kUpdChunk + E * ((k / E) ^ key(r)) + (k % E);
   }
 };
+// As, Bs: kTile * kUpdChunk values each, 16-byte aligned.  rawOut / nbNext: see
+// updateTileDirectBody (chain staging buffer of the next panel's rows).
 template <typename T>
-__global__ __launch_bounds__(256) void updateTileBulk(const UpdTaskFat* tasks, DataRef<T> dref) {
+__device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T* As, T* Bs,
+                                             GP<T> rawOut = nullptr, int nbNext = 0) {
   constexpr int KC = kUpdChunk, E = BulkSwizzle<T>::E, SLOTS = KC / E, RPI = 64 / SLOTS;
   constexpr int NI = kTile / (4 * RPI);  // wave instructions per operand and wave
   typedef __attribute__((address_space(1))) const void* GV;
   typedef __attribute__((address_space(3))) void* LV;
-  __shared__ __attribute__((aligned(16))) T As[kTile * KC];
-  __shared__ __attribute__((aligned(16))) T Bs[kTile * KC];
-  const UpdTaskFat t = tasks[blockIdx.x];
-  GP<T> data = pickData(dref);
   GP<const T> P = data + t.srcOff;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = t.K, lda = t.lda;
@@ -1522,12 +1521,24 @@ __global__ __launch_bounds__(256) void updateTileBulk(const UpdTaskFat* tasks, D
           if (t.atomic) {
             atomicSub(p, (*accs[q])[reg]);
           } else {
-            *p = old[q * 4 + reg] - (*accs[q])[reg];
+            const T val = old[q * 4 + reg] - (*accs[q])[reg];
+            *p = val;
+            if (rawOut && t.colTile == 0 && qc < nbNext && qr >= nbNext) {
+              rawOut[(int64_t)(qr - nbNext) * kTile + qc] = val;
+            }
           }
         }
       }
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void updateTileBulk(const UpdTaskFat* tasks, DataRef<T> dref) {
+  __shared__ __attribute__((aligned(16))) T As[kTile * kUpdChunk];
+  __shared__ __attribute__((aligned(16))) T Bs[kTile * kUpdChunk];
+  const UpdTaskFat t = tasks[blockIdx.x];
+  bulkTileBody<T>(t, pickData(dref), As, Bs);
 }
 
 // K5d  direct variant for the update tiles of a one-panel level that all belong to ONE
@@ -1698,13 +1709,16 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
                                                              int kStart, T* dinvOut, T* rawOut,
                                                              int64_t rawStride) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
-  __shared__ T As[kTile * LD];
-  __shared__ T Bs[kTile * LD];
+  __shared__ __attribute__((aligned(16))) T As[kTile * LD];
+  __shared__ __attribute__((aligned(16))) T Bs[kTile * LD];
   GP<T> data = pickData(dref);
   if (blockIdx.x != 0) {
     __builtin_amdgcn_s_setprio(2);
-    updateTileDirectBody<T>(pd, sd, 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1), data, As, Bs,
-                            rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr, next.nb);
+    const int idx = 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1);
+    GP<T> raw = rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr;
+    // (the bulk tile body -- operands straight to LDS, no register prefetch -- was measured
+    //  slower for these tiles: they run on the chain's stream, where latency counts)
+    updateTileDirectBody<T>(pd, sd, idx, data, As, Bs, raw, next.nb);
     return;
   }
   __builtin_amdgcn_s_setprio(3);
