@@ -188,7 +188,7 @@ def main():
             #   elim_factor: every element of the eliminated columns read and written once
             pair_src_bytes = 8.0 * 2.0 * st["elim_pair_operand_elems"]
             work_of = {
-                "update": ("updateTile<%s>" % DT, "mfma", st["upd_flops"] - st["upd_flops_direct"]),
+                "update": ("updateTileBulk<%s>" % DT, "mfma", st["upd_flops"] - st["upd_flops_direct"]),
                 # (one-panel levels: update tiles + the next panel's potrf, and inside an outer block
                 #  also the panel's trsm, in one launch)
                 "chain_update": ("chainStep|updateTileDirectPotrf<%s>" % DT, "mfma",
