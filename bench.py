@@ -188,7 +188,7 @@ def main():
             #   elim_factor: every element of the eliminated columns read and written once
             pair_src_bytes = 8.0 * 2.0 * st["elim_pair_operand_elems"]
             work_of = {
-                "update": ("updateTileBulk<%s>" % DT, "mfma", st["upd_flops"] - st["upd_flops_direct"]),
+                "update": ("updateTileBulk|updateTile<%s>" % DT, "mfma", st["upd_flops"] - st["upd_flops_direct"]),
                 # (one-panel levels: update tiles + the next panel's potrf, and inside an outer block
                 #  also the panel's trsm, in one launch)
                 "chain_update": ("chainStep|updateTileDirectPotrf<%s>" % DT, "mfma",
@@ -221,8 +221,11 @@ def main():
             try:
                 with open(os.path.join(HERE, "profiles", "pmc_traffic.json")) as f:
                     pmc = json.load(f)
-                ent = pmc.get(args.workload, {}).get(kname.split("<")[0])
-                if ent:
+                names = kname.split("<")[0].split("|")
+                ents = [pmc.get(args.workload, {}).get(n) for n in names]
+                ents = [e for e in ents if e]
+                if ents:
+                    ent = {k: sum(e[k] for e in ents) for k in ("fetch_KB_per_factor", "write_KB_per_factor")}
                     roof["traffic"] = (2.0 * ent["fetch_KB_per_factor"] +
                                        ent["write_KB_per_factor"]) * 1024.0 / max(launches, 1)
                     roof["traffic_source"] = pmc.get("_source", "profiles/pmc_traffic.json")
