@@ -276,7 +276,8 @@ def test_lump_widths_around_panel_and_block_boundaries(dtype):
 
 
 @pytest.mark.parametrize("knob", ["BSP_NO_LOOKAHEAD=1", "BSP_DIRECT_CHAIN=0", "BSP_FUSE_POTRF=0",
-                                  "BSP_SPLIT_DIAG=0", "BSP_ELIM_FACTOR_DESC=0"])
+                                  "BSP_SPLIT_DIAG=0", "BSP_ELIM_FACTOR_DESC=0",
+                                  "BSP_MERGED_CHAIN=0", "BSP_BULK_KERNEL=0"])
 def test_schedule_variants(monkeypatch, knob):
     """every optimisation of the launch schedule can be switched off (the environment is read
     when the solver is created); each fallback must still factor correctly"""
@@ -297,6 +298,24 @@ def test_schedule_variants(monkeypatch, knob):
     got = _gpu_factor(sol, data)
     mask = sol.lowerMask()
     assert np.linalg.norm((got - ref)[mask]) / np.linalg.norm(ref[mask]) < 1e-12
+
+
+@pytest.mark.parametrize("ahead", ["0", "0.6", "100"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lookahead_units_over_many_outer_blocks(monkeypatch, ahead, dtype):
+    """a dense lump of seven outer blocks: the side stream applies (source block -> column block)
+    units in deadline order -- lazily (BSP_BULK_AHEAD=0: every column block receives all its
+    pending source blocks at once, accumulated with atomics), by the default budget, or eagerly
+    (100: every unit as soon as its source block is done); widths that leave a ragged last block"""
+    monkeypatch.setenv("BSP_BULK_AHEAD", ahead)
+    n = 1700
+    ss = T.columns_to_structure([set(range(i, n)) for i in range(n)])
+    sol = B.create_solver(B.Settings(), np.ones(n, dtype=np.int64), ss)
+    data = spd_data(sol, 23, beta_factor=1.2)
+    _, A = dense_lower_chol(sol, data)
+    Lg = lower_of(sol, _gpu_factor(sol, data.astype(dtype))).astype(np.float64)
+    tol = 1e-10 if dtype == np.float64 else 5e-5
+    assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < tol
 
 
 def test_wide_dense_lump_residual():
