@@ -18,6 +18,10 @@ namespace hipk {
 
 // One matrix (single) or a batch of identical-structure matrices (many, indexed by blockIdx.y);
 // replaces the Plain/Batched policy structs of MatOpsCuda.cu:345-368.
+#ifndef BSP_TILE_PRIO
+#define BSP_TILE_PRIO 2  // s_setprio of the chain launches' tile workgroups (the potrf / trsm ones: 3)
+#endif
+
 template <typename T>
 struct DataRef {
   T* single;
@@ -1672,7 +1676,7 @@ __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, 
   constexpr int LD = kUpdChunk + 2;
   __shared__ T As[kTile * LD];
   __shared__ T Bs[kTile * LD];
-  __builtin_amdgcn_s_setprio(2);
+  __builtin_amdgcn_s_setprio(BSP_TILE_PRIO);
   updateTileDirectBody<T>(pd, sd, xcdContiguous(blockIdx.x, nTasks), pickData(dref), As, Bs,
                           rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr, nbNext);
 }
@@ -1713,7 +1717,7 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
   __shared__ __attribute__((aligned(16))) T Bs[kTile * LD];
   GP<T> data = pickData(dref);
   if (blockIdx.x != 0) {
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(BSP_TILE_PRIO);
     const int idx = 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1);
     GP<T> raw = rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr;
     // (the bulk tile body -- operands straight to LDS, no register prefetch -- was measured
@@ -1892,7 +1896,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     return;
   }
 
-  __builtin_amdgcn_s_setprio(2);
+  __builtin_amdgcn_s_setprio(BSP_TILE_PRIO);
   int idx = fuse ? 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1) : xcdContiguous(blockIdx.x, nTasks);
   int colTile = sd.q0, rowTile;
   for (;;) {
