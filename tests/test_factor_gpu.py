@@ -126,6 +126,24 @@ def test_batched_factor(dtype):
             assert err < EPS[dtype][1], (i, q, err)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_batched_wide_dense_lump(dtype):
+    """a batch through the one-panel-level chain kernels (chain step, staging buffer and inverted
+    diagonal blocks have one slot per matrix) and the lookahead units: three matrices of one wide
+    supernode, each against its own dense factor"""
+    n = 1100
+    ss = T.columns_to_structure([set(range(i, n)) for i in range(n)])
+    sol = B.create_solver(B.Settings(), np.ones(n, dtype=np.int64), ss)
+    datas = [spd_data(sol, 40 + q, beta_factor=1.2) for q in range(3)]
+    devs = [to_dev(d.astype(dtype)) for d in datas]
+    sol.factor(devs)
+    tol = 1e-10 if dtype == np.float64 else 5e-5
+    for q in range(3):
+        _, A = dense_lower_chol(sol, datas[q])
+        Lg = lower_of(sol, devs[q].cpu().numpy()).astype(np.float64)
+        assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < tol, q
+
+
 @pytest.mark.parametrize("elim_set,last_ids", [(False, False), (True, False), (False, True),
                                                (True, True)])
 def test_create_solver_policies(elim_set, last_ids):
