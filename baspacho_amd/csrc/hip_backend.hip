@@ -199,6 +199,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
     if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
     if (const char* e = std::getenv("BSP_MERGED_CHAIN")) mergedChain = e[0] != '0';
+    if (const char* e = std::getenv("BSP_EARLY_FORK")) earlyFork = e[0] != '0';
     if (const char* e = std::getenv("BSP_BULK_KERNEL")) bulkKernel = e[0] != '0';
   }
 
@@ -317,6 +318,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
   bool fusePotrf = true;    // next panel's potrf inside the update launch (BSP_FUSE_POTRF=0 disables)
   bool bulkKernel = true;   // self-contained tasks + 16-byte staging for plain intra-lump tiles (BSP_BULK_KERNEL=0: table-driven updateTile)
+  bool earlyFork = true;    // fork the side stream before the level's own update launch (BSP_EARLY_FORK=0: after)
   bool mergedChain = true;  // trsm + update (+ next potrf) of an intra-block step in one launch (BSP_MERGED_CHAIN=0 disables)
   bool directChain = true;  // descriptor-by-value kernels on one-panel levels (BSP_DIRECT_CHAIN=0 disables)
   vector<hipEvent_t> events;
@@ -448,6 +450,30 @@ struct HipNumericCtx : NumericCtx<T> {
       if (!waitedDef && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
         hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
       }
+      const bool anyDef = lr.defEnd > lr.defBegin;
+      auto forkSide = [&]() {
+        // (under the source-ordered schedule the fork came AFTER the level's own update launch,
+        //  whose "now" tiles ran 3x faster alone than beside freshly started bulk tiles; with the
+        //  deadline-ordered units the side stream is busy either way and the earlier fork wins)
+        hipEvent_t fork = sym.eventFromPool();
+        hipCHECK(hipEventRecord(fork, sym.stream));
+        hipCHECK(hipStreamWaitEvent(sym.sideStream(), fork, 0));
+        // first the tiles the next block's own update must wait for, then (event) the rest:
+        // the side stream keeps running them while the chain goes on, and the next block's
+        // deferred tiles queue up right behind
+        if (lr.defMid > lr.defBegin) {
+          launchUpdate(plan, lr.defBegin, lr.defMid, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+        }
+        defDone[li] = sym.eventFromPool();
+        hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
+        if (lr.defEnd > lr.defMid) {
+          launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+        }
+        sideUsed = true;
+      };
+      // (the lookahead units read this level's panel columns and write columns the level's own
+      //  update does not touch: they can be forked before it)
+      if (lookahead && anyDef && sym.earlyFork) forkSide();
       const int64_t updBegin = lr.updBegin;
       if (lr.updEnd > updBegin) {
         timer.begin(direct && lr.directSeg >= 0 ? kProfChainUpdate : kProfUpdate);
@@ -474,26 +500,7 @@ struct HipNumericCtx : NumericCtx<T> {
         timer.end();
       }
       rawValid = stage;
-      const bool anyDef = lr.defEnd > lr.defBegin;
-      if (lookahead && anyDef) {
-        // Fork AFTER the level's own update launch: those "now" tiles (the next outer block's
-        // columns) are on the critical path and run 3x faster alone than beside the bulk tiles.
-        hipEvent_t fork = sym.eventFromPool();
-        hipCHECK(hipEventRecord(fork, sym.stream));
-        hipCHECK(hipStreamWaitEvent(sym.sideStream(), fork, 0));
-        // first the tiles the next block's own update must wait for, then (event) the rest:
-        // the side stream keeps running them while the chain goes on, and the next block's
-        // deferred tiles queue up right behind
-        if (lr.defMid > lr.defBegin) {
-          launchUpdate(plan, lr.defBegin, lr.defMid, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
-        }
-        defDone[li] = sym.eventFromPool();
-        hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
-        if (lr.defEnd > lr.defMid) {
-          launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
-        }
-        sideUsed = true;
-      }
+      if (lookahead && anyDef && !sym.earlyFork) forkSide();
       if (!lookahead) {  // (the same two launches as the lookahead schedule, on the main stream)
         if (lr.defMid > lr.defBegin) {
           timer.begin(kProfUpdate);
