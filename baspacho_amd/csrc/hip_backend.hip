@@ -200,6 +200,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
     if (const char* e = std::getenv("BSP_MERGED_CHAIN")) mergedChain = e[0] != '0';
     if (const char* e = std::getenv("BSP_EARLY_FORK")) earlyFork = e[0] != '0';
+    if (const char* e = std::getenv("BSP_MERGED_BLOCK_LAST")) mergedBlockLast = e[0] != '0';
     if (const char* e = std::getenv("BSP_BULK_KERNEL")) bulkKernel = e[0] != '0';
   }
 
@@ -318,6 +319,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
   bool fusePotrf = true;    // next panel's potrf inside the update launch (BSP_FUSE_POTRF=0 disables)
   bool bulkKernel = true;   // self-contained tasks + 16-byte staging for plain intra-lump tiles (BSP_BULK_KERNEL=0: table-driven updateTile)
+  bool mergedBlockLast = true;  // the block-last step (rank-256 now-update) as one chain-step launch too
   bool earlyFork = true;    // fork the side stream before the level's own update launch (BSP_EARLY_FORK=0: after)
   bool mergedChain = true;  // trsm + update (+ next potrf) of an intra-block step in one launch (BSP_MERGED_CHAIN=0 disables)
   bool directChain = true;  // descriptor-by-value kernels on one-panel levels (BSP_DIRECT_CHAIN=0 disables)
@@ -413,7 +415,7 @@ struct HipNumericCtx : NumericCtx<T> {
       const bool fuse = direct && lr.directSeg >= 0 && lr.fuseNext && sym.fusePotrf &&
                         li + 1 < levels.size() && levels[li + 1].directPanel >= 0 &&
                         lr.updEnd > lr.updBegin;
-      const int splitK = (fuse && sym.splitDiag && nT) ? lr.splitK : 0;
+      int splitK = (fuse && sym.splitDiag && nT) ? lr.splitK : 0;
       const bool directUpd = direct && lr.directSeg >= 0 && lr.updEnd > lr.updBegin;
       // does this level's update stage the next panel's rows?
       const bool stage = rawBase && directUpd && lr.rawNext && li + 1 < levels.size() &&
@@ -421,9 +423,25 @@ struct HipNumericCtx : NumericCtx<T> {
       const PanelDesc nextPanel = (stage || fuse) ? plan.host.panels[levels[li + 1].directPanel]
                                                   : PanelDesc{};
       // one launch for trsm + update (+ next potrf): intra-block step whose rows were staged
-      const bool merged = rawValid && directUpd && nT && !plan.host.segs[lr.directSeg].outer &&
-                          plan.host.srcs[plan.host.segs[lr.directSeg].src].K ==
-                              plan.host.panels[lr.directPanel].nb;
+      // (inside an outer block: K = nb, every source column is solved in the launch; block-last
+      //  step: the block-wide source, its leading K - nb columns are final in memory)
+      bool merged = false;
+      int64_t memOff = 0;
+      int kMem = 0;
+      if (rawValid && directUpd && nT) {
+        const SegDesc& sd = plan.host.segs[lr.directSeg];
+        const SrcDesc& sr = plan.host.srcs[sd.src];
+        const PanelDesc& pdc = plan.host.panels[lr.directPanel];
+        if (!sd.outer && sr.K == pdc.nb) {
+          merged = true;
+        } else if (sd.outer == 1 && sym.mergedBlockLast && sr.K > pdc.nb &&
+                   (sr.K - pdc.nb) % kTile == 0 && sr.rowsBelow == pdc.rowsBelow && sr.lda == pdc.lda) {
+          merged = true;
+          memOff = sr.off;
+          kMem = sr.K - pdc.nb;
+        }
+      }
+      if (merged) splitK = 0;
       bool waitedDef = false;
       if (splitK && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
         hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
@@ -473,7 +491,8 @@ struct HipNumericCtx : NumericCtx<T> {
       };
       // (the lookahead units read this level's panel columns and write columns the level's own
       //  update does not touch: they can be forked before it)
-      if (lookahead && anyDef && sym.earlyFork) forkSide();
+      const bool forkEarly = sym.earlyFork && !merged;  // (merged: the panel is solved in the launch)
+      if (lookahead && anyDef && forkEarly) forkSide();
       const int64_t updBegin = lr.updBegin;
       if (lr.updEnd > updBegin) {
         timer.begin(direct && lr.directSeg >= 0 ? kProfChainUpdate : kProfUpdate);
@@ -481,7 +500,8 @@ struct HipNumericCtx : NumericCtx<T> {
         if (merged) {
           hipk::chainStep<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
               plan.host.panels[lr.directPanel], plan.host.segs[lr.directSeg], (int)nUpd, nextPanel,
-              fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext);
+              fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
+              memOff, kMem);
           potrfFused = fuse;
         } else if (fuse) {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
@@ -500,7 +520,7 @@ struct HipNumericCtx : NumericCtx<T> {
         timer.end();
       }
       rawValid = stage;
-      if (lookahead && anyDef && !sym.earlyFork) forkSide();
+      if (lookahead && anyDef && !forkEarly) forkSide();
       if (!lookahead) {  // (the same two launches as the lookahead schedule, on the main stream)
         if (lr.defMid > lr.defBegin) {
           timer.begin(kProfUpdate);

@@ -1834,11 +1834,51 @@ struct ChainTile {
     if (storeRow) trsmStoreRows<T>(storeRow, actI, nb, lane, xi);
     ldsBarrier();
   }
+  // D[t] += (rows ri of Pm, columns 0..kMem) (rows rj of Pm)^T: source columns of the outer block
+  // that earlier panels already solved (block-last step).  64 columns at a time: the tile-row
+  // operand straight into registers (MFMA A-operand layout), the tile-column operand through XB.
+  // Rows beyond the end are clamped: their products only reach entries the scatter masks off.
+  static __device__ __forceinline__ void multiplyMem(GP<const T> Pm, int lda, int kMem, int rowTile,
+                                                     int colTile, int rowsBelow, int segEnd,
+                                                     bool diag, T* XB, Acc (&D)[4]) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, q = lane >> 4;
+    GP<const T> rowI = Pm + (int64_t)min(rowTile + 16 * w + n, rowsBelow - 1) * lda + 4 * q;
+    GP<const T> rowJ = Pm + (int64_t)min(colTile + (tid >> 2), segEnd - 1) * lda + 16 * (tid & 3);
+    for (int kb = 0; kb < kMem; kb += kTile) {
+      Acc am[4];
+      T v[16];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) am[j][r] = rowI[kb + 16 * j + r];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) v[c] = rowJ[kb + c];
+      ldsBarrier();  // XB free
+#pragma unroll
+      for (int c = 0; c < 16; c++) XB[(tid >> 2) * kXbLd + 16 * (tid & 3) + c] = v[c];
+      ldsBarrier();
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (!diag || t <= w) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              D[t] = Mfma<T>::run(am[j][r], XB[(16 * t + n) * kXbLd + 16 * j + 4 * q + r], D[t]);
+            }
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+    }
+    if (kMem > 0) ldsBarrier();  // XB is rewritten by solve()
+  }
+  // D[t] += X_i (X_j rows 16t..16t+15)^T
   __device__ __forceinline__ void multiply(const T* XB, Acc (&D)[4]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      D[t] = Acc{0, 0, 0, 0};
       if (!diagTile || t <= w) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -1858,7 +1898,8 @@ struct ChainTile {
 template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void chainStep(
     PanelDesc pd, SegDesc sd, int nTasks, PanelDesc next, int fuse, DataRef<T> dref,
-    const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase) {
+    const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase,
+    int64_t memOff, int kMem) {
   __shared__ T XB[kTile * kXbLd];
   static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd <= kTile * kXbLd, "potrf LDS fits in XB");
   using Acc = typename Mfma<T>::Acc;
@@ -1878,10 +1919,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     T* Ld = XB + 4 * kPanelWidth * 4;
     ChainTile<T> ct;
     const int ri = 16 * w + n;
-    ct.load(rawIn, Lkk, dinv, lda, nb, ri, ri, rowsBelow, segEnd, true);
+    if (kMem == 0) ct.load(rawIn, Lkk, dinv, lda, nb, ri, ri, rowsBelow, segEnd, true);
     auto pre = [&](Acc* acc) {
+      Acc D[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+      if (kMem > 0) {
+        ChainTile<T>::multiplyMem(data + memOff, lda, kMem, 0, 0, rowsBelow, segEnd, true, XB, D);
+        ct.load(rawIn, Lkk, dinv, lda, nb, ri, ri, rowsBelow, segEnd, true);
+      }
       ct.solve(nb, XB, P + (int64_t)ri * lda);
-      Acc D[4];
       ct.multiply(XB, D);
 #pragma unroll
       for (int t = 0; t < 4; t++) {
@@ -1909,6 +1954,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     colTile += kTile;
   }
   const int ri = rowTile + 16 * w + n, rj = colTile + 16 * w + n;
+  Acc D[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  if (kMem > 0) {
+    ChainTile<T>::multiplyMem(data + memOff, lda, kMem, rowTile, colTile, rowsBelow, segEnd,
+                              rowTile == colTile, XB, D);
+  }
   ChainTile<T> ct;
   ct.load(rawIn, Lkk, dinv, lda, nb, ri, rj, rowsBelow, segEnd, rowTile == colTile);
   // (column tile q0 covers every row tile once: its workgroups store X_i in place)
@@ -1926,7 +1976,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       old[t * 4 + reg] = tgt[(int64_t)qr * sd.tgtStride + qc];
     }
   }
-  Acc D[4];
   ct.multiply(XB, D);
   GP<T> rawOut = (GP<T>)rawOutBase + blockIdx.y * rawStride;
   const int nbNext = next.nb;
