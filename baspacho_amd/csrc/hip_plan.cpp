@@ -844,7 +844,11 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                             pr.rawNext;
         const SegDesc& sd = plan.segs[lr.directSeg];
         const PanelDesc& pd = plan.panels[lr.directPanel];
-        if (staged && !sd.outer && plan.srcs[sd.src].K == pd.nb) {
+        const SrcDesc& sr = plan.srcs[sd.src];
+        const bool intraStep = !sd.outer && sr.K == pd.nb;
+        const bool blockLast = sd.outer == 1 && sr.K > pd.nb && (sr.K - pd.nb) % kTile == 0 &&
+                               sr.rowsBelow == pd.rowsBelow && sr.lda == pd.lda;
+        if (staged && (intraStep || blockLast)) {
           plan.trsmFlopsMerged += double(pd.rowsBelow) * pd.nb * pd.nb;
         }
       }
