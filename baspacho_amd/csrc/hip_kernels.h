@@ -1844,9 +1844,9 @@ struct ChainTile {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, q = lane >> 4;
     GP<const T> rowI = Pm + (int64_t)min(rowTile + 16 * w + n, rowsBelow - 1) * lda + 4 * q;
     GP<const T> rowJ = Pm + (int64_t)min(colTile + (tid >> 2), segEnd - 1) * lda + 16 * (tid & 3);
-    for (int kb = 0; kb < kMem; kb += kTile) {
-      Acc am[4];
-      T v[16];
+    Acc am[4];
+    T v[16];
+    auto fetch = [&](int kb) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
 #pragma unroll
@@ -1854,10 +1854,17 @@ struct ChainTile {
       }
 #pragma unroll
       for (int c = 0; c < 16; c++) v[c] = rowJ[kb + c];
+    };
+    if (kMem > 0) fetch(0);
+    for (int kb = 0; kb < kMem; kb += kTile) {
+      Acc a[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) a[j] = am[j];
       ldsBarrier();  // XB free
 #pragma unroll
       for (int c = 0; c < 16; c++) XB[(tid >> 2) * kXbLd + 16 * (tid & 3) + c] = v[c];
       ldsBarrier();
+      if (kb + kTile < kMem) fetch(kb + kTile);  // (the next 64 columns while these are multiplied)
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         if (!diag || t <= w) {
@@ -1865,7 +1872,7 @@ struct ChainTile {
           for (int j = 0; j < 4; j++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-              D[t] = Mfma<T>::run(am[j][r], XB[(16 * t + n) * kXbLd + 16 * j + 4 * q + r], D[t]);
+              D[t] = Mfma<T>::run(a[j][r], XB[(16 * t + n) * kXbLd + 16 * j + 4 * q + r], D[t]);
             }
           }
         }
