@@ -110,6 +110,28 @@ def test_flops_formula_and_plan_stats():
         sol.sparseEliminationRanges()) else 0)
 
 
+@pytest.mark.parametrize("n", [700, 1700, 2049])
+def test_lookahead_schedule_covers_every_update_once(monkeypatch, n):
+    """host-side check of the device plan of one dense lump: however the lookahead units are
+    scheduled (as late as allowed, default budget, as early as possible), the update work of the
+    plan is the same and equals the dense count -- every (source columns -> target element) update
+    is planned exactly once.  Dense count: element (i, j), j <= i, of the n x n lower triangle
+    receives a rank-1 update from every column k that lies in an earlier 64-column panel than j
+    (the columns of j's own panel act inside its potrf / trsm): 2 * sum_j 64 (j // 64) (n - j)."""
+    ss = T.columns_to_structure([set(range(i, n)) for i in range(n)])
+    dense = 2.0 * sum(64 * (j // 64) * (n - j) for j in range(n))
+    seen = []
+    for ahead in ("0", "0.6", "100"):
+        monkeypatch.setenv("BSP_BULK_AHEAD", ahead)
+        sol = B.create_solver(B.Settings(), np.ones(n, dtype=np.int64), ss)
+        assert sol.numLumps() == 1
+        st = sol.planStats()
+        seen.append((st["upd_flops"], st["trsm_flops"], st["potrf_flops"]))
+        assert abs(st["upd_flops"] - dense) <= 1e-9 * dense, (ahead, st["upd_flops"], dense)
+    assert seen[0] == seen[1] == seen[2]
+    assert seen[0][1] >= st["trsm_flops_merged"] > 0 and seen[0][2] >= st["potrf_flops_fused"] > 0
+
+
 def test_block_tridiagonal_config_c1():
     """BASELINE config 0: 3334 x (3x3) block tridiagonal, symbolic analysis + oracle factor"""
     from oracle import cref
