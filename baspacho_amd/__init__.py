@@ -304,6 +304,21 @@ class Solver:
         _check(getattr(self._lib, "bsp_factor_per_op_" + _suffix(data))(
             self._h, ctypes.c_void_p(_ptr_of(data))))
 
+    def forcePerOp(self, on=True):
+        """TESTING: route factor / solve* / addMvFrom through the reference's per-op NumericCtx /
+        SolveCtx boundary (bsp_force_per_op); usable as a context manager"""
+        _check(self._lib.bsp_force_per_op(self._h, ctypes.c_int32(1 if on else 0)))
+        solver = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                return solver
+
+            def __exit__(self_inner, *exc):
+                _check(solver._lib.bsp_force_per_op(solver._h, ctypes.c_int32(0)))
+                return False
+        return _Scope()
+
     def factorUpTo(self, data, span_index):
         self._check_data(data)
         _check(getattr(self._lib, "bsp_factor_up_to_" + _suffix(data))(
@@ -394,13 +409,16 @@ class Solver:
         _check(self._lib.bsp_plan_stats_full(self._h, ctypes.byref(st)))
         return {n: getattr(st, n) for n, _ in _CPlanStats._fields_}
 
-    def factorProfiled(self, data):
-        """one factor() with every launch bracketed by HIP events on the execution stream;
-        returns {kernel class: (total ms, launches)}"""
+    def factorProfiled(self, data, in_situ=False):
+        """one factor() with every launch bracketed by HIP events; returns {kernel class: (total
+        ms, launches)}.  in_situ=False: launches serialised on the execution stream (isolated
+        kernel times); in_situ=True: the real two-stream schedule, each launch timed on the stream
+        it runs on"""
         self._check_data(data)
         ms = (ctypes.c_double * 6)()
         ln = (ctypes.c_int64 * 6)()
-        _check(self._lib.bsp_factor_profiled_f64(self._h, ctypes.c_void_p(_ptr_of(data)), ms, ln))
+        fn = self._lib.bsp_factor_profiled_insitu_f64 if in_situ else self._lib.bsp_factor_profiled_f64
+        _check(fn(self._h, ctypes.c_void_p(_ptr_of(data)), ms, ln))
         return {k: (ms[i], ln[i]) for i, k in enumerate(PROF_KINDS)}
 
     # ---- host helpers on the skeleton (CoalescedBlockMatrix.cpp:124-187) ------------------

@@ -239,6 +239,12 @@ int bsp_factor_per_op_f32(bsp_solver* s, float* d) {
   BSP_CATCH
 }
 
+int bsp_force_per_op(bsp_solver* s, int32_t on) {
+  BSP_TRY
+  hipBackendForcePerOp(s->solver->internalSymbolicContext(), on != 0);
+  BSP_CATCH
+}
+
 template <typename T>
 static void doElim(bsp_solver* s, T* d, int64_t idx) {
   const auto& ranges = s->solver->sparseEliminationRanges();
@@ -414,11 +420,10 @@ int bsp_debug_read_trace(long long* out, int max_records, int* n_records) {
   BSP_CATCH
 }
 
-int bsp_factor_profiled_f64(bsp_solver* s, double* d, double ms[6], int64_t launches[6]) {
-  BSP_TRY
+static void factorProfiled(bsp_solver* s, double* d, bool inSitu, double ms[6], int64_t launches[6]) {
   HipKernelProfile prof;
   SymbolicCtx& sym = s->solver->internalSymbolicContext();
-  hipBackendSetProfile(sym, &prof);
+  hipBackendSetProfile(sym, &prof, inSitu);
   try {
     s->solver->factor(d);
   } catch (...) {
@@ -430,6 +435,15 @@ int bsp_factor_profiled_f64(bsp_solver* s, double* d, double ms[6], int64_t laun
     ms[i] = prof.ms[i];
     launches[i] = prof.launches[i];
   }
+}
+int bsp_factor_profiled_f64(bsp_solver* s, double* d, double ms[6], int64_t launches[6]) {
+  BSP_TRY
+  factorProfiled(s, d, false, ms, launches);
+  BSP_CATCH
+}
+int bsp_factor_profiled_insitu_f64(bsp_solver* s, double* d, double ms[6], int64_t launches[6]) {
+  BSP_TRY
+  factorProfiled(s, d, true, ms, launches);
   BSP_CATCH
 }
 

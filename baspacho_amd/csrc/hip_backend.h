@@ -31,9 +31,12 @@ struct HipPlanStats {
           numTrsmTasks = 0, chainTabEntries = 0, maxPanelsInLevel = 0, numAtomicUpdTasks = 0;
 };
 
-// while `prof` is non-null every kernel launch of the context is bracketed by HIP events on
-// the execution stream and accumulated per kernel class (factor calls then synchronise)
-void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof);
+// while `prof` is non-null every kernel launch of the context is bracketed by HIP events and
+// accumulated per kernel class (factor calls then synchronise).  inSitu = false: the launches run
+// one after the other on the execution stream (lookahead off: isolated kernel times); inSitu =
+// true: the real schedule, side-stream launches timed on the side stream (what a kernel takes
+// beside the others -- the number a rocprofv3 kernel trace of the timed steps shows)
+void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof, bool inSitu = false);
 
 // sustained fp64 MFMA rate of this GPU measured with a register-only probe kernel (TFLOP/s)
 double hipBackendMfmaF64ProbeTflops();

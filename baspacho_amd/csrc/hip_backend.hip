@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 
@@ -150,6 +151,51 @@ struct DevPlan {
   }
 };
 
+// Pointer arrays of a batched call (one device pointer per matrix / vector) travel through a small
+// ring of pinned host slots and device slots, copied on the execution stream: no synchronous
+// hipMemcpy, no per-call allocation, and a slot is not rewritten while an earlier call's kernels
+// may still read it (the reference re-uploads the array for every op, MatOpsCuda.cu:730,761,788).
+struct PtrRing {
+  static constexpr int kSlots = 32;
+  char* host = nullptr;
+  DevBuf dev;
+  size_t slotBytes = 0;
+  int next = 0;
+  hipEvent_t ev[kSlots] = {};
+  bool used[kSlots] = {};
+  ~PtrRing() { release(); }
+  void release() {
+    for (int i = 0; i < kSlots; i++) {
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+      ev[i] = nullptr;
+      used[i] = false;
+    }
+    if (host) (void)hipHostFree(host);
+    host = nullptr;
+    dev.release();
+    slotBytes = 0;
+  }
+  const void* push(const void* src, size_t bytes, hipStream_t stream) {
+    if (bytes > slotBytes) {  // (first call, or a larger batch than ever before)
+      if (slotBytes) hipCHECK(hipDeviceSynchronize());
+      release();
+      slotBytes = (std::max<size_t>(bytes, 512) + 255) & ~size_t(255);
+      hipCHECK(hipHostMalloc((void**)&host, slotBytes * kSlots, hipHostMallocDefault));
+      dev.resize(slotBytes * kSlots);
+      for (int i = 0; i < kSlots; i++) hipCHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    }
+    const int s = next;
+    next = (next + 1) % kSlots;
+    if (used[s]) hipCHECK(hipEventSynchronize(ev[s]));
+    std::memcpy(host + s * slotBytes, src, bytes);
+    char* d = reinterpret_cast<char*>(dev.ptr) + s * slotBytes;
+    hipCHECK(hipMemcpyAsync(d, host + s * slotBytes, bytes, hipMemcpyHostToDevice, stream));
+    hipCHECK(hipEventRecord(ev[s], stream));
+    used[s] = true;
+    return d;
+  }
+};
+
 struct HipSymElimCtx : SymElimCtx {
   int64_t lumpsBegin = 0, lumpsEnd = 0;
 };
@@ -158,24 +204,25 @@ struct HipSymElimCtx : SymElimCtx {
 struct LaunchTimer {
   hipStream_t stream;
   HipKernelProfile* prof;
-  struct Rec { int kind; hipEvent_t a, b; };
+  struct Rec { int kind; hipEvent_t a, b; hipStream_t on; };
   vector<Rec> recs;
   LaunchTimer(hipStream_t s, HipKernelProfile* p) : stream(s), prof(p) {}
-  void begin(int kind) {
+  // `on`: the stream the launch goes to (in-situ mode times the side-stream launches there)
+  void begin(int kind, hipStream_t on = nullptr) {
     if (!prof) return;
-    Rec r{kind, nullptr, nullptr};
+    Rec r{kind, nullptr, nullptr, on ? on : stream};
     hipCHECK(hipEventCreate(&r.a));
     hipCHECK(hipEventCreate(&r.b));
-    hipCHECK(hipEventRecord(r.a, stream));
+    hipCHECK(hipEventRecord(r.a, r.on));
     recs.push_back(r);
   }
   void end() {
     if (!prof) return;
-    hipCHECK(hipEventRecord(recs.back().b, stream));
+    hipCHECK(hipEventRecord(recs.back().b, recs.back().on));
   }
   void finish() {
     if (!prof) return;
-    hipCHECK(hipStreamSynchronize(stream));
+    hipCHECK(hipStreamSynchronize(stream));  // (the side stream has been joined into it)
     for (auto& r : recs) {
       float ms = 0;
       hipCHECK(hipEventElapsedTime(&ms, r.a, r.b));
@@ -216,8 +263,22 @@ struct HipSymbolicCtx : SymbolicCtx {
 
   virtual void setStream(void* s) override { stream = (hipStream_t)s; }
 
+  // Everything a Solver puts on the GPU (skeleton mirrors, plans, scratch, streams, events) lives
+  // on the device that was current at its first use; later calls must run with that device current.
+  void checkDevice() {
+    int cur = -1;
+    hipCHECK(hipGetDevice(&cur));
+    if (device < 0) device = cur;
+    if (cur != device) {
+      throw std::runtime_error("HIP backend: this Solver was first used on device " +
+                               std::to_string(device) + " but the current device is " +
+                               std::to_string(cur) + " (make its device current before the call)");
+    }
+  }
+
   void ensureSkelOnDevice() {
     if (skelUploaded) return;
+    checkDevice();
     dSpanStart.upload(skel.spanStart);
     dSpanToLump.upload(skel.spanToLump);
     dLumpStart.upload(skel.lumpStart);
@@ -266,6 +327,7 @@ struct HipSymbolicCtx : SymbolicCtx {
 
   // plan of a fused factor over lumps [startLump, upToLump), built and uploaded on first use
   DevPlan& planFor(const vector<int64_t>& ranges, int64_t startLump, int64_t upToLump, int tag) {
+    checkDevice();
     auto key = std::make_tuple(tag, startLump, upToLump);
     auto it = plans.find(key);
     if (it == plans.end()) {
@@ -310,6 +372,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   vector<int64_t> sparseElimRanges;
   hipStream_t stream = nullptr;
   HipKernelProfile* profile = nullptr;
+  bool profileInSitu = false;  // profile with the lookahead schedule left on (two streams)
   bool lookaheadEnabled = true;
   unsigned bulkExtraLds = 6 * 1024;
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
@@ -325,6 +388,14 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool directChain = true;  // descriptor-by-value kernels on one-panel levels (BSP_DIRECT_CHAIN=0 disables)
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
+  int device = -1;  // device of the first use (checkDevice)
+  // scratch that outlives the per-call NumericCtx / SolveCtx objects (those are created and
+  // destroyed around every factor() / solve(), Solver.cpp:176,223, while their kernels may still be
+  // queued): sized on first use, only ever grown
+  DevBuf dinvScratch, rawScratch;
+  PtrRing ptrRing;
+  bool rowFormAttrSet[2] = {false, false};  // elimRowMfma dynamic-LDS attribute (fp64, fp32)
+  std::map<std::pair<int64_t, int64_t>, std::pair<std::unique_ptr<DevBuf>, size_t>> addMvTileLists;
 
   bool skelUploaded = false;
   DevBuf dSpanStart, dSpanToLump, dLumpStart, dSpanOffsetInLump, dChainColPtr, dChainRowSpan,
@@ -369,21 +440,23 @@ struct HipNumericCtx : NumericCtx<T> {
   void launchLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::DataRef<BT> ref,
                     LaunchTimer& timer) {
     const dim3 gy(1, (unsigned)batchSize, 1);
-    const bool lookahead = sym.profile == nullptr && sym.lookaheadEnabled;
+    // (profiled runs serialise the launches on the execution stream, unless the in-situ mode asks
+    //  for the real two-stream schedule with every launch timed on the stream it runs on)
+    const bool lookahead = (sym.profile == nullptr || sym.profileInSitu) && sym.lookaheadEnabled;
     vector<hipEvent_t> defDone(levels.size(), nullptr);
     bool potrfFused = false;  // this level's potrf ran inside the previous level's update launch
     bool sideUsed = false;
     // inverted diagonal blocks of the chain panels: written by a panel's potrf, read by its trsm
     // (two slots per matrix, alternating from panel to panel)
-    dinvScratch.resize((size_t)batchSize * hipk::kDinvBatchStride * sizeof(BT));
-    BT* dinvBase = const_cast<BT*>(dinvScratch.as<BT>());
+    sym.dinvScratch.resize((size_t)batchSize * hipk::kDinvBatchStride * sizeof(BT));
+    BT* dinvBase = const_cast<BT*>(sym.dinvScratch.as<BT>());
     int dinvSlot = 0;  // slot of the current level's panel
     // staging buffer of the chain (chainStep): unsolved rows of the current / next panel
     const int64_t rawSlot = plan.host.maxChainRows * kTile;
     BT* rawBase = nullptr;
     if (rawSlot > 0 && sym.mergedChain) {
-      rawScratch.resize((size_t)batchSize * 2 * rawSlot * sizeof(BT));
-      rawBase = const_cast<BT*>(rawScratch.as<BT>());
+      sym.rawScratch.resize((size_t)batchSize * 2 * rawSlot * sizeof(BT));
+      rawBase = const_cast<BT*>(sym.rawScratch.as<BT>());
     }
     bool rawValid = false;  // the previous level staged this level's panel rows
     for (size_t li = 0; li < levels.size(); li++) {
@@ -480,12 +553,16 @@ struct HipNumericCtx : NumericCtx<T> {
         // the side stream keeps running them while the chain goes on, and the next block's
         // deferred tiles queue up right behind
         if (lr.defMid > lr.defBegin) {
+          timer.begin(kProfUpdate, sym.sideStream());
           launchUpdate(plan, lr.defBegin, lr.defMid, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+          timer.end();
         }
         defDone[li] = sym.eventFromPool();
         hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
         if (lr.defEnd > lr.defMid) {
+          timer.begin(kProfUpdate, sym.sideStream());
           launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+          timer.end();
         }
         sideUsed = true;
       };
@@ -570,7 +647,7 @@ struct HipNumericCtx : NumericCtx<T> {
     if (er.useRowForm) {
       const int64_t nRows = er.rowEnd - er.rowBegin;
       const int ldsBytes = sizeof(BT) == 8 ? er.rowLdsBytes : er.rowLdsBytesF32;
-      static bool attrSet = false;  // (per instantiation: BT is part of the enclosing class)
+      bool& attrSet = sym.rowFormAttrSet[sizeof(BT) == 8 ? 0 : 1];  // per device = per Solver
       if (!attrSet) {
         hipCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hipk::elimRowMfma<BT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -729,22 +806,50 @@ struct HipNumericCtx : NumericCtx<T> {
 
   virtual void pseudoFactorSpans(T* data, int64_t spanBegin, int64_t spanEnd) override {
     if (spanEnd <= spanBegin) return;
+    const CoalescedBlockMatrixSkel& sk = sym.skel;
+    // spans of up to kElimSmallMax columns: one wave per span (diagonal block in LDS, rows in
+    // registers).  Wider spans (the reference has no width limit, MatOpsCuda.cu:188-233) go through
+    // the panel potrf / trsm kernels, one dense-op plan per span; runs of narrow spans in between
+    // are batched into one launch each.
+    hipk::DataRef<BT> ref = makeRef(data);
+    auto narrowRun = [&](int64_t b, int64_t e) {
+      if (e <= b) return;
+      hipk::pseudoFactorSpansKernel<BT><<<dim3((unsigned)((e - b + 3) / 4), (unsigned)batchSize), 256,
+                                          0, sym.stream>>>(sym.skelDev(), ref, b, e);
+    };
+    const bool la = sym.lookaheadEnabled;
+    sym.lookaheadEnabled = false;
+    int64_t runBegin = spanBegin;
     for (int64_t s = spanBegin; s < spanEnd; s++) {
-      if (sym.skel.spanStart[s + 1] - sym.skel.spanStart[s] > kElimSmallMax) {
-        throw std::runtime_error("HIP backend: pseudoFactorSpans supports spans of up to " +
-                                 std::to_string(kElimSmallMax) + " columns");
+      const int64_t n = sk.spanStart[s + 1] - sk.spanStart[s];
+      if (n <= kElimSmallMax) continue;
+      narrowRun(runBegin, s);
+      runBegin = s + 1;
+      const int64_t lump = sk.spanToLump[s];
+      const int64_t lda = sk.lumpStart[lump + 1] - sk.lumpStart[lump];
+      const int64_t c0 = sk.chainColPtr[lump], nCh = sk.chainColPtr[lump + 1] - c0;
+      const int64_t idxInLump = s - sk.lumpToSpan[lump];
+      // (the chains of a lump column follow each other: the rows below the span's diagonal block
+      //  start n rows after it)
+      const int64_t offD = sk.chainData[c0 + idxInLump] + sk.spanOffsetInLump[s];
+      const int64_t rowsBelow = sk.chainRowsTillEnd[c0 + nCh - 1] - sk.chainRowsTillEnd[c0 + idxInLump];
+      LaunchTimer timer(sym.stream, nullptr);
+      DevPlan& pf = adoptPlan(buildDenseOpPlan(n, 0, offD, /*potrfOnly=*/true, 0, lda));
+      launchLevels(pf, pf.host.levels, ref, timer);
+      if (rowsBelow > 0) {
+        DevPlan& ps = adoptPlan(buildDenseOpPlan(n, rowsBelow, offD, /*potrfOnly=*/false, 0, lda));
+        launchLevels(ps, ps.host.levels, ref, timer);
       }
     }
-    hipk::pseudoFactorSpansKernel<BT><<<dim3((unsigned)((spanEnd - spanBegin + 3) / 4),
-                                             (unsigned)batchSize), 256, 0, sym.stream>>>(
-        sym.skelDev(), makeRef(data), spanBegin, spanEnd);
+    narrowRun(runBegin, spanEnd);
+    sym.lookaheadEnabled = la;
     hipCHECK(hipGetLastError());
   }
 
   HipSymbolicCtx& sym;
   int batchSize;
   int64_t tempBufSize = 0;
-  DevBuf devPtrs, temp, spanToChainOffset, dinvScratch, rawScratch;
+  DevBuf temp, spanToChainOffset;  // per-op boundary only (saveSyrkGemm / prepareAssemble)
   vector<std::unique_ptr<DevPlan>> opPlans;
 };
 
@@ -759,14 +864,14 @@ hipk::DataRef<float> HipNumericCtx<float>::makeRef(float* data) {
 template <>
 hipk::DataRef<double> HipNumericCtx<vector<double*>>::makeRef(vector<double*>* data) {
   BASPACHO_CHECK_EQ((int)data->size(), batchSize);
-  devPtrs.upload(*data);
-  return {nullptr, devPtrs.as<double*>()};
+  return {nullptr, (double* const*)sym.ptrRing.push(data->data(), data->size() * sizeof(double*),
+                                                    sym.stream)};
 }
 template <>
 hipk::DataRef<float> HipNumericCtx<vector<float*>>::makeRef(vector<float*>* data) {
   BASPACHO_CHECK_EQ((int)data->size(), batchSize);
-  devPtrs.upload(*data);
-  return {nullptr, devPtrs.as<float*>()};
+  return {nullptr, (float* const*)sym.ptrRing.push(data->data(), data->size() * sizeof(float*),
+                                                   sym.stream)};
 }
 
 NumericCtxBase* HipSymbolicCtx::createNumericCtxForType(std::type_index tIdx, int64_t tempSize,
@@ -788,7 +893,9 @@ struct HipSolveCtx : SolveCtx<T> {
   using BT = BaseType<T>;
   HipSolveCtx(HipSymbolicCtx& sym_, int nRHS_, int batch_) : sym(sym_), nRHS(nRHS_), batch(batch_) {}
 
-  virtual bool hasFusedSolve() const override { return true; }
+  // (TESTING switch hipBackendForcePerOp: the solver then drives the reference's op-by-op loops,
+  //  Solver.cpp:303-328,357-381,419-448, over the per-op virtuals below)
+  virtual bool hasFusedSolve() const override { return !sym.forcePerOp; }
 
   dim3 grid(unsigned x) const { return dim3(x, (unsigned)nRHS, (unsigned)batch); }
 
@@ -936,20 +1043,25 @@ struct HipSolveCtx : SolveCtx<T> {
   void addMvImpl(const BT* data, int64_t startLump, int64_t upToLump, const BT* in,
                  int64_t inStride, BT* out, int64_t outStride, BT alpha) {
     const CoalescedBlockMatrixSkel& sk = sym.skel;
-    vector<int64_t> tiles;
-    for (int64_t l = startLump; l < upToLump; l++) {
-      const int64_t c0 = sk.chainColPtr[l], nCh = sk.chainColPtr[l + 1] - c0;
-      const int64_t rows = sk.chainRowsTillEnd[c0 + nCh - 1];
-      for (int64_t r = 0; r < rows; r += kTile) {
-        tiles.push_back(l);
-        tiles.push_back(r);
+    // (lump, row tile) list of the range: built and uploaded once per range, kept by the Solver
+    auto& ent = sym.addMvTileLists[{startLump, upToLump}];
+    if (!ent.first) {
+      vector<int64_t> tiles;
+      for (int64_t l = startLump; l < upToLump; l++) {
+        const int64_t c0 = sk.chainColPtr[l], nCh = sk.chainColPtr[l + 1] - c0;
+        const int64_t rows = sk.chainRowsTillEnd[c0 + nCh - 1];
+        for (int64_t r = 0; r < rows; r += kTile) {
+          tiles.push_back(l);
+          tiles.push_back(r);
+        }
       }
+      ent.first.reset(new DevBuf);
+      ent.first->upload(tiles);
+      ent.second = tiles.size() / 2;
     }
-    if (tiles.empty()) return;
-    addMvTiles.upload(tiles);
-    hipk::addMvKernel<BT><<<dim3((unsigned)(tiles.size() / 2), (unsigned)nRHS), 256, 0,
-                            sym.stream>>>(sym.skelDev(), addMvTiles.as<int64_t>(), data, in,
-                                          inStride, out, outStride, alpha);
+    if (ent.second == 0) return;
+    hipk::addMvKernel<BT><<<dim3((unsigned)ent.second, (unsigned)nRHS), 256, 0, sym.stream>>>(
+        sym.skelDev(), ent.first->as<int64_t>(), data, in, inStride, out, outStride, alpha);
     hipCHECK(hipGetLastError());
   }
   template <typename V>
@@ -958,23 +1070,151 @@ struct HipSolveCtx : SolveCtx<T> {
     throw std::runtime_error("HIP backend: addMvFrom is defined for single matrices only");
   }
 
-  [[noreturn]] static void perOp(const char* what) {
-    throw std::runtime_error(std::string("HIP backend: per-op ") + what +
-                             " is not exposed; use solve()/solveL()/solveLt() (fused path)");
+  // ---- per-op boundary (MatOps.h:139-168; reference kernels MatOpsCuda.cu:836-1181).  solve() never
+  // goes through these (fused path); they exist so that a driver written against the reference's
+  // SolveCtx -- the op-by-op loops of Solver.cpp:303-328,357-381,419-448, kept in solver.cpp -- runs
+  // on this backend.  Correct, not fast: the dense triangular solves build a one-off device plan.
+  hipk::SolveRef<BT> matOnly(const T* data) { return refOf(data, (T*)nullptr, 0); }
+  hipk::SolveRef<BT> vecOnly(const T* v, int64_t ld) { return refOf((const T*)nullptr, const_cast<T*>(v), ld); }
+  hipk::SolveRef<BT> refOf(const BT* data, BT* C, int64_t ldc) { return {data, C, nullptr, nullptr, ldc}; }
+  template <typename V>
+  hipk::SolveRef<V> refOf(const vector<V*>* data, vector<V*>* C, int64_t ldc) {
+    hipk::SolveRef<V> r{nullptr, nullptr, nullptr, nullptr, ldc};
+    if (data) {
+      BASPACHO_CHECK_EQ((int)data->size(), batch);
+      r.mats = (const V* const*)sym.ptrRing.push(data->data(), data->size() * sizeof(V*), sym.stream);
+    }
+    if (C) {
+      BASPACHO_CHECK_EQ((int)C->size(), batch);
+      r.vecs = (V* const*)sym.ptrRing.push(C->data(), C->size() * sizeof(V*), sym.stream);
+    }
+    return r;
   }
-  virtual void sparseElimSolveL(const SymElimCtx&, const T*, int64_t, int64_t, T*, int64_t) override { perOp("sparseElimSolveL"); }
-  virtual void sparseElimSolveLt(const SymElimCtx&, const T*, int64_t, int64_t, T*, int64_t) override { perOp("sparseElimSolveLt"); }
-  virtual void symm(const T*, int64_t, int64_t, const T*, int64_t, int64_t, T*, int64_t, BaseType<T>) override { perOp("symm"); }
-  virtual void solveL(const T*, int64_t, int64_t, T*, int64_t, int64_t) override { perOp("solveL"); }
-  virtual void gemv(const T*, int64_t, int64_t, int64_t, const T*, int64_t, int64_t, BaseType<T>) override { perOp("gemv"); }
-  virtual void assembleVec(int64_t, int64_t, T*, int64_t) override { perOp("assembleVec"); }
-  virtual void solveLt(const T*, int64_t, int64_t, T*, int64_t, int64_t) override { perOp("solveLt"); }
-  virtual void gemvT(const T*, int64_t, int64_t, int64_t, T*, int64_t, int64_t, BaseType<T>) override { perOp("gemvT"); }
-  virtual void assembleVecT(const T*, int64_t, int64_t, int64_t) override { perOp("assembleVecT"); }
+  BT* tmpBuf() {  // order x nRHS values per batch entry, as CpuBaseSolveCtx::tmpBuf
+    tmp.resize((size_t)tmpStride() * batch * sizeof(BT));
+    return const_cast<BT*>(tmp.as<BT>());
+  }
+  int64_t tmpStride() const { return sym.skel.order() * nRHS; }
+
+  virtual void sparseElimSolveL(const SymElimCtx& elimData, const T* data, int64_t lumpsBegin,
+                                int64_t lumpsEnd, T* C, int64_t ldc) override {
+    const HipSymElimCtx* e = dynamic_cast<const HipSymElimCtx*>(&elimData);
+    BASPACHO_CHECK_NOTNULL(e);
+    BASPACHO_CHECK_EQ(e->lumpsBegin, lumpsBegin);
+    BASPACHO_CHECK_EQ(e->lumpsEnd, lumpsEnd);
+    DevPlan& plan = sym.planFor({lumpsBegin, lumpsEnd}, lumpsBegin, lumpsEnd, /*tag=*/1);
+    hipk::SolveRef<BT> ref = makeRef(data, C, ldc);
+    for (const ElimRangePlan& er : plan.host.elimRanges) elimRange<false>(plan, er, ref);
+    hipCHECK(hipGetLastError());
+  }
+  virtual void sparseElimSolveLt(const SymElimCtx& elimData, const T* data, int64_t lumpsBegin,
+                                 int64_t lumpsEnd, T* C, int64_t ldc) override {
+    const HipSymElimCtx* e = dynamic_cast<const HipSymElimCtx*>(&elimData);
+    BASPACHO_CHECK_NOTNULL(e);
+    BASPACHO_CHECK_EQ(e->lumpsBegin, lumpsBegin);
+    BASPACHO_CHECK_EQ(e->lumpsEnd, lumpsEnd);
+    DevPlan& plan = sym.planFor({lumpsBegin, lumpsEnd}, lumpsBegin, lumpsEnd, /*tag=*/1);
+    hipk::SolveRef<BT> ref = makeRef(data, C, ldc);
+    for (auto it = plan.host.elimRanges.rbegin(); it != plan.host.elimRanges.rend(); ++it) {
+      elimRange<true>(plan, *it, ref);
+    }
+    hipCHECK(hipGetLastError());
+  }
+
+  virtual void symm(const T* data, int64_t offset, int64_t n, const T* C, int64_t offC, int64_t ldc,
+                    T* D, int64_t ldd, BaseType<T> alpha) override {
+    if (n <= 0) return;
+    hipk::perOpSymm<BT><<<grid((unsigned)((n + 3) / 4)), 256, 0, sym.stream>>>(
+        matOnly(data), offset, n, vecOnly(C, ldc), offC, vecOnly(D, ldd), alpha);
+    hipCHECK(hipGetLastError());
+  }
+
+  // dense triangular solve with the n x n block at `offset`: the block's panels and row tiles as a
+  // one-off plan (the same kernels as the fused path, panel by panel)
+  template <bool BACKWARD>
+  void denseTriSolve(const T* data, int64_t offset, int64_t n, T* C, int64_t offC, int64_t ldc) {
+    if (n <= 0) return;
+    opPlans.emplace_back(new DevPlan);
+    DevPlan& plan = *opPlans.back();
+    plan.host = buildDenseOpPlan(n, 0, offset, /*potrfOnly=*/true, /*vecOff=*/offC);
+    vector<LevelRange> levels = plan.host.levels;  // (upload() keeps the level table)
+    plan.upload();
+    const bool bs = sym.blockSolve;
+    sym.blockSolve = false;  // (the block kernels expect the chain flags of a factor plan)
+    denseLevels<BACKWARD>(plan, levels, makeRef(data, C, ldc));
+    sym.blockSolve = bs;
+    hipCHECK(hipGetLastError());
+  }
+  virtual void solveL(const T* data, int64_t offset, int64_t n, T* C, int64_t offC,
+                      int64_t ldc) override {
+    denseTriSolve<false>(data, offset, n, C, offC, ldc);
+  }
+  virtual void solveLt(const T* data, int64_t offset, int64_t n, T* C, int64_t offC,
+                       int64_t ldc) override {
+    denseTriSolve<true>(data, offset, n, C, offC, ldc);
+  }
+
+  virtual void gemv(const T* data, int64_t offset, int64_t nRows, int64_t nCols, const T* A,
+                    int64_t offA, int64_t lda, BaseType<T> alpha) override {
+    if (nRows <= 0) return;
+    BASPACHO_CHECK_LE(nRows, sym.skel.order());
+    hipk::perOpGemv<BT><<<grid((unsigned)((nRows + 3) / 4)), 256, 0, sym.stream>>>(
+        matOnly(data), offset, nRows, nCols, vecOnly(A, lda), offA, alpha, tmpBuf(), tmpStride(), nRHS);
+    hipCHECK(hipGetLastError());
+  }
+  virtual void gemvT(const T* data, int64_t offset, int64_t nRows, int64_t nCols, T* A,
+                     int64_t offA, int64_t lda, BaseType<T> alpha) override {
+    if (nRows <= 0 || nCols <= 0) return;
+    const int64_t colTiles = (nCols + 63) / 64;
+    const int64_t rowChunks = (nRows + hipk::kPerOpRowChunk - 1) / hipk::kPerOpRowChunk;
+    hipk::perOpGemvT<BT><<<grid((unsigned)(colTiles * rowChunks)), 256, 0, sym.stream>>>(
+        matOnly(data), offset, nRows, nCols, vecOnly(A, lda), offA, alpha, tmpBuf(), tmpStride(), nRHS);
+    hipCHECK(hipGetLastError());
+  }
+  virtual void assembleVec(int64_t chainColPtr, int64_t numColItems, T* C, int64_t ldc) override {
+    if (numColItems <= 0) return;
+    hipk::perOpAssembleVec<BT, false><<<grid((unsigned)numColItems), 256, 0, sym.stream>>>(
+        sym.skelDev(), chainColPtr, vecOnly(C, ldc), tmpBuf(), tmpStride(), nRHS);
+    hipCHECK(hipGetLastError());
+  }
+  virtual void assembleVecT(const T* C, int64_t ldc, int64_t chainColPtr,
+                            int64_t numColItems) override {
+    if (numColItems <= 0) return;
+    hipk::perOpAssembleVec<BT, true><<<grid((unsigned)numColItems), 256, 0, sym.stream>>>(
+        sym.skelDev(), chainColPtr, vecOnly(C, ldc), tmpBuf(), tmpStride(), nRHS);
+    hipCHECK(hipGetLastError());
+  }
+
+  // ---- fragmented ops (MatOps.h:170-184, MatOpsFast.cpp:613-1018): whole MV / L / L^T sweeps over
+  // a range of spans that are lumps of their own, one right-hand side, contiguous vector.  On this
+  // backend they are the fused range kernels (a range of unmerged lumps is just a range).
+  virtual bool hasFragmentedOps() override { return true; }
+  virtual void fragmentedMV(const T* data, const T* x, int64_t spanBegin, int64_t spanEnd, T* y,
+                            BaseType<T> alpha) override {
+    checkFragmented(spanBegin, spanEnd);
+    addMvImpl(data, spanBegin, spanEnd, x, sym.skel.order(), y, sym.skel.order(), alpha);
+  }
+  virtual void fragmentedSolveL(const T* data, int64_t spanBegin, int64_t spanEnd, T* y) override {
+    checkFragmented(spanBegin, spanEnd);
+    solveLRange(data, spanBegin, spanEnd, y, sym.skel.order());
+  }
+  virtual void fragmentedSolveLt(const T* data, int64_t spanBegin, int64_t spanEnd, T* y) override {
+    checkFragmented(spanBegin, spanEnd);
+    solveLtRange(data, spanBegin, spanEnd, y, sym.skel.order());
+  }
+  void checkFragmented(int64_t spanBegin, int64_t spanEnd) const {
+    BASPACHO_CHECK_EQ(nRHS, 1);
+    BASPACHO_CHECK_LE(spanBegin, spanEnd);
+    BASPACHO_CHECK_LE(spanEnd, sym.skel.numLumps());
+    // spans in the range are lumps of their own (Solver.cpp:299,352,413)
+    BASPACHO_CHECK_EQ(sym.skel.lumpToSpan[spanBegin], spanBegin);
+    BASPACHO_CHECK_EQ(sym.skel.lumpToSpan[spanEnd] - sym.skel.lumpToSpan[spanBegin], spanEnd - spanBegin);
+  }
 
   HipSymbolicCtx& sym;
   int nRHS, batch;
-  DevBuf devMats, devVecs, addMvTiles;
+  DevBuf tmp;
+  vector<std::unique_ptr<DevPlan>> opPlans;
 };
 
 template <>
@@ -988,20 +1228,12 @@ hipk::SolveRef<float> HipSolveCtx<float>::makeRef(const float* data, float* C, i
 template <>
 hipk::SolveRef<double> HipSolveCtx<vector<double*>>::makeRef(const vector<double*>* data,
                                                              vector<double*>* C, int64_t ldc) {
-  BASPACHO_CHECK_EQ((int)data->size(), batch);
-  BASPACHO_CHECK_EQ((int)C->size(), batch);
-  devMats.upload(*data);
-  devVecs.upload(*C);
-  return {nullptr, nullptr, devMats.as<const double*>(), devVecs.as<double*>(), ldc};
+  return refOf(data, C, ldc);
 }
 template <>
 hipk::SolveRef<float> HipSolveCtx<vector<float*>>::makeRef(const vector<float*>* data,
                                                            vector<float*>* C, int64_t ldc) {
-  BASPACHO_CHECK_EQ((int)data->size(), batch);
-  BASPACHO_CHECK_EQ((int)C->size(), batch);
-  devMats.upload(*data);
-  devVecs.upload(*C);
-  return {nullptr, nullptr, devMats.as<const float*>(), devVecs.as<float*>(), ldc};
+  return refOf(data, C, ldc);
 }
 
 SolveCtxBase* HipSymbolicCtx::createSolveCtxForType(std::type_index tIdx, int nRHS, int batch) {
@@ -1070,10 +1302,11 @@ void hipBackendForcePerOp(SymbolicCtx& sym, bool on) {
   h->forcePerOp = on;
 }
 
-void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof) {
+void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof, bool inSitu) {
   HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
   BASPACHO_CHECK_NOTNULL(h);
   h->profile = prof;
+  h->profileInSitu = prof != nullptr && inSitu;
 }
 
 HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t upToLump) {

@@ -868,8 +868,12 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
   return plan;
 }
 
-HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly) {
+HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly, int64_t vecOff,
+                             int64_t ldaIn) {
   HipPlanHost plan;
+  const int64_t ld = ldaIn > 0 ? ldaIn : n;  // row stride of the block and of the rows below it
+  BASPACHO_CHECK_GE(ld, n);
+  BASPACHO_CHECK_LT(ld, (int64_t)INT32_MAX);
   BASPACHO_CHECK_LT(n + k, (int64_t)INT32_MAX);
   const int64_t rowsB = potrfOnly ? 0 : k;
   for (int64_t blockStart = 0; blockStart < n; blockStart += kOuterWidth) {
@@ -879,11 +883,12 @@ HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly)
       LevelRange lr{};
       lr.waitDefLevel = -1;
       PanelDesc pd{};
-      pd.diagOff = offA + c0 * n + c0;
-      pd.lda = (int32_t)n;
+      pd.diagOff = offA + c0 * ld + c0;
+      pd.lda = (int32_t)ld;
       pd.nb = nb;
       pd.nRest = (int32_t)(n - c0 - nb);
       pd.rowsBelow = (int32_t)(pd.nRest + rowsB);
+      pd.vecOff = (int32_t)(vecOff + c0);
       const int32_t pIdx = (int32_t)plan.panels.size();
       plan.panels.push_back(pd);
       const int32_t rowMin = potrfOnly ? 0 : pd.nRest;  // trsm: only the k rows are touched
@@ -902,7 +907,7 @@ HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly)
         sd.q0 = 0;
         sd.m = (int32_t)cols;
         sd.tgtBase = tgtBase;
-        sd.tgtStride = (int32_t)n;
+        sd.tgtStride = (int32_t)ld;
         sd.rowMin = potrfOnly ? 0 : sr.nRest;
         plan.segs.push_back(sd);
         const int32_t s = (int32_t)plan.segs.size() - 1;
@@ -915,21 +920,21 @@ HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly)
       const int64_t innerCols = blockEnd - c0 - nb;
       if (innerCols > 0 && pd.rowsBelow > 0) {
         SrcDesc sr{};
-        sr.off = pd.diagOff + (int64_t)nb * n;
-        sr.lda = (int32_t)n;
+        sr.off = pd.diagOff + (int64_t)nb * ld;
+        sr.lda = (int32_t)ld;
         sr.K = nb;
         sr.rowsBelow = pd.rowsBelow;
         sr.nRest = pd.nRest;
-        addSeg(sr, innerCols, offA + (c0 + nb) * n + (c0 + nb));
+        addSeg(sr, innerCols, offA + (c0 + nb) * ld + (c0 + nb));
       }
       if (c0 + nb == blockEnd && n - blockEnd > 0) {
         SrcDesc sr{};
-        sr.off = offA + blockEnd * n + blockStart;
-        sr.lda = (int32_t)n;
+        sr.off = offA + blockEnd * ld + blockStart;
+        sr.lda = (int32_t)ld;
         sr.K = (int32_t)(blockEnd - blockStart);
         sr.nRest = (int32_t)(n - blockEnd);
         sr.rowsBelow = (int32_t)(sr.nRest + rowsB);
-        addSeg(sr, n - blockEnd, offA + blockEnd * n + blockEnd);
+        addSeg(sr, n - blockEnd, offA + blockEnd * ld + blockEnd);
       }
       lr.updEnd = (int64_t)plan.updTasks.size();
       lr.defBegin = lr.defMid = lr.defEnd = lr.updEnd;

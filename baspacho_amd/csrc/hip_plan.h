@@ -242,7 +242,12 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& skel,
 // on a row-major n x n block at offA followed (contiguously, as in Solver::factorLump,
 // Solver.cpp:42-64) by k rows: potrfOnly -> Cholesky of the block, rows below untouched;
 // otherwise -> the k rows are solved against the already factored block.
-HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly);
+// vecOff: position of the block's first column in a right-hand side vector (the per-op
+// SolveCtx::solveL / solveLt reuse the potrfOnly plan: its panels and row tiles).
+// lda: row stride of the block and of the rows below it (0: the block is contiguous, lda = n);
+// a span inside a wider lump has lda = lump width (NumericCtx::pseudoFactorSpans).
+HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly,
+                             int64_t vecOff = 0, int64_t lda = 0);
 
 // Forward solve over a sparse-elimination range in gather form: the below-diagonal blocks of
 // the small lumps listed per TARGET row span, so that a workgroup sums the products of up to

@@ -642,5 +642,102 @@ __global__ __launch_bounds__(256) void addMvKernel(SkelDev sk, const int64_t* lu
   }
 }
 
+
+// ---- per-op SolveCtx boundary (MatOps.h:139-168) -------------------------------------------------
+// Kernels behind the reference's op-by-op solve driver (Solver.cpp:303-328,357-381,419-448):
+// symm / gemv / assembleVec / gemvT / assembleVecT on a dense temporary of nRows x nRHS values,
+// row-major, one slice per batch entry (blockIdx.z) -- the layout of CpuBaseSolveCtx::tmpBuf
+// (MatOpsCpuBase.h:381-428) and of the device buffer of MatOpsCuda.cu:1093-1181.  These take the
+// place of the cublas gemm / symm calls there; solve() itself never goes through them (fused
+// path), so they are written for clarity: one wave per row, lanes over the columns.
+template <typename T>
+__device__ __forceinline__ GP<T> solveTmp(T* tmp, int64_t tmpStride) {
+  return (GP<T>)tmp + (int64_t)blockIdx.z * tmpStride;
+}
+
+// tmp[r][rhs] = alpha * M[r][:] . A[offA + :, rhs]      (SolveCtx::gemv)
+template <typename T>
+__global__ __launch_bounds__(256) void perOpGemv(SolveRef<T> mv, int64_t offM, int64_t nRows,
+                                                 int64_t nCols, SolveRef<T> av, int64_t offA, T alpha,
+                                                 T* tmp, int64_t tmpStride, int nRHS) {
+  // mv: matrices (data); av: the vectors A (.vec / .vecs, .ldc = lda)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= nRows) return;
+  GP<const T> M = solveMat(mv) + offM + r * nCols;
+  GP<const T> x = (GP<const T>)solveVec(av) + offA;
+  T dot = T(0);
+  for (int64_t c = lane; c < nCols; c += 64) dot += M[c] * x[c];
+  dot = waveSum(dot);
+  if (lane == 0) solveTmp(tmp, tmpStride)[r * nRHS + blockIdx.y] = alpha * dot;
+}
+
+// A[offA + c, rhs] += alpha * sum_r M[r][c] * tmp[r][rhs]      (SolveCtx::gemvT)
+// workgroup = 64 columns x a chunk of 256 rows (wave w takes rows w, w+4, ...), one atomic per
+// column and workgroup
+constexpr int kPerOpRowChunk = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void perOpGemvT(SolveRef<T> mv, int64_t offM, int64_t nRows,
+                                                  int64_t nCols, SolveRef<T> av, int64_t offA, T alpha,
+                                                  const T* tmp, int64_t tmpStride, int nRHS) {
+  __shared__ T part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t colTiles = (nCols + 63) / 64;
+  const int64_t c = (int64_t)(blockIdx.x % colTiles) * 64 + lane;
+  const int64_t rBegin = (int64_t)(blockIdx.x / colTiles) * kPerOpRowChunk;
+  const int64_t rEnd = min(rBegin + (int64_t)kPerOpRowChunk, nRows);
+  GP<const T> M = solveMat(mv) + offM;
+  GP<const T> t = solveTmp(const_cast<T*>(tmp), tmpStride);
+  T acc = T(0);
+  if (c < nCols) {
+    for (int64_t r = rBegin + wave; r < rEnd; r += 4) acc += M[r * nCols + c] * t[r * nRHS + blockIdx.y];
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < nCols) {
+    unsafeAtomicAdd((T*)(solveVec(av) + offA + c),
+                    alpha * (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]));
+  }
+}
+
+// D[offC + i, rhs] += alpha * sum_j S(i,j) C[offC + j, rhs],  S = symmetric matrix whose lower
+// triangle is the row-major n x n block at offM      (SolveCtx::symm)
+template <typename T>
+__global__ __launch_bounds__(256) void perOpSymm(SolveRef<T> mv, int64_t offM, int64_t n,
+                                                 SolveRef<T> cv, int64_t offC, SolveRef<T> dv, T alpha) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  GP<const T> A = solveMat(mv) + offM;
+  GP<const T> x = (GP<const T>)solveVec(cv) + offC;
+  T dot = T(0);
+  for (int64_t j = lane; j < n; j += 64) dot += (j <= i ? A[i * n + j] : A[j * n + i]) * x[j];
+  dot = waveSum(dot);
+  if (lane == 0) solveVec(dv)[offC + i] += alpha * dot;
+}
+
+// C[spanStart(chain i) + j, rhs] += tmp[rowOffset(i) + j][rhs] over the chains
+// [chainColPtr, chainColPtr + numColItems) of one lump column      (SolveCtx::assembleVec);
+// GATHER: the transposed copy, tmp <- C      (SolveCtx::assembleVecT).  One workgroup per chain.
+template <typename T, bool GATHER>
+__global__ __launch_bounds__(256) void perOpAssembleVec(SkelDev sk, int64_t chainColPtr,
+                                                        SolveRef<T> cv, T* tmp, int64_t tmpStride,
+                                                        int nRHS) {
+  const int64_t ch = chainColPtr + blockIdx.x;
+  const int64_t startRow = sk.chainRowsTillEnd[chainColPtr - 1];
+  const int64_t rowOffset = sk.chainRowsTillEnd[ch - 1] - startRow;
+  const int64_t span = sk.chainRowSpan[ch];
+  const int64_t s0 = sk.spanStart[span], sz = sk.spanStart[span + 1] - s0;
+  GP<T> C = solveVec(cv) + s0;
+  GP<T> t = solveTmp(tmp, tmpStride) + rowOffset * nRHS + blockIdx.y;
+  for (int64_t j = threadIdx.x; j < sz; j += 256) {
+    if (GATHER) {
+      t[j * nRHS] = C[j];
+    } else {
+      C[j] += t[j * nRHS];
+    }
+  }
+}
+
 }  // namespace hipk
 }  // namespace BaSpaCho

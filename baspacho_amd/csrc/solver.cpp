@@ -411,10 +411,30 @@ void Solver::addMvFrom(const T* matData, int64_t spanIndex, const T* inVecData, 
   BASPACHO_CHECK_EQ(factorSkel.spanOffsetInLump[spanIndex], 0);
   const int64_t startLump = factorSkel.spanToLump[spanIndex];
   const int64_t upToLump = (int64_t)factorSkel.lumpStart.size() - 1;
-  // (the reference's symm / gemv / assembleVec sequence, Solver.cpp:419-448, is one fused
-  //  device kernel here)
-  slvCtx->addMvRange(matData, startLump, upToLump, inVecData, inStride, outVecData, outStride,
-                     alpha);
+  if (slvCtx->hasFusedSolve()) {
+    // (the reference's symm / gemv / assembleVec sequence below is one fused device kernel here)
+    slvCtx->addMvRange(matData, startLump, upToLump, inVecData, inStride, outVecData, outStride,
+                       alpha);
+    return;
+  }
+  // op-by-op, as the reference drives it (Solver.cpp:412-448)
+  const int64_t spansInRange = factorSkel.lumpToSpan[upToLump] - factorSkel.lumpToSpan[startLump];
+  if (spansInRange == upToLump - startLump && slvCtx->hasFragmentedOps() && nRHS == 1) {
+    BASPACHO_CHECK_EQ(factorSkel.lumpToSpan[startLump], startLump);
+    slvCtx->fragmentedMV(matData, inVecData, startLump, upToLump, outVecData, alpha);
+    return;
+  }
+  for (int64_t l = startLump; l < upToLump; l++) {
+    ColumnGeom g = columnGeom(factorSkel, l);
+    const int64_t vecOff = factorSkel.lumpStart[l];
+    slvCtx->symm(matData, g.diagOffset, g.width, inVecData, vecOff, inStride, outVecData, outStride,
+                 alpha);
+    if (g.rowsBelow == 0) continue;
+    slvCtx->gemv(matData, g.belowOffset, g.rowsBelow, g.width, inVecData, vecOff, inStride, alpha);
+    slvCtx->assembleVec(g.firstBelowChain, g.numBelowChains, outVecData, outStride);
+    slvCtx->assembleVecT(inVecData, inStride, g.firstBelowChain, g.numBelowChains);
+    slvCtx->gemvT(matData, g.belowOffset, g.rowsBelow, g.width, outVecData, vecOff, outStride, alpha);
+  }
 }
 
 template <typename T>

@@ -130,6 +130,11 @@ int bsp_factor_from_f32(bsp_solver* s, float* dev_data, int64_t span_index);
    in the reference's call order (Solver.cpp:164-219) instead of the fused path */
 int bsp_factor_per_op_f64(bsp_solver* s, double* dev_data);
 int bsp_factor_per_op_f32(bsp_solver* s, float* dev_data);
+/* TESTING: while on, factor / solve* / addMvFrom of this solver are driven op by op through the
+   reference's NumericCtx / SolveCtx boundary (MatOps.h:113-184) in the reference's call order
+   (Solver.cpp:164-219, 270-397, 400-449) -- sparseElimSolveL/Lt, symm, solveL, gemv, assembleVec,
+   solveLt, gemvT, assembleVecT, fragmentedMV/SolveL/SolveLt -- instead of the fused paths */
+int bsp_force_per_op(bsp_solver* s, int32_t on);
 /* TESTING hook of the reference: numCtx->doElimination(solver.internalGetElimCtx(i), ...)
    (Solver.h:139-145, tests/FactorTest.cpp:158-160) */
 int bsp_do_elimination_f64(bsp_solver* s, double* dev_data, int64_t elim_range_index);
@@ -164,7 +169,7 @@ int bsp_add_mv_from_f32(bsp_solver* s, const float* dev_mat, int64_t span_index,
                         int64_t in_stride, float* dev_out, int64_t out_stride, int32_t nrhs,
                         float alpha);
 /* Solver::pseudoFactorFrom  Solver.h:92-94: Cholesky of the diagonal block of every span from
-   span_index on, the rows below it divided by the factor (spans of up to 16 columns) */
+   span_index on, the rows below it divided by the factor (any span width, MatOpsCuda.cu:188-233) */
 int bsp_pseudo_factor_from_f64(bsp_solver* s, double* dev_data, int64_t span_index);
 int bsp_pseudo_factor_from_f32(bsp_solver* s, float* dev_data, int64_t span_index);
 /* Solver::solve<std::vector<T*>> etc. (Solver.h:64-73 with the batch types of MatOps.h:38-42):
@@ -203,6 +208,10 @@ enum {
   BSP_PROF_NUM_KINDS = 6
 };
 int bsp_factor_profiled_f64(bsp_solver* s, double* dev_data, double ms[6], int64_t launches[6]);
+/* the same with the real two-stream schedule left on: every launch timed on the stream it runs
+   on, i.e. what a kernel takes beside the others (= what a rocprofv3 kernel trace shows) */
+int bsp_factor_profiled_insitu_f64(bsp_solver* s, double* dev_data, double ms[6],
+                                   int64_t launches[6]);
 
 /* sustained v_mfma_f64_16x16x4_f64 rate of the current GPU (TFLOP/s), register-only probe */
 int bsp_probe_mfma_f64(double* tflops);
