@@ -319,6 +319,26 @@ class Solver:
                 return False
         return _Scope()
 
+    def collectOpStats(self, on=True):
+        """Solver::enableStats + per-op samples of the per-op boundary (bsp_collect_op_stats)"""
+        _check(self._lib.bsp_collect_op_stats(self._h, ctypes.c_int32(1 if on else 0)))
+
+    def opStats(self):
+        """{"potrf": (n,2) [n, s], "trsm": (n,3) [n, k, s], "syge": (n,4) [m, n, k, s],
+        "asmbl": (n,3) [blockRows, blockCols, s]} collected since collectOpStats(True)"""
+        out = {}
+        for which, (name, nsz) in enumerate((("potrf", 1), ("trsm", 2), ("syge", 3), ("asmbl", 2))):
+            cnt = ctypes.c_int64(0)
+            _check(self._lib.bsp_read_op_stats(self._h, ctypes.c_int32(which), None, ctypes.c_int64(0),
+                                               ctypes.byref(cnt)))
+            buf = np.zeros((cnt.value, 4))
+            if cnt.value:
+                _check(self._lib.bsp_read_op_stats(
+                    self._h, ctypes.c_int32(which), buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                    ctypes.c_int64(cnt.value), ctypes.byref(cnt)))
+            out[name] = np.concatenate([buf[:, :nsz], buf[:, 3:4]], axis=1)
+        return out
+
     def factorUpTo(self, data, span_index):
         self._check_data(data)
         _check(getattr(self._lib, "bsp_factor_up_to_" + _suffix(data))(

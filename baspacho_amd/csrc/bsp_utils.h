@@ -3,6 +3,7 @@
 // DebugMacros.h:17-50 (precondition failures throw std::runtime_error).
 #pragma once
 
+#include <array>
 #include <cstdint>
 #include <sstream>
 #include <stdexcept>
@@ -100,12 +101,21 @@ struct OpStat {
   bool enabled = false;
   int64_t numRuns = 0;
   double totTime = 0, lastTime = 0, maxTime = 0;
-  void reset() { numRuns = 0; totTime = lastTime = maxTime = 0; }
-  void add(double t) {
+  // per-call samples {size0, size1, size2, seconds} (the role of the reference's callBack hook,
+  // Utils.h:100-119, which bench -Z uses to dump one CSV row per op, Bench.cpp:72-124)
+  bool keepSamples = false;
+  std::vector<std::array<double, 4>> samples;
+  void reset() {
+    numRuns = 0;
+    totTime = lastTime = maxTime = 0;
+    samples.clear();
+  }
+  void add(double t, double s0 = 0, double s1 = 0, double s2 = 0) {
     numRuns++;
     totTime += t;
     lastTime = t;
     if (t > maxTime) maxTime = t;
+    if (keepSamples) samples.push_back({s0, s1, s2, t});
   }
   std::string toString() const;
 };

@@ -17,12 +17,14 @@ for f in $SRCS; do
     pids+=($!)
   fi
 done
-o=../_build/hip_backend.o
-OBJS="$OBJS $o"
-if [ ! -f "$o" ] || [ hip_backend.hip -nt "$o" ] || [ -n "$(find . -name '*.h' -newer "$o" -print -quit)" ]; then
-  $HIPCC $FLAGS -c hip_backend.hip -o "$o" &
-  pids+=($!)
-fi
+for f in hip_backend.hip bal_pipeline.hip; do
+  o=../_build/${f%.hip}.o
+  OBJS="$OBJS $o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -name '*.h' -newer "$o" -print -quit)" ]; then
+    $HIPCC $FLAGS -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC -shared -fPIC --offload-arch=gfx950 $OBJS -o $OUT
 echo "built $OUT"

@@ -7,6 +7,7 @@
 #include <string>
 #include <unordered_set>
 
+#include "bal_pipeline.h"
 #include "computation_model.h"
 #include "hip_backend.h"
 #include "solver.h"
@@ -239,6 +240,27 @@ int bsp_factor_per_op_f32(bsp_solver* s, float* d) {
   BSP_CATCH
 }
 
+int bsp_collect_op_stats(bsp_solver* s, int32_t on) {
+  BSP_TRY
+  SymbolicCtx& sym = s->solver->internalSymbolicContext();
+  s->solver->enableStats(on != 0);
+  s->solver->resetStats();
+  for (OpStat* st : {&sym.potrfStat, &sym.trsmStat, &sym.sygeStat, &sym.asmblStat}) st->keepSamples = on != 0;
+  BSP_CATCH
+}
+int bsp_read_op_stats(bsp_solver* s, int32_t which, double* out, int64_t capacity, int64_t* count) {
+  BSP_TRY
+  SymbolicCtx& sym = s->solver->internalSymbolicContext();
+  const OpStat* sts[4] = {&sym.potrfStat, &sym.trsmStat, &sym.sygeStat, &sym.asmblStat};
+  BASPACHO_CHECK(which >= 0 && which < 4);
+  const auto& v = sts[which]->samples;
+  *count = (int64_t)v.size();
+  for (int64_t i = 0; i < std::min<int64_t>(capacity, (int64_t)v.size()); i++) {
+    for (int j = 0; j < 4; j++) out[4 * i + j] = v[i][j];
+  }
+  BSP_CATCH
+}
+
 int bsp_force_per_op(bsp_solver* s, int32_t on) {
   BSP_TRY
   hipBackendForcePerOp(s->solver->internalSymbolicContext(), on != 0);
@@ -374,6 +396,34 @@ int bsp_solve_batched_f32(bsp_solver* s, const float* const* mats, float* const*
                           int32_t batch, int64_t stride, int32_t nrhs, int32_t which) {
   BSP_TRY
   solveBatched<float>(s, mats, vecs, batch, stride, nrhs, which);
+  BSP_CATCH
+}
+
+int bsp_bal_linearize_f64(int64_t numObs, const int64_t* obsCam, const int64_t* obsPt,
+                          const double* obsXy, const double* cams, const double* pts, double* res,
+                          double* Jc, double* Jp, void* stream) {
+  BSP_TRY
+  balLinearize(numObs, obsCam, obsPt, obsXy, cams, pts, res, Jc, Jp, stream);
+  BSP_CATCH
+}
+int bsp_bal_fill_hessian_f64(bsp_solver* s, int64_t numPts, int64_t numCams, int64_t numObs,
+                             const int64_t* obsCam, const int64_t* obsPt, const double* Jc,
+                             const double* Jp, const double* res, double lambda, double* data,
+                             double* grad, int64_t* dbg, void* stream) {
+  BSP_TRY
+  BASPACHO_CHECK_EQ(numPts + numCams, s->solver->skel().numSpans());
+  balFillHessian<double>(s->solver->deviceAccessor(), numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
+                         res, lambda, data, grad, dbg, stream);
+  BSP_CATCH
+}
+int bsp_bal_fill_hessian_f32(bsp_solver* s, int64_t numPts, int64_t numCams, int64_t numObs,
+                             const int64_t* obsCam, const int64_t* obsPt, const double* Jc,
+                             const double* Jp, const double* res, float lambda, float* data,
+                             float* grad, int64_t* dbg, void* stream) {
+  BSP_TRY
+  BASPACHO_CHECK_EQ(numPts + numCams, s->solver->skel().numSpans());
+  balFillHessian<float>(s->solver->deviceAccessor(), numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
+                        res, lambda, data, grad, dbg, stream);
   BSP_CATCH
 }
 

@@ -235,6 +235,32 @@ struct LaunchTimer {
   }
 };
 
+// per-op statistics of the per-op boundary (OpStat, Utils.h:48-121 of the reference): HIP events
+// around the launches of one op, read back synchronously -- only while stats are enabled
+struct OpTimer {
+  OpStat& st;
+  hipStream_t stream;
+  hipEvent_t a = nullptr, b = nullptr;
+  double s0, s1, s2;
+  OpTimer(OpStat& st_, hipStream_t stream_, double s0_ = 0, double s1_ = 0, double s2_ = 0)
+      : st(st_), stream(stream_), s0(s0_), s1(s1_), s2(s2_) {
+    if (!st.enabled) return;
+    hipCHECK(hipEventCreate(&a));
+    hipCHECK(hipEventCreate(&b));
+    hipCHECK(hipEventRecord(a, stream));
+  }
+  ~OpTimer() {
+    if (!a) return;
+    float ms = 0;
+    if (hipEventRecord(b, stream) == hipSuccess && hipEventSynchronize(b) == hipSuccess &&
+        hipEventElapsedTime(&ms, a, b) == hipSuccess) {
+      st.add(ms * 1e-3, s0, s1, s2);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+  }
+};
+
 struct HipSymbolicCtx : SymbolicCtx {
   HipSymbolicCtx(const CoalescedBlockMatrixSkel& skel_, const vector<int64_t>& permutation_)
       : skel(skel_), permutation(permutation_) {
@@ -734,6 +760,7 @@ struct HipNumericCtx : NumericCtx<T> {
   virtual void potrf(int64_t n, T* data, int64_t offA) override {
     sym.potrfBiggestN = std::max(sym.potrfBiggestN, n);
     DevPlan& plan = adoptPlan(buildDenseOpPlan(n, 0, offA, /*potrfOnly=*/true));
+    OpTimer opTimer(sym.potrfStat, sym.stream, (double)n);
     LaunchTimer timer(sym.stream, nullptr);
     const bool la = sym.lookaheadEnabled;
     sym.lookaheadEnabled = false;
@@ -747,6 +774,7 @@ struct HipNumericCtx : NumericCtx<T> {
     // (Solver.cpp:43-64); the blocked solve relies on that contiguity
     BASPACHO_CHECK_EQ(offB, offA + n * n);
     DevPlan& plan = adoptPlan(buildDenseOpPlan(n, k, offA, /*potrfOnly=*/false));
+    OpTimer opTimer(sym.trsmStat, sym.stream, (double)n, (double)k);
     LaunchTimer timer(sym.stream, nullptr);
     const bool la = sym.lookaheadEnabled;
     sym.lookaheadEnabled = false;
@@ -780,6 +808,7 @@ struct HipNumericCtx : NumericCtx<T> {
     }
     DevPlan& plan = adoptPlan(std::move(host));
     sym.gemmCalls++;
+    OpTimer opTimer(sym.sygeStat, sym.stream, (double)m, (double)n, (double)k);
     // temp := -(P P^T) on the lower trapezoid (the strictly upper part of the leading m x m block
     // "doesn't matter", MatOps.h:129); assemble() adds it
     launchUpdate(plan, 0, plan.numUpdTasks, makeRef(const_cast<T*>(data)),
@@ -798,6 +827,7 @@ struct HipNumericCtx : NumericCtx<T> {
   virtual void assemble(T* data, int64_t rectRowBegin, int64_t dstStride, int64_t srcColDataOffset,
                         int64_t srcRectWidth, int64_t numBlockRows, int64_t numBlockCols) override {
     hipk::SkelDev sk = sym.skelDev();
+    OpTimer opTimer(sym.asmblStat, sym.stream, (double)numBlockRows, (double)numBlockCols);
     hipk::assembleKernel<BT><<<dim3((unsigned)numBlockRows, (unsigned)batchSize), 256, 0, sym.stream>>>(
         sk, spanToChainOffset.as<int64_t>(), temp.as<BT>(), tempBufSize, makeRef(data),
         rectRowBegin, dstStride, srcColDataOffset, srcRectWidth, numBlockRows, numBlockCols);

@@ -115,7 +115,10 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
     return;
   }
   lap("count pairs");
-  if (nPairs >= (int64_t)INT32_MAX) return;
+  // (pairBegin / pairEnd are int32 indices into the plan-wide pair streams, which accumulate over
+  //  all elimination ranges: the RUNNING total has to fit, not just this range; otherwise the
+  //  range keeps the scatter kernel, useGather = false)
+  if ((int64_t)plan.elimPairOffJ.size() + nPairs >= (int64_t)INT32_MAX) return;
   for (int64_t c = 0; c < nChainsTot; c++) bucketPtr[c + 1] += bucketPtr[c];
   std::vector<Pair> sorted((size_t)nPairs);
   {

@@ -1,23 +1,32 @@
 #!/usr/bin/env python
-"""bench.py -- fp64 factor() throughput of the MI355X backend on the BAL-871-shaped Schur problem.
+"""bench.py -- fp64 factor() throughput of the MI355X backend.
 
-A "step" = one Solver::factor() of one matrix resident in HBM (per rank).  Protocol follows the
-reference's BAL_bench (benchmarking/BaAtLargeBench.cpp:44-97,155-171): structure only from the
-problem (points first, size 3; cameras after, size 9; one block per observation), sparse
-elimination range {0, numPts}, numeric data = uniform(-1,1) seed 37 then damp(0, 1.2*order),
-warm-up factor, timed factor on device-resident data (H2D excluded).  The BAL file is not
-available offline, so the structure comes from the committed synthetic generator
-(baspacho_amd/testing.py: gen_bal_synthetic, 871 cameras / 527480 points / 2.79 M observations).
+A "step" = one Solver::factor() of this rank's matrices, resident in HBM.  Protocol follows the
+reference's benches (benchmarking/BaAtLargeBench.cpp:44-97,155-171, Bench.cpp:150-160,227-233):
+structure only from the problem, numeric data = uniform(-1,1) seed 37 (+q for matrix q of a batch)
+then damp(0, 1.2*order) (1.3 for batches), warm-up factors, timed factors on device-resident data
+(H2D excluded), every timed step on a pristine copy.
 
-N>1: one process per GPU; rank 0 runs the symbolic analysis and broadcasts the flat symbolic
-plan over RCCL; every rank then factors its own matrix of that structure (batched mode sharded
-over the GPUs, no collective inside a factorisation) -> weak scaling.
+--gpus 1 (default): the headline config, BAL-871 Schur problem (BASELINE.json configs[2]):
+  points first (size 3), cameras after (size 9), one block per observation, sparse elimination
+  range {0, numPts}.  The BAL file is not available offline: the structure comes from the committed
+  synthetic generator (baspacho_amd/testing.py: gen_bal_synthetic, 871 cameras / 527480 points /
+  2.79 M observations) unless --bal-file PATH supplies a real one (loader: baspacho_amd/bal.py).
+  Extra workloads measured in the same run and reported inside the same JSON line: "batched" =
+  BASELINE configs[3] (64 x GRID 82x82 x 3, one batched factor() per step) and "c5" = BAL-1723
+  shaped fp32 factor + fp64 iterative refinement (configs[4]).
+--gpus N > 1 (torchrun, one process per GPU): the batched config of BASELINE's metric ("batch
+  throughput at 1/2/4/8 GPUs"): rank 0 runs the symbolic analysis, broadcasts the flat plan over
+  RCCL, the 64 matrices are sharded contiguously (no collective inside a factorisation);
+  "scaling": "strong" (total work fixed).  "bal871_replicas" (one BAL-871 matrix per GPU, weak)
+  and "batched_1gpu" (rank 0 alone factoring all 64: the 1-GPU point of the same curve) ride along.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,34 +39,51 @@ if ROOT not in sys.path:
 
 import baspacho_amd as B  # noqa: E402
 from baspacho_amd import testing as T  # noqa: E402
+from baspacho_amd.distributed import broadcast_solver, shard_batch  # noqa: E402
 
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = ROOT
 DT = "double"
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix (= vector) peak, AMD datasheet
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_problem(name):
+def build_problem(name, bal_file=None):
+    """returns (paramSizes, SparseStructure, sparseElimRanges, description, data source)"""
+    if name == "bal871" and bal_file:
+        from baspacho_amd import bal
+        prob = bal.load_bal(bal_file)
+        sizes, ss, ranges = bal.bal_structure(prob)
+        return sizes, ss, ranges, "BAL file %s: %d cams x 9, %d pts x 3, %d obs" % (
+            os.path.basename(bal_file), prob.num_cams, prob.num_pts, len(prob.obs_cam)), "file"
     if name == "bal871":
         sizes, ss, cam, pt = T.gen_bal_synthetic()
-        return sizes, ss, [0, 527480], "synthetic BAL-871 stand-in: 871 cams x 9, 527480 pts x 3, %d obs" % len(cam)
+        return sizes, ss, [0, 527480], ("synthetic BAL-871 stand-in: 871 cams x 9, 527480 pts x 3, "
+                                        "%d obs" % len(cam)), "synthetic"
+    if name == "bal1723":
+        sizes, ss, cam, pt = T.gen_bal_synthetic(num_cams=1723, num_pts=156502, mean_track=4.4,
+                                                 band=24, far_prob=0.02, seed=41)
+        return sizes, ss, [0, 156502], ("synthetic BAL-1723 stand-in: 1723 cams x 9, 156502 pts x 3, "
+                                        "%d obs" % len(cam)), "synthetic"
     if name == "bal-small":
         sizes, ss, cam, pt = T.gen_bal_synthetic(num_cams=120, num_pts=40000, band=16)
-        return sizes, ss, [0, 40000], "synthetic BAL-like: 120 cams, 40000 pts, %d obs" % len(cam)
+        return sizes, ss, [0, 40000], "synthetic BAL-like: 120 cams, 40000 pts, %d obs" % len(cam), "synthetic"
     if name == "flat50k":
         ss = T.gen_flat(16667, 3.0e-4, 37)
-        return np.full(16667, 3, dtype=np.int64), ss, [], "FLAT 16667 x 3, fill 3e-4"
+        return np.full(16667, 3, dtype=np.int64), ss, [], "FLAT 16667 x 3, fill 3e-4", "synthetic"
     if name == "grid82":
         ss = T.gen_grid(82, 82, 1.0, 2, 37)
-        return np.full(82 * 82, 3, dtype=np.int64), ss, [], "GRID 82x82 conn 2 x 3"
+        return np.full(82 * 82, 3, dtype=np.int64), ss, [], "GRID 82x82 conn 2 x 3", "synthetic"
     if name == "tridiag":
-        return np.full(3334, 3, dtype=np.int64), T.block_tridiagonal(3334), [], "block-tridiagonal 3334 x 3"
+        return (np.full(3334, 3, dtype=np.int64), T.block_tridiagonal(3334), [],
+                "block-tridiagonal 3334 x 3", "synthetic")
     raise ValueError(name)
 
 
 def residual_probe(sol, host_A, L_dev, nprobe=2, seed=5):
-    """size-independent check of L L^T = A at FULL size: ||L (L^T x) - A x|| / ||A x|| for random
-    x, A and L applied as block-sparse operators through the skeleton (checker = oracle/)"""
+    """size-independent check of L L^T = A at FULL size: the VECTOR probe ||L (L^T x) - A x|| /
+    ||A x|| for random x, A and L applied as block-sparse operators through the skeleton
+    (checker = oracle/; the Frobenius form ||L L^T - A||_F / ||A||_F is what the dense-size tests
+    in tests/ check)"""
     from oracle import cref
     L = L_dev.cpu().numpy()
     skh = cref.SkelHandle(sol.skel())
@@ -68,17 +94,273 @@ def residual_probe(sol, host_A, L_dev, nprobe=2, seed=5):
     return worst
 
 
+class Runner:
+    """this rank's share of a workload: solver, pristine matrices in HBM, timed factor steps"""
+
+    def __init__(self, ctx, workload, total_batch, batched, bal_file=None, participate=True):
+        self.ctx, self.workload, self.batched = ctx, workload, batched
+        rank, world, device = ctx["rank"], ctx["world"], ctx["device"]
+        self.t_sym, self.desc, self.source = 0.0, "", "synthetic"
+        sol = None
+        if rank == 0:
+            sizes, ss, ranges, self.desc, self.source = build_problem(workload, bal_file)
+            t0 = time.time()
+            sol = B.create_solver(B.Settings(), sizes, ss, ranges)
+            self.t_sym = time.time() - t0
+        if world > 1 and participate:
+            sol = broadcast_solver(sol, src=0, device=device)
+        self.sol = sol
+        if sol is None:
+            return
+        sol.setStream(torch.cuda.current_stream(device))
+        self.order, self.flops = sol.order(), sol.factorFlops()
+        self.total_batch = total_batch
+        self.q0, self.q1 = shard_batch(total_batch, world, rank) if participate else (0, total_batch)
+        # seeds / damping as the reference's benches: seed 37 (+q), damp 1.2 (1.3 for batches)
+        self.hosts = []
+        for q in range(self.q0, self.q1):
+            h = T.random_data(sol.dataSize(), -1.0, 1.0, 37 + q)
+            sol.damp(h, 0.0, self.order * (1.3 if batched else 1.2))
+            self.hosts.append(h)
+        self.A_devs = [torch.from_numpy(h).to(device) for h in self.hosts]
+
+    def run(self, steps, warmup, sync_ranks=True):
+        """W untimed + K timed factor() calls, barrier + synchronize on both sides, max over ranks"""
+        dist, device = (self.ctx["dist"] if sync_ranks else None), self.ctx["device"]
+        n_buf = steps + warmup
+        if self.batched:
+            bufs = [[a.clone() for a in self.A_devs] for _ in range(n_buf)]
+        else:
+            bufs = [self.A_devs[0].clone() for _ in range(n_buf)]
+        torch.cuda.synchronize(device)
+        for i in range(warmup):
+            self.sol.factor(bufs[i])
+        torch.cuda.synchronize(device)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.sol.factor(bufs[warmup + i])
+        torch.cuda.synchronize(device)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+        if dist:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        self.last = bufs[-1][0] if self.batched else bufs[-1]
+        if sync_ranks:   # every rank took part: the whole batch, or one matrix per rank
+            n_mat = self.total_batch if self.batched else self.ctx["world"]
+        else:            # this rank alone
+            n_mat = self.total_batch if self.batched else 1
+        ms = 1e3 * elapsed / steps
+        return {"value": round(n_mat * self.flops * steps / elapsed / 1e9, 2), "unit": "GF/s",
+                "ms_per_step": round(ms, 4), "matrices_per_step": n_mat,
+                "matrices_per_s": round(n_mat * steps / elapsed, 2)}
+
+
+def physical_cores():
+    """(physical cores, hardware threads, model name) of the host"""
+    cores, model, threads = set(), "", 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                threads += 1
+            elif line.startswith("model name") and not model:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+                cores.add((phys, core))
+    except OSError:
+        pass
+    return (len(cores) or os.cpu_count() or 1), (threads or os.cpu_count() or 1), model
+
+
+def cpu_baseline(sol, host, flops, value):
+    """the BackendFast restatement (oracle/blas_factor.c: same call sequence and syrk/gemm rule as
+    MatOpsFast.cpp) on the host cores: 1 warm-up + median of 3 full factors of the same matrix"""
+    from oracle import cref
+    n_phys, n_threads, model = physical_cores()
+    # small problems run slower on a wide BLAS team (per-call fork/join on tiny fronts): about one
+    # thread per 0.5 GF of work; the headline workload gets every physical core the BLAS accepts
+    want = max(1, min(n_phys, int(flops / 0.5e9)))
+    _, blas_desc = cref.blas_lib(want)
+    cap = want
+    for tok in blas_desc.split():
+        if tok.startswith("MAX_THREADS="):
+            cap = int(tok.split("=")[1])
+    used = min(want, cap)
+    skh = cref.SkelHandle(sol.skel())
+    ranges = sol.sparseEliminationRanges()
+    times, elims = [], []
+    for it in range(4):
+        hostA = host.copy()
+        t0 = time.perf_counter()
+        es = cref.blas_factor(skh, hostA, ranges, want)
+        dt = time.perf_counter() - t0
+        if it > 0:      # (first run = warm-up: page faults of the copy, BLAS thread start-up)
+            times.append(dt)
+            elims.append(es)
+        if dt > 20.0:
+            break
+    if not times:
+        times, elims = [dt], [es]
+    dt = statistics.median(times)
+    out = {"value": round(flops / dt / 1e9, 2), "unit": "GF/s", "cores": used, "kind": "port",
+           "seconds": round(dt, 3), "seconds_all": [round(t, 3) for t in times],
+           "elim_seconds": round(statistics.median(elims), 3),
+           "sample": "full factor() of the same matrix (same plan, same data): 1 warm-up + median of %d"
+                     % len(times),
+           "host": {"model": model, "physical_cores": n_phys, "hardware_threads": n_threads},
+           "blas": blas_desc,
+           "blas_thread_cap": cap,
+           "note": "cores = BLAS/OpenMP threads actually used (the wheel's OpenBLAS is built with "
+                   "MAX_THREADS=%d; its DYNAMIC_ARCH picks the AVX-512 SkylakeX kernels on this "
+                   "host, the widest it has)" % cap}
+    out["speedup_gpu_over_cpu"] = round(value / out["value"], 2)
+    return out
+
+
+def roofline_block(sol, A_dev, flops, ms_per_step, workload):
+    """per-kernel-class times with HIP events on the stream each launch runs on, (a) in the real
+    two-stream schedule (in situ: what rocprofv3's kernel trace shows) and (b) serialised; the
+    dominant class is the one with the largest IN-SITU time"""
+    st = sol.planStats()
+    out = {}
+    prof_iso = sol.factorProfiled(A_dev.clone(), in_situ=False)
+    prof = sol.factorProfiled(A_dev.clone(), in_situ=True)
+    out["kernel_ms"] = {k: [round(v[0], 4), v[1]] for k, v in prof.items()}
+    out["kernel_ms_isolated"] = {k: [round(v[0], 4), v[1]] for k, v in prof_iso.items()}
+    # algorithmic work of every kernel class, from the plan (DESIGN.md "Kernels"):
+    #   update / chain_update: 2 K per lower-trapezoid target element (symmetric update)
+    #   elim_update: every below-diagonal source block read ONCE (distinct source bytes) + one
+    #     read-modify-write of every distinct target element
+    #   elim_factor: every element of the eliminated columns read and written once
+    sk = sol.skel()
+    ranges = sol.sparseEliminationRanges()
+    diag_elems = 0.0
+    for r in range(len(ranges) - 1):
+        w = np.diff(sk["lumpStart"][int(ranges[r]):int(ranges[r + 1]) + 1]).astype(np.float64)
+        diag_elems += float((w * w).sum())
+    elim_src_bytes = 8.0 * (st["elim_col_elems"] - diag_elems)
+    work_of = {
+        "update": ("updateTileBulk|updateTile<%s>" % DT, "mfma", st["upd_flops"] - st["upd_flops_direct"]),
+        # (one-panel levels: update tiles + the next panel's potrf, and inside an outer block also
+        #  the panel's trsm, in one launch)
+        "chain_update": ("chainStep|updateTileDirectPotrf<%s>" % DT, "mfma",
+                         st["upd_flops_direct"] + st["trsm_flops_merged"] + st["potrf_flops_fused"]),
+        "elim_update": ("elimGatherMfma<%s>" % DT, "hbm", elim_src_bytes + 16.0 * st["elim_target_elems"]),
+        "elim_factor": ("elimFactorTiny|elimFactorSmall<%s>" % DT, "hbm", 16.0 * st["elim_col_elems"]),
+        "trsm": ("trsmPanel<%s>" % DT, "mfma", st["trsm_flops"] - st["trsm_flops_merged"]),
+        "potrf": ("potrfPanel<%s>" % DT, "mfma", st["potrf_flops"] - st["potrf_flops_fused"]),
+    }
+    dom = max(prof, key=lambda k: prof[k][0])
+    ms, launches = prof[dom]
+    kname, bound, amount = work_of[dom]
+    scale = 1e12 if bound == "mfma" else 1e9
+    rate = amount / (ms * 1e-3) / scale
+    peak = PEAK_FP64_MFMA_TFLOPS if bound == "mfma" else PEAK_HBM_GBS
+    iso_ms = prof_iso[dom][0]
+    roof = {"kernel": kname, "bound": bound, "achieved": round(rate, 3), "peak": peak,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "frac": round(rate / peak, 4),
+            "frac_isolated": round(amount / (iso_ms * 1e-3) / scale / peak, 4) if iso_ms > 0 else None,
+            "traffic": None, "launches": launches,
+            "avg_launch_ms": round(ms / max(launches, 1), 5),
+            "timing": "HIP events around every launch on the stream it runs on, lookahead "
+                      "schedule on (in situ); frac_isolated = same launches serialised",
+            ("algorithmic_flops_per_launch" if bound == "mfma" else "algorithmic_bytes_per_launch"):
+                amount / max(launches, 1),
+            ("algorithmic_flops" if bound == "mfma" else "algorithmic_bytes"): amount,
+            "share_of_kernel_time": round(ms / sum(v[0] for v in prof.values()), 3)}
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+    # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported), same workload
+    try:
+        with open(os.path.join(HERE, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        names = kname.split("<")[0].split("|")
+        ents = [pmc.get(workload, {}).get(n) for n in names]
+        ents = [e for e in ents if e]
+        if ents:
+            ent = {k: sum(e[k] for e in ents) for k in ("fetch_KB_per_factor", "write_KB_per_factor")}
+            roof["traffic"] = (2.0 * ent["fetch_KB_per_factor"] +
+                               ent["write_KB_per_factor"]) * 1024.0 / max(launches, 1)
+            roof["traffic_source"] = pmc.get("_source", "profiles/pmc_traffic.json")
+    except (OSError, ValueError):
+        pass
+    # the same fraction recomputed from the committed rocprofv3 kernel stats (avg_ns of the class)
+    try:
+        with open(os.path.join(HERE, "profiles", "rocprof_roofline.json")) as f:
+            rr = json.load(f).get(workload, {})
+        if dom in rr:
+            roof["rocprof"] = rr[dom]
+    except (OSError, ValueError):
+        pass
+    if bound == "mfma":
+        probe = B.probe_mfma_f64_tflops()   # back-to-back fp64 MFMAs on this very GPU
+        roof["measured_mfma_probe"] = round(probe, 2)
+        roof["frac_of_probe"] = round(rate / probe, 4)
+    out["roofline"] = roof
+    sec = {}
+    for k, (nm, bd, amt) in work_of.items():
+        if prof[k][0] > 0 and amt > 0:
+            sc = 1e12 if bd == "mfma" else 1e9
+            pk = PEAK_FP64_MFMA_TFLOPS if bd == "mfma" else PEAK_HBM_GBS
+            r = amt / (prof[k][0] * 1e-3) / sc
+            ent = {"kernel": nm, "rate": round(r, 3 if bd == "mfma" else 1),
+                   "unit": "TFLOP/s" if bd == "mfma" else "GB/s", "frac": round(r / pk, 4),
+                   "ms": round(prof[k][0], 4), "launches": prof[k][1],
+                   ("algorithmic_flops" if bd == "mfma" else "algorithmic_bytes"): amt}
+            if prof_iso[k][0] > 0:
+                ent["rate_isolated"] = round(amt / (prof_iso[k][0] * 1e-3) / sc, 3 if bd == "mfma" else 1)
+            sec[k] = ent
+    out["kernel_rates"] = sec
+    # whole-factor roofline: max(flops / MFMA peak, compulsory bytes / HBM peak)
+    t_roof = max(flops / (PEAK_FP64_MFMA_TFLOPS * 1e12), 16.0 * sol.dataSize() / (PEAK_HBM_GBS * 1e9))
+    out["factor_roofline_frac"] = round(t_roof / (ms_per_step * 1e-3), 4)
+    return out
+
+
+def c5_block(device):
+    """BASELINE configs[4]: fp32 factor + fp64 iterative refinement on a BAL-1723 shaped problem,
+    all numerics in the library (factor<float>, solve<float>, addMvFrom<double>)"""
+    from baspacho_amd.refine import solve_refined
+    sizes, ss, ranges, desc, _ = build_problem("bal1723")
+    sol = B.create_solver(B.Settings(), sizes, ss, ranges)
+    sol.setStream(torch.cuda.current_stream(device))
+    h = T.random_data(sol.dataSize(), -1.0, 1.0, 37)
+    sol.damp(h, 0.0, sol.order() * 1.2)
+    A = torch.from_numpy(h).to(device)
+    b = torch.from_numpy(T.random_data(sol.order(), -1, 1, 38)).to(device)
+    tm = {}
+    solve_refined(sol, A, b, tol=1e-10)                 # warm-up (plans, solve lists)
+    x, iters, hist = solve_refined(sol, A, b, tol=1e-10, timings=tm)
+    return {"workload": desc, "order": sol.order(), "factor_f32_ms": round(tm["factor_f32_ms"], 3),
+            "refine_ms": round(tm["refine_ms"], 3), "iterations": iters,
+            "final_rel_residual": hist[-1], "factor_GF": round(sol.factorFlops() / 1e9, 2),
+            "factor_f32_GFs": round(sol.factorFlops() / tm["factor_f32_ms"] / 1e6, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="bal871")
-    ap.add_argument("--batch", type=int, default=0,
+    ap.add_argument("--workload", default=None,
+                    help="default: bal871 at --gpus 1, grid82 (batch 64, sharded) at --gpus N > 1")
+    ap.add_argument("--batch", type=int, default=None,
                     help="total number of identical-structure matrices (sharded over the GPUs); "
-                         "0 = one matrix per GPU")
+                         "0 = one matrix per GPU, each its own factor() (replicas)")
+    ap.add_argument("--bal-file", default=None, help="BAL text file for the bal871 workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,196 +376,104 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, "launch with torchrun --nproc-per-node == --gpus"
+    ctx = {"rank": rank, "world": world, "device": device, "dist": dist}
 
-    # ---- symbolic analysis on rank 0, plan broadcast over RCCL ------------------------------
-    t_sym = 0.0
-    desc = ""
-    sol = None
-    if rank == 0:
-        sizes, ss, ranges, desc = build_problem(args.workload)
-        t0 = time.time()
-        sol = B.create_solver(B.Settings(), sizes, ss, ranges)
-        t_sym = time.time() - t0
-    if world > 1:
-        from baspacho_amd.distributed import broadcast_solver
-        sol = broadcast_solver(sol, src=0, device=device)
-    sol.setStream(torch.cuda.current_stream(device))
-
-    # ---- numeric data: K+W pristine copies of this rank's matrices resident in HBM ------------
-    order, flops = sol.order(), sol.factorFlops()
-    from baspacho_amd.distributed import shard_batch
-    total_batch = args.batch if args.batch > 0 else world
-    q0, q1 = shard_batch(total_batch, world, rank)
-    n_local = q1 - q0
-    # seeds / damping as the reference's batched bench (Bench.cpp:227-233): seed 37+q
-    hosts = []
-    for q in range(q0, q1):
-        h = T.random_data(sol.dataSize(), -1.0, 1.0, 37 + q)
-        sol.damp(h, 0.0, order * (1.2 if args.batch == 0 else 1.3))
-        hosts.append(h)
-    host = hosts[0]
-    A_devs = [torch.from_numpy(h).to(device) for h in hosts]
-    A_dev = A_devs[0]
-    n_buf = args.steps + args.warmup
-    if args.batch == 0:
-        bufs = [A_dev.clone() for _ in range(n_buf)]
+    workload = args.workload or ("bal871" if world == 1 else "grid82")
+    if args.batch is None:
+        batch = 64 if (workload == "grid82" and world > 1) else 0
     else:
-        bufs = [[a.clone() for a in A_devs] for _ in range(n_buf)]   # batched factor() per step
-    torch.cuda.synchronize(device)
+        batch = args.batch
+    batched = batch > 0
+    total_batch = batch if batched else world
 
-    for i in range(args.warmup):
-        sol.factor(bufs[i])
-    torch.cuda.synchronize(device)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        sol.factor(bufs[args.warmup + i])
-    torch.cuda.synchronize(device)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    main_run = Runner(ctx, workload, total_batch, batched, args.bal_file)
+    res = main_run.run(args.steps, args.warmup)
+    sol = main_run.sol
 
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = total_batch * flops * args.steps / elapsed / 1e9
-
+    metric = {"bal871": "factor_gflops_fp64_bal871_schur"}.get(workload, "factor_gflops_fp64_" + workload)
+    if batched:
+        metric = "batched_" + metric
     out = {
-        "metric": "factor_gflops_fp64_bal871_schur" if args.workload == "bal871"
-        else "factor_gflops_fp64_" + args.workload,
-        "value": round(value, 2), "unit": "GF/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": args.workload, "description": desc, "order": order,
-                   "data_MB": round(sol.dataSize() * 8 / 1e6, 1), "matrices_per_gpu": n_local,
-                   "batch": total_batch,
-                   "factor_GF_per_matrix": round(flops / 1e9, 3),
-                   "parallelism": "batch-shard x%d (plan broadcast over RCCL)" % world},
+        "metric": metric, "value": res["value"], "unit": "GF/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": "strong" if batched else "weak", "vs_baseline": None,
+        "dtype": "f64", "data": main_run.source if rank == 0 else "synthetic",
+        "config": {"workload": workload, "description": main_run.desc, "order": main_run.order,
+                   "data_MB": round(sol.dataSize() * 8 / 1e6, 1),
+                   "matrices_per_gpu": main_run.q1 - main_run.q0, "batch": total_batch,
+                   "matrices_per_s": res["matrices_per_s"],
+                   "factor_GF_per_matrix": round(main_run.flops / 1e9, 3),
+                   "numeric_data": "mock: uniform(-1,1) seed 37(+q), damp(0, %.1f*order), as the "
+                                   "reference's benches" % (1.3 if batched else 1.2),
+                   "parallelism": ("batch of %d sharded over %d GPU(s), plan broadcast over RCCL"
+                                   % (total_batch, world)) if batched else
+                                  ("one matrix per GPU x%d (replicas; a single factorisation is not sharded)" % world)},
     }
 
     if rank == 0:
-        # ---- parity at full size: residual probe of the last timed factor -------------------
-        last = bufs[-1] if args.batch == 0 else bufs[-1][0]
-        out["residual_probe"] = residual_probe(sol, host, last)
+        # ---- parity at full size: vector residual probe of the last timed factor ---------------
+        out["residual_probe"] = residual_probe(sol, main_run.hosts[0], main_run.last)
+        out["residual_probe_kind"] = "vector probe ||L(L^T x) - A x|| / ||A x||, 2 random x (not the Frobenius norm)"
         st = sol.planStats()
         out["plan"] = {k: st[k] for k in ("num_launches", "num_levels", "num_panels",
                                           "num_upd_tasks", "num_atomic_upd_tasks")}
-        out["analysis_s"] = round(t_sym, 3)
-
-        # ---- roofline of the dominant kernel, HIP events on the execution stream ------------
+        out["analysis_s"] = round(main_run.t_sym, 3)
         if not args.no_profile:
-            work = A_dev.clone()
-            prof = sol.factorProfiled(work)
-            tot = sum(v[0] for v in prof.values())
-            out["kernel_ms"] = {k: [round(v[0], 4), v[1]] for k, v in prof.items()}
-            # algorithmic work of every kernel class, from the plan (DESIGN.md "Kernels"):
-            #   update / chain_update: 2 K per lower-trapezoid target element (symmetric update)
-            #   elim_update: the source blocks of every pair read once (the operands of the
-            #     products) + one read-modify-write of every target element
-            #   elim_factor: every element of the eliminated columns read and written once
-            pair_src_bytes = 8.0 * 2.0 * st["elim_pair_operand_elems"]
-            work_of = {
-                "update": ("updateTileBulk|updateTile<%s>" % DT, "mfma", st["upd_flops"] - st["upd_flops_direct"]),
-                # (one-panel levels: update tiles + the next panel's potrf, and inside an outer block
-                #  also the panel's trsm, in one launch)
-                "chain_update": ("chainStep|updateTileDirectPotrf<%s>" % DT, "mfma",
-                                 st["upd_flops_direct"] + st["trsm_flops_merged"] + st["potrf_flops_fused"]),
-                "elim_update": ("elimGatherMfma<%s>" % DT, "hbm",
-                                pair_src_bytes + 16.0 * st["elim_target_elems"]),
-                "elim_factor": ("elimFactorTiny|elimFactorSmall<%s>" % DT, "hbm", 16.0 * st["elim_col_elems"]),
-                "trsm": ("trsmPanel<%s>" % DT, "mfma", st["trsm_flops"] - st["trsm_flops_merged"]),
-                "potrf": ("potrfPanel<%s>" % DT, "mfma", st["potrf_flops"] - st["potrf_flops_fused"]),
-            }
-            # dominant class = largest event time; classes within 5 % of it count as tied and the
-            # one carrying more of the algorithmic work wins (all classes are in kernel_rates)
-            tmax = max(v[0] for v in prof.values())
-            share = {k: work_of[k][2] / (flops if work_of[k][1] == "mfma" else 16.0 * sol.dataSize())
-                     for k in prof}
-            dom = max((k for k in prof if prof[k][0] >= 0.95 * tmax), key=lambda k: share[k])
-            ms, launches = prof[dom]
-            kname, bound, amount = work_of[dom]
-            rate = amount / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9)
-            peak = PEAK_FP64_MFMA_TFLOPS if bound == "mfma" else PEAK_HBM_GBS
-            roof = {"kernel": kname, "bound": bound, "achieved": round(rate, 3), "peak": peak,
-                    "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-                    "frac": round(rate / peak, 4), "traffic": None, "launches": launches,
-                    "avg_launch_ms": round(ms / max(launches, 1), 5),
-                    ("algorithmic_flops_per_launch" if bound == "mfma"
-                     else "algorithmic_bytes_per_launch"): amount / max(launches, 1),
-                    "share_of_factor": round(ms / tot, 3)}
-            # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
-            # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported), same workload
-            try:
-                with open(os.path.join(HERE, "profiles", "pmc_traffic.json")) as f:
-                    pmc = json.load(f)
-                names = kname.split("<")[0].split("|")
-                ents = [pmc.get(args.workload, {}).get(n) for n in names]
-                ents = [e for e in ents if e]
-                if ents:
-                    ent = {k: sum(e[k] for e in ents) for k in ("fetch_KB_per_factor", "write_KB_per_factor")}
-                    roof["traffic"] = (2.0 * ent["fetch_KB_per_factor"] +
-                                       ent["write_KB_per_factor"]) * 1024.0 / max(launches, 1)
-                    roof["traffic_source"] = pmc.get("_source", "profiles/pmc_traffic.json")
-            except (OSError, ValueError):
-                pass
-            if bound == "mfma":
-                # what back-to-back fp64 MFMAs sustain on this very GPU (register-only probe)
-                probe = B.probe_mfma_f64_tflops()
-                roof["measured_mfma_probe"] = round(probe, 2)
-                roof["frac_of_probe"] = round(rate / probe, 4)
-            out["roofline"] = roof
-            # every kernel class, for the record
-            sec = {}
-            for k, (nm, bd, amt) in work_of.items():
-                if prof[k][0] > 0 and amt > 0:
-                    r = amt / (prof[k][0] * 1e-3) / (1e12 if bd == "mfma" else 1e9)
-                    sec[k] = {"kernel": nm, "rate": round(r, 3 if bd == "mfma" else 1),
-                              "unit": "TFLOP/s" if bd == "mfma" else "GB/s"}
-            out["kernel_rates"] = sec
-            # whole-factor roofline: max(flops / MFMA peak, compulsory bytes / HBM peak)
-            t_roof = max(flops / (PEAK_FP64_MFMA_TFLOPS * 1e12),
-                         16.0 * sol.dataSize() / (PEAK_HBM_GBS * 1e9))
-            out["factor_roofline_frac"] = round(t_roof / (ms_per_step * 1e-3), 4)
-
-        # ---- device solve() on the last factor (not part of the metric; BENCHMARK_RESULTS.md of the
-        #      reference reports solve-1 timings separately too)
+            out.update(roofline_block(sol, main_run.A_devs[0], main_run.flops, res["ms_per_step"]
+                                      if not batched else res["ms_per_step"] / max(1, main_run.q1 - main_run.q0),
+                                      workload))
+        # ---- device solve() on the last factor (not part of the metric)
         try:
+            order = main_run.order
             rhs = torch.from_numpy(T.random_data(order, -1, 1, 38)).to(device)
             work = rhs.clone()
-            sol.solve(last, work, order, 1)  # warm-up
+            sol.solve(main_run.last, work, order, 1)  # warm-up
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             work.copy_(rhs)
-            sol.solve(last, work, order, 1)
+            sol.solve(main_run.last, work, order, 1)
             torch.cuda.synchronize(device)
             out["solve1_ms"] = round(1e3 * (time.perf_counter() - t0), 3)
         except Exception as e:
             out["solve1_ms"] = "error: %s" % e
 
-        # ---- CPU baseline: the BackendFast restatement (oracle/blas_factor.c) on host cores --
+    # ---- extra workloads (every rank takes part in the collective ones) ------------------------
+    if not args.no_extras and args.workload is None and args.batch is None and not args.bal_file:
+        try:
+            if world == 1:
+                r = Runner(ctx, "grid82", 64, True)
+                e = r.run(3, 1)
+                e.update({"workload": "64 x GRID 82x82 conn 2 x 3 (BASELINE configs[3]), one batched "
+                                      "factor() per step", "n_gpus": 1, "scaling": "strong"})
+                out["batched"] = e
+                del r
+                torch.cuda.empty_cache()
+                out["c5"] = c5_block(device)
+            else:
+                r = Runner(ctx, "bal871", world, False)
+                e = r.run(3, 1)
+                e.update({"workload": "BAL-871 stand-in, one matrix per GPU", "scaling": "weak"})
+                out["bal871_replicas"] = e
+                del r
+                torch.cuda.empty_cache()
+                if rank == 0:   # the 1-GPU point of the batched curve, measured in this very job
+                    r1 = Runner(ctx, "grid82", 64, True, participate=False)
+                    e1 = r1.run(3, 1, sync_ranks=False)
+                    e1.update({"workload": "all 64 matrices on rank 0 alone", "n_gpus": 1})
+                    out["batched_1gpu"] = e1
+                    out["scaling_efficiency_vs_batched_1gpu"] = round(
+                        out["value"] / (world * e1["value"]), 4)
+                if dist:
+                    dist.barrier()
+        except Exception as e:  # extras never fail the bench
+            out["extras_error"] = repr(e)
+
+    if rank == 0:
+        # ---- CPU baseline: the BackendFast restatement (oracle/blas_factor.c) on host cores ----
         if world == 1 and not args.no_cpu_baseline:
             try:
-                from oracle import cref
-                # small problems run slower on a wide BLAS team (per-call fork/join on tiny fronts):
-                # about one thread per 0.5 GF of work, all cores for the headline workload
-                cores = max(1, min(os.cpu_count() or 1, int(flops / 0.5e9)))
-                _, blas_desc = cref.blas_lib(cores)
-                hostA = host.copy()
-                skh = cref.SkelHandle(sol.skel())
-                t0 = time.perf_counter()
-                elim_s = cref.blas_factor(skh, hostA, sol.sparseEliminationRanges(), cores)
-                dt = time.perf_counter() - t0
-                out["cpu_baseline"] = {
-                    "value": round(flops / dt / 1e9, 2), "unit": "GF/s", "cores": cores,
-                    "kind": "port", "seconds": round(dt, 3), "elim_seconds": round(elim_s, 3),
-                    "sample": "1 full factor() of the same matrix (same plan, same data)",
-                    "blas": blas_desc}
-                out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+                out["cpu_baseline"] = cpu_baseline(sol, main_run.hosts[0], main_run.flops,
+                                                   out["value"] / total_batch)
             except Exception as e:  # the baseline is a report, never a reason to fail the bench
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out))

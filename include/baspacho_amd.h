@@ -130,6 +130,15 @@ int bsp_factor_from_f32(bsp_solver* s, float* dev_data, int64_t span_index);
    in the reference's call order (Solver.cpp:164-219) instead of the fused path */
 int bsp_factor_per_op_f64(bsp_solver* s, double* dev_data);
 int bsp_factor_per_op_f32(bsp_solver* s, float* dev_data);
+/* Solver::enableStats + the per-op stat callbacks of the reference (Utils.h:100-119) as bench -Z
+   uses them (benchmarking/Bench.cpp:72-124): while on, every potrf / trsm / saveSyrkGemm / assemble
+   call of the per-op boundary is timed (HIP events around its launches) and kept as one sample
+   {size0, size1, size2, seconds}: which = 0 potrf {n}, 1 trsm {n, k}, 2 syrk/gemm {m, n, k},
+   3 assemble {blockRows, blockCols}.  bsp_read_op_stats copies up to `capacity` samples (4 doubles
+   each) and reports how many exist.  Input of the cost-model fit (tools/fit_computation_model.py,
+   examples/OptimizeCompModel.cpp:64-275 in the reference). */
+int bsp_collect_op_stats(bsp_solver* s, int32_t on);
+int bsp_read_op_stats(bsp_solver* s, int32_t which, double* out, int64_t capacity, int64_t* count);
 /* TESTING: while on, factor / solve* / addMvFrom of this solver are driven op by op through the
    reference's NumericCtx / SolveCtx boundary (MatOps.h:113-184) in the reference's call order
    (Solver.cpp:164-219, 270-397, 400-449) -- sparseElimSolveL/Lt, symm, solveL, gemv, assembleVec,
@@ -179,6 +188,29 @@ int bsp_solve_batched_f64(bsp_solver* s, const double* const* dev_mats, double* 
                           int32_t batch, int64_t stride, int32_t nrhs, int32_t which);
 int bsp_solve_batched_f32(bsp_solver* s, const float* const* dev_mats, float* const* dev_vecs,
                           int32_t batch, int64_t stride, int32_t nrhs, int32_t which);
+
+/* ---- BAL caller pipeline on the device (benchmarking/BaAtLargeOptimizer.cpp:100-131 computeStep,
+   with the 9-parameter cameras of a BAL file: Rodrigues rotation, translation, f, k1, k2).  All
+   pointers are device memory.
+   bsp_bal_linearize: reprojection residual res[2 nObs] and Jacobians Jc[nObs][2][9] (camera),
+   Jp[nObs][2][3] (point) of every observation (obs_xy[nObs][2], cams[nCams][9], pts[nPts][3]).
+   bsp_bal_fill_hessian: data += J^T J through Solver::deviceAccessor() -- accessor.diagBlock(pt),
+   accessor.diagBlock(cam), accessor.block(cam, pt) per observation -- grad += J^T r (may be NULL),
+   then the LM damping d <- d (1 + lambda) + 1e-3 lambda of every diagonal entry.  The caller zeroes
+   data / grad first; parameters are numbered points first, cameras after (BaAtLargeBench.cpp:50-57).
+   dbg (may be NULL): 7 int64 per observation = what the accessor returned on the device (block
+   offset, stride, flipped; camera diag offset, stride; point diag offset, stride). */
+int bsp_bal_linearize_f64(int64_t num_obs, const int64_t* obs_cam, const int64_t* obs_pt,
+                          const double* obs_xy, const double* cams, const double* pts, double* res,
+                          double* Jc, double* Jp, void* stream);
+int bsp_bal_fill_hessian_f64(bsp_solver* s, int64_t num_pts, int64_t num_cams, int64_t num_obs,
+                             const int64_t* obs_cam, const int64_t* obs_pt, const double* Jc,
+                             const double* Jp, const double* res, double lambda, double* dev_data,
+                             double* dev_grad, int64_t* dev_dbg, void* stream);
+int bsp_bal_fill_hessian_f32(bsp_solver* s, int64_t num_pts, int64_t num_cams, int64_t num_obs,
+                             const int64_t* obs_cam, const int64_t* obs_pt, const double* Jc,
+                             const double* Jp, const double* res, float lambda, float* dev_data,
+                             float* dev_grad, int64_t* dev_dbg, void* stream);
 
 /* ---- measurement helpers (no reference counterpart; Solver::printStats is the analogue) */
 /* algorithmic flops of a full factor: sum over lumps n^3/3 + r n^2 + r^2 n */

@@ -70,3 +70,12 @@ def test_shard_batch_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [e - b for b, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_runner_shards_a_batch_world2_metadata():
+    """the shapes bench.py --gpus N uses: a batch of 64 over 1/2/4/8 ranks is 64/N each, and the
+    strong-scaling value counts every matrix once"""
+    from baspacho_amd.distributed import shard_batch
+    for world in (1, 2, 4, 8):
+        assert [shard_batch(64, world, r)[1] - shard_batch(64, world, r)[0] for r in range(world)] == \
+            [64 // world] * world
