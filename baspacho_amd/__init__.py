@@ -49,7 +49,7 @@ class _CPlanStats(ctypes.Structure):
                [(n, ctypes.c_int64) for n in
                 ["num_launches", "num_levels", "num_panels", "num_segs", "num_upd_tasks",
                  "num_trsm_tasks", "chain_tab_entries", "max_panels_in_level",
-                 "num_atomic_upd_tasks"]]
+                 "num_atomic_upd_tasks", "num_gather_groups"]]
 
 
 @dataclass

@@ -455,6 +455,7 @@ int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out) {
   out->chain_tab_entries = p.chainTabEntries;
   out->max_panels_in_level = p.maxPanelsInLevel;
   out->num_atomic_upd_tasks = p.numAtomicUpdTasks;
+  out->num_gather_groups = p.numGatherGroups;
   BSP_CATCH
 }
 

@@ -275,11 +275,13 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_EARLY_FORK")) earlyFork = e[0] != '0';
     if (const char* e = std::getenv("BSP_MERGED_BLOCK_LAST")) mergedBlockLast = e[0] != '0';
     if (const char* e = std::getenv("BSP_BULK_KERNEL")) bulkKernel = e[0] != '0';
+    if (const char* e = std::getenv("BSP_ELIM_OVERLAP")) elimOverlap = e[0] != '0';
   }
 
   virtual ~HipSymbolicCtx() override {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
+    if (elim) (void)hipStreamDestroy(elim);
   }
 
   virtual void setSparseElimRanges(const vector<int64_t>& ranges) override {
@@ -383,6 +385,14 @@ struct HipSymbolicCtx : SymbolicCtx {
     }
     return side;
   }
+  hipStream_t elimStream() {
+    if (!elim) {
+      int least = 0, greatest = 0;
+      hipCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      hipCHECK(hipStreamCreateWithPriority(&elim, hipStreamNonBlocking, least));
+    }
+    return elim;
+  }
   hipEvent_t eventFromPool() {
     if (nextEvent == events.size()) {
       hipEvent_t e;
@@ -402,7 +412,8 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool lookaheadEnabled = true;
   unsigned bulkExtraLds = 6 * 1024;
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr, elim = nullptr;
+  bool elimOverlap = false;    // sparse-elimination update overlapped with the dense phase (opt-in: BSP_ELIM_OVERLAP=1)
   bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
   bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
@@ -463,12 +474,25 @@ struct HipNumericCtx : NumericCtx<T> {
 
   // One level = potrf -> trsm -> update on the execution stream.  Deferred (lookahead) tiles go to
   // the side stream after the level's trsm and are joined back by events where the plan says so.
+  // (profiled runs serialise the launches on the execution stream, unless the in-situ mode asks
+  //  for the real multi-stream schedule with every launch timed on the stream it runs on)
+  bool lookaheadOn() const {
+    return (sym.profile == nullptr || sym.profileInSitu) && sym.lookaheadEnabled;
+  }
+
+  // gatherDone (overlapped elimination, launchElim): one event per gather group, recorded on the
+  // elimination stream; levels name the group they need (LevelRange::waitGather / defWaitGather*)
   void launchLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::DataRef<BT> ref,
-                    LaunchTimer& timer) {
+                    LaunchTimer& timer, const vector<hipEvent_t>* gatherDone = nullptr) {
     const dim3 gy(1, (unsigned)batchSize, 1);
-    // (profiled runs serialise the launches on the execution stream, unless the in-situ mode asks
-    //  for the real two-stream schedule with every launch timed on the stream it runs on)
-    const bool lookahead = (sym.profile == nullptr || sym.profileInSitu) && sym.lookaheadEnabled;
+    const bool lookahead = lookaheadOn();
+    int waitedMain = -1, waitedSide = -1;  // gather groups the two streams already wait for
+    auto waitGather = [&](hipStream_t st, int group, int& waited) {
+      if (!gatherDone || group <= waited) return;
+      group = std::min<int>(group, (int)gatherDone->size() - 1);
+      if (group > waited) hipCHECK(hipStreamWaitEvent(st, (*gatherDone)[group], 0));
+      waited = group;
+    };
     vector<hipEvent_t> defDone(levels.size(), nullptr);
     bool potrfFused = false;  // this level's potrf ran inside the previous level's update launch
     bool sideUsed = false;
@@ -490,6 +514,7 @@ struct HipNumericCtx : NumericCtx<T> {
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
       const bool direct = sym.directChain && lr.directPanel >= 0;
+      waitGather(sym.stream, lr.waitGather, waitedMain);
       const int slot = dinvSlot;
       dinvSlot ^= 1;
       BT* dinvCur = dinvBase + slot * hipk::kDinvSlot;
@@ -579,6 +604,7 @@ struct HipNumericCtx : NumericCtx<T> {
         // the side stream keeps running them while the chain goes on, and the next block's
         // deferred tiles queue up right behind
         if (lr.defMid > lr.defBegin) {
+          waitGather(sym.sideStream(), lr.defWaitGatherMid, waitedSide);
           timer.begin(kProfUpdate, sym.sideStream());
           launchUpdate(plan, lr.defBegin, lr.defMid, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
           timer.end();
@@ -586,6 +612,7 @@ struct HipNumericCtx : NumericCtx<T> {
         defDone[li] = sym.eventFromPool();
         hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
         if (lr.defEnd > lr.defMid) {
+          waitGather(sym.sideStream(), lr.defWaitGatherEnd, waitedSide);
           timer.begin(kProfUpdate, sym.sideStream());
           launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
           timer.end();
@@ -642,10 +669,12 @@ struct HipNumericCtx : NumericCtx<T> {
       hipCHECK(hipEventRecord(join, sym.sideStream()));
       hipCHECK(hipStreamWaitEvent(sym.stream, join, 0));
     }
+    // (and everything on the elimination stream)
+    if (gatherDone && !gatherDone->empty()) waitGather(sym.stream, (int)gatherDone->size() - 1, waitedMain);
   }
 
   void launchElim(DevPlan& plan, const ElimRangePlan& er, hipk::DataRef<BT> ref,
-                  LaunchTimer& timer) {
+                  LaunchTimer& timer, vector<hipEvent_t>* gatherDoneOut = nullptr) {
     hipk::SkelDev sk = sym.skelDev();
     const unsigned gy = (unsigned)batchSize;
     const int64_t nLumps = er.lumpEnd - er.lumpBegin;
@@ -685,6 +714,26 @@ struct HipNumericCtx : NumericCtx<T> {
           plan.elimPairOffJ.as<uint32_t>(), plan.elimPairOffI.as<uint32_t>(),
           plan.elimPairSlot.as<uint16_t>(), ref, (uint32_t)(sym.skel.dataSize() - 1));
       timer.end();
+    } else if (er.useGather && er.overlapLump >= 0 && lookaheadOn() && sym.elimOverlap &&
+               gatherDoneOut != nullptr) {
+      // OVERLAPPED with the dense phase: the groups (items by outer block of the target column)
+      // run in order on a stream of their own; the caller hands the events to launchLevels
+      hipEvent_t fork = sym.eventFromPool();
+      hipCHECK(hipEventRecord(fork, sym.stream));
+      hipCHECK(hipStreamWaitEvent(sym.elimStream(), fork, 0));
+      for (size_t q = 0; q + 1 < er.groupItem.size(); q++) {
+        const int64_t n = er.groupItem[q + 1] - er.groupItem[q];
+        if (n > 0) {
+          timer.begin(kProfElimUpdate, sym.elimStream());
+          hipk::elimGatherMfma<BT><<<dim3((unsigned)((n + 3) / 4), gy), 256, 0, sym.elimStream()>>>(
+              plan.elimItems.as<ElimGatherItem>() + er.groupItem[q], plan.elimPairOffJ.as<uint32_t>(),
+              plan.elimPairOffI.as<uint32_t>(), ref, (int)n);
+          timer.end();
+        }
+        hipEvent_t done = sym.eventFromPool();
+        hipCHECK(hipEventRecord(done, sym.elimStream()));
+        gatherDoneOut->push_back(done);
+      }
     } else if (er.useGather) {
       const int64_t nItems = er.itemEnd - er.itemBegin;
       if (nItems > 0) {
@@ -725,8 +774,11 @@ struct HipNumericCtx : NumericCtx<T> {
     hipk::DataRef<BT> ref = makeRef(data);
     LaunchTimer timer(sym.stream, sym.profile);
     sym.resetEventPool();
-    for (const ElimRangePlan& er : plan.host.elimRanges) launchElim(plan, er, ref, timer);
-    launchLevels(plan, plan.host.levels, ref, timer);
+    vector<hipEvent_t> gatherDone;  // filled when the last range's update overlaps the dense phase
+    for (const ElimRangePlan& er : plan.host.elimRanges) {
+      launchElim(plan, er, ref, timer, &er == &plan.host.elimRanges.back() ? &gatherDone : nullptr);
+    }
+    launchLevels(plan, plan.host.levels, ref, timer, gatherDone.empty() ? nullptr : &gatherDone);
     hipCHECK(hipGetLastError());
     timer.finish();
   }
@@ -1369,6 +1421,9 @@ HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t up
   int64_t atomicTasks = 0;
   for (auto& t : p.updTasks) atomicTasks += t.atomic;
   s.numAtomicUpdTasks = atomicTasks;
+  if (!p.elimRanges.empty() && p.elimRanges.back().overlapLump >= 0 && h->elimOverlap) {
+    s.numGatherGroups = (int64_t)p.elimRanges.back().groupItem.size() - 1;
+  }
   return s;
 }
 

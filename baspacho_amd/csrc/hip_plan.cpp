@@ -60,8 +60,13 @@ void sortBuckets(V& v, const std::vector<int64_t>& ptr, Less less) {
   for (auto& th : pool) th.join();
 }
 
-void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, ElimRangePlan& er) {
+// overlapLump >= 0: the caller would like to overlap this range's update with the factorization of
+// that (single, wide) dense lump; granted -- er.overlapLump set, items grouped by target column
+// block -- when every target lies in it and every item is an MFMA item.
+void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, ElimRangePlan& er,
+                     int64_t overlapLump = -1) {
   er.useGather = false;
+  er.overlapLump = -1;
   if (sk.dataSize() >= (int64_t(1) << 32)) return;
   const bool timing = std::getenv("BSP_TIMING") != nullptr;
   auto tic = std::chrono::steady_clock::now();
@@ -94,6 +99,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
         const int64_t si = sk.chainRowSpan[i];
         const int64_t siSize = sk.spanStart[si + 1] - sk.spanStart[si];
         mapTarget(sk.spanToLump[si]);
+        if (sk.spanToLump[si] != overlapLump) overlapLump = -1;
         for (int64_t j = i; j < cEnd; j++) {
           const int64_t sj = sk.chainRowSpan[j];
           if ((sk.spanStart[sj + 1] - sk.spanStart[sj]) * siSize > kGatherMaxElems) return false;
@@ -278,6 +284,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   er.itemBegin = (int64_t)plan.elimItems.size();
   vector<int64_t> itemRowTag;  // target chain of every emitted item
   vector<int32_t> itemChunk;   // source-data chunk of every emitted item
+  vector<int32_t> itemColBlock;  // outer block of the target column inside its lump
   sortBuckets(sorted, bucketPtr, [](const Pair& x, const Pair& y) {
     return x.si != y.si ? x.si < y.si : x.width < y.width;
   });
@@ -322,6 +329,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
         plan.elimItems.push_back(it);
         itemRowTag.push_back(c);
         itemChunk.push_back((int32_t)chunkOfU);
+        itemColBlock.push_back((int32_t)(sk.spanOffsetInLump[si] / kOuterWidth));
         u = u1;
       }
       if (plan.elimItems.size() - firstItem > 1) {
@@ -337,6 +345,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   {
     vector<ElimGatherItem> large, tiny, wide;
     vector<int64_t> tagL;
+    vector<int32_t> cbL;
     for (int64_t k = er.itemBegin; k < er.itemEnd; k++) {
       const ElimGatherItem& it = plan.elimItems[k];
       if (int(it.rows) * int(it.cols) <= 16) {
@@ -346,6 +355,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
       } else {
         large.push_back(it);
         tagL.push_back(itemRowTag[k - er.itemBegin]);
+        cbL.push_back(itemColBlock[k - er.itemBegin]);
       }
     }
     auto dst = plan.elimItems.begin() + er.itemBegin;
@@ -353,6 +363,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
     dst = std::copy(tiny.begin(), tiny.end(), dst);
     std::copy(wide.begin(), wide.end(), dst);
     itemRowTag = tagL;
+    itemColBlock = cbL;
     itemChunk.assign(large.size(), 0);
     er.itemEnd = er.itemBegin + (int64_t)large.size();
     er.tinyBegin = er.itemEnd;
@@ -360,56 +371,88 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
     er.ldsBegin = er.tinyEnd;
     er.ldsEnd = er.ldsBegin + (int64_t)wide.size();
   }
-  // XCD-aware order (speed only).  A workgroup takes 4 consecutive items and workgroup b runs on
-  // XCD b % 8, each XCD with its own 4 MB L2.  All items of one target ROW (same sj) read the same
-  // B_j source blocks, so a row is handed to ONE XCD (row r -> XCD r % 8, rows balance the load
-  // statistically) instead of being sprayed over all eight L2s (measured L2 hit rate 26 %).
-  {
+  // OVERLAP groups: items by outer block of the target column, a few blocks per group -- early
+  // groups small (the dense chain waits for the first one), later ones larger
+  vector<int64_t> groupBounds = {0, er.itemEnd - er.itemBegin};  // relative item indices
+  if (overlapLump >= 0 && er.tinyEnd == er.tinyBegin && er.ldsEnd == er.ldsBegin &&
+      er.itemEnd - er.itemBegin >= 4096) {
     const int64_t nItems = er.itemEnd - er.itemBegin;
-    if (nItems >= 512) {
-      vector<ElimGatherItem> tmp(plan.elimItems.begin() + er.itemBegin, plan.elimItems.end());
-      int32_t nChunks = 0;
-      for (int32_t ch : itemChunk) nChunks = std::max(nChunks, ch + 1);
-      int64_t out = er.itemBegin;
-      // Chunk-major: the source columns are visited in slices of kGatherChunkElems values, so that
-      // a slice (re-read ~11x by the pairs that use it) stays resident in the 256 MB Infinity
-      // Cache instead of streaming the whole elimination range from HBM for every target row.
-      for (int32_t ch = 0; ch < nChunks; ch++) {
-        vector<vector<int64_t>> perXcd(8);
-        int64_t row = -1, rowKey = -1;
-        for (int64_t k = 0; k < nItems; k++) {
-          if (itemChunk[k] != ch) continue;
-          if (itemRowTag[k] != rowKey) {
-            rowKey = itemRowTag[k];
-            row++;
+    const int64_t width = sk.lumpStart[overlapLump + 1] - sk.lumpStart[overlapLump];
+    const int32_t numBlocks = (int32_t)((width + kOuterWidth - 1) / kOuterWidth);
+    vector<int32_t> colBounds = {0};
+    for (int32_t step = 2; colBounds.back() < numBlocks; step += (colBounds.size() % 2 == 0)) {
+      colBounds.push_back(std::min<int32_t>(numBlocks, colBounds.back() + step));
+    }
+    auto groupOf = [&](int32_t cb) {
+      return (int32_t)(std::upper_bound(colBounds.begin(), colBounds.end(), cb) - colBounds.begin()) - 1;
+    };
+    vector<int64_t> order(nItems);
+    for (int64_t k = 0; k < nItems; k++) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+      return groupOf(itemColBlock[x]) < groupOf(itemColBlock[y]);
+    });
+    vector<ElimGatherItem> tmp(plan.elimItems.begin() + er.itemBegin, plan.elimItems.begin() + er.itemEnd);
+    vector<int64_t> tag2(nItems);
+    const int32_t nGroups = (int32_t)colBounds.size() - 1;
+    groupBounds.assign(nGroups + 1, nItems);
+    er.groupPairs.assign(nGroups, 0.0);
+    int32_t cur = -1;
+    for (int64_t k = 0; k < nItems; k++) {
+      const int32_t gq = groupOf(itemColBlock[order[k]]);
+      while (cur < gq) groupBounds[++cur] = k;
+      plan.elimItems[er.itemBegin + k] = tmp[order[k]];
+      tag2[k] = itemRowTag[order[k]];
+      er.groupPairs[gq] += double(tmp[order[k]].pairEnd - tmp[order[k]].pairBegin);
+    }
+    while (cur < nGroups) groupBounds[++cur] = nItems;
+    itemRowTag = tag2;
+    er.overlapLump = overlapLump;
+    er.groupColBlock = colBounds;
+    er.groupItem.resize(nGroups + 1);
+    for (int32_t q = 0; q <= nGroups; q++) er.groupItem[q] = er.itemBegin + groupBounds[q];
+  }
+  // XCD-aware order (speed only), inside every group.  A workgroup takes 4 consecutive items and
+  // workgroup b runs on XCD b % 8, each XCD with its own 4 MB L2.  All items of one target ROW (same
+  // sj) read the same B_j source blocks, so a row is handed to ONE XCD (row r -> XCD r % 8, rows
+  // balance the load statistically) instead of being sprayed over all eight L2s (measured L2 hit
+  // rate 26 %).
+  for (size_t gq = 0; gq + 1 < groupBounds.size(); gq++) {
+    const int64_t g0 = groupBounds[gq], g1 = groupBounds[gq + 1];
+    const int64_t nItems = g1 - g0;
+    if (nItems < 512) continue;
+    vector<ElimGatherItem> tmp(plan.elimItems.begin() + er.itemBegin + g0,
+                               plan.elimItems.begin() + er.itemBegin + g1);
+    vector<vector<int64_t>> perXcd(8);
+    int64_t row = -1, rowKey = -1;
+    for (int64_t k = 0; k < nItems; k++) {
+      if (itemRowTag[g0 + k] != rowKey) {
+        rowKey = itemRowTag[g0 + k];
+        row++;
+      }
+      perXcd[row % 8].push_back(k);
+    }
+    size_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t remaining = nItems, out = er.itemBegin + g0;
+    while (remaining > 0) {
+      for (int x = 0; x < 8 && remaining > 0; x++) {
+        int src = x;
+        if (cursor[src] >= perXcd[src].size()) {  // this XCD's list is exhausted: steal
+          size_t best = 0;
+          for (int y = 0; y < 8; y++) {
+            const size_t left = perXcd[y].size() - cursor[y];
+            if (left > best) {
+              best = left;
+              src = y;
+            }
           }
-          perXcd[row % 8].push_back(k);
         }
-        size_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int64_t remaining = 0;
-        for (auto& v : perXcd) remaining += (int64_t)v.size();
-        while (remaining > 0) {
-          for (int x = 0; x < 8 && remaining > 0; x++) {
-            int src = x;
-            if (cursor[src] >= perXcd[src].size()) {  // this XCD's list is exhausted: steal
-              size_t best = 0;
-              for (int y = 0; y < 8; y++) {
-                const size_t left = perXcd[y].size() - cursor[y];
-                if (left > best) {
-                  best = left;
-                  src = y;
-                }
-              }
-            }
-            for (int q = 0; q < 4 && cursor[src] < perXcd[src].size(); q++) {
-              plan.elimItems[out++] = tmp[perXcd[src][cursor[src]++]];
-              remaining--;
-            }
-          }
+        for (int q = 0; q < 4 && cursor[src] < perXcd[src].size(); q++) {
+          plan.elimItems[out++] = tmp[perXcd[src][cursor[src]++]];
+          remaining--;
         }
       }
-      BASPACHO_CHECK_EQ(out, er.itemEnd);
     }
+    BASPACHO_CHECK_EQ(out, er.itemBegin + g1);
   }
   lap("sort + emit items");
 }
@@ -443,6 +486,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
 
   // per-panel segment ranges (segments of one panel are contiguous in plan.segs)
   vector<int64_t> panelSegBegin, panelSegEnd;
+  // overlapped elimination (set after the elimination ranges are planned, used by addPanels)
+  const ElimRangePlan* ov = nullptr;
+  vector<int64_t> optionalLimit;  // per outer block b of the overlap lump
 
   // ---- helper: cut a lump into outer blocks and panels; returns number of panels.
   // Segments of a panel: the remaining columns of its outer block (source = the panel, K = nb);
@@ -550,6 +596,8 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                   u.m = (int32_t)std::min<int64_t>(kOuterWidth, n - c * kOuterWidth);
                   u.pad = multi;
                   plan.segs.push_back(u);
+                  plan.segColBlock.resize(plan.segs.size(), -1);
+                  plan.segColBlock.back() = (int32_t)c;
                 }
                 pendingFrom[c] = b + 1;
               };
@@ -561,7 +609,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                 budgetUs -= unitFlops(c) / kBulkFlopsPerUs;
                 pushUnit(c++, 2);
               }
-              for (; c < numBlocks && budgetUs > 0; c++) {
+              const int64_t cLimit = (ov && l == ov->overlapLump && b < (int64_t)optionalLimit.size())
+                                         ? optionalLimit[b] : numBlocks;
+              for (; c < numBlocks && budgetUs > 0 && c <= cLimit; c++) {
                 budgetUs -= unitFlops(c) / kBulkFlopsPerUs;
                 pushUnit(c, 3);
               }
@@ -647,8 +697,46 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       }
     }
     elimBigBuckets.push_back(std::move(big));
-    buildElimGather(sk, plan, er);
+    // candidate for overlapping this range's update with the dense phase: it is the last range
+    // before the dense part, which is ONE wide lump inside the planned interval, and the range has
+    // no wide lumps of its own (buildElimGather checks that every target lies in that lump)
+    int64_t overlapLump = -1;
+    {
+      const int64_t denseBegin0 = std::max(startLump, denseFrom);
+      // (opt-in: measured on BAL-871 the update takes 2.4x as long beside the dense kernels and
+      //  slows the chain by as much as it saves, 7.85 against 7.63 ms -- DESIGN.md "tried")
+      const char* e = std::getenv("BSP_ELIM_OVERLAP");
+      const bool enabled = e && e[0] == '1';
+      if (enabled && re == denseFrom && denseBegin0 == denseFrom && upToLump == denseFrom + 1 &&
+          upToLump <= nLumps && elimBigBuckets.back().empty() &&
+          sk.lumpStart[denseFrom + 1] - sk.lumpStart[denseFrom] >= 6 * kOuterWidth) {
+        overlapLump = denseFrom;
+      }
+    }
+    buildElimGather(sk, plan, er, overlapLump);
     plan.elimRanges.push_back(std::move(er));
+  }
+  // overlapped elimination: which column blocks of the dense lump may receive OPTIONAL lookahead
+  // units forked at block b -- only those whose gather group is expected to be complete by then
+  // (plan-time estimate; events enforce the order, this only keeps the side stream from stalling)
+  ov = (!plan.elimRanges.empty() && plan.elimRanges.back().overlapLump >= 0)
+           ? &plan.elimRanges.back() : nullptr;
+  if (ov) {
+    constexpr double kGatherPairsPerUs = 5.5e3;  // beside the dense kernels (8.9e3 alone)
+    const LumpCols g = lumpCols(sk, ov->overlapLump);
+    const int64_t numBlocks = (g.width + kOuterWidth - 1) / kOuterWidth;
+    vector<double> groupDone(ov->groupPairs.size());
+    double t = 0;
+    for (size_t q = 0; q < groupDone.size(); q++) groupDone[q] = (t += ov->groupPairs[q] / kGatherPairsPerUs);
+    double tBlock = groupDone[ov->groupOfColBlock(std::min<int64_t>(1, numBlocks - 1))];
+    optionalLimit.assign(numBlocks, numBlocks);
+    for (int64_t b = 0; b < numBlocks; b++) {
+      const double rows = double(g.width - (b + 1) * kOuterWidth + g.rowsBelow);
+      tBlock += 118.0 + 0.012 * std::max(rows, 0.0);  // units forked at block b start about here
+      int64_t lim = b + 2;
+      while (lim + 1 < numBlocks && groupDone[ov->groupOfColBlock(lim + 1)] <= tBlock) lim++;
+      optionalLimit[b] = lim;
+    }
   }
 
   // ---- dense lumps
@@ -721,6 +809,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                          buckets[bi + 1].size() == 1 &&
                          plan.panels[buckets[bi + 1][0].panel].lump == plan.panels[bucket[0].panel].lump;
       vector<UpdTask> deferred, deferredLate;
+      int32_t maxCbMid = -1, maxCbLate = -1;  // furthest target column block of the deferred units
       int32_t nowSegs = 0, nowSeg = -1;  // segments with non-deferred 64x64 tiles in this level
       bool nowPlain = true;              // ... all intra-lump, non-atomic, untouched order
       // how many panels of this level hit each target lump
@@ -746,18 +835,39 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           }
           bool anyDeferred = false;
           const int32_t step = kTile;
-          for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += step) {
-            const bool defer = sd.outer >= 2;  // lookahead units: every tile goes to the side stream
-            for (int32_t rT = cT; rT < sr.rowsBelow; rT += step) {
-              const UpdTask t{(int32_t)s, rT, cT, atomic};
-              if (defer) {
-                const bool late = sd.outer == 3;
-                (late ? deferredLate : deferred).push_back(t);
-                anyDeferred = true;
-              } else {
-                plan.updTasks.push_back(t);
+          const bool defer = sd.outer >= 2;  // lookahead units: every tile goes to the side stream
+          if (defer) {
+            // ROW-tile-major: the (up to four) column tiles of one row tile are neighbours in the
+            // list, so the XCD that gets this stretch of the list (xcdOrder) fetches the row
+            // operand A_i once for all of them and keeps the unit's few column operands B_j (<= 0.5
+            // MB) in its L2.  Column-major order handed the column tiles of a row to four different
+            // XCDs, i.e. every 128 KB row operand crossed the fabric four times.
+            const bool late = sd.outer == 3;
+            vector<UpdTask>& dst = late ? deferredLate : deferred;
+            static const bool rowMajor = [] {
+              const char* e = std::getenv("BSP_BULK_ROW_MAJOR");
+              return !(e && e[0] == '0');
+            }();
+            if (rowMajor) {
+              for (int32_t rT = sd.q0; rT < sr.rowsBelow; rT += step) {
+                for (int32_t cT = sd.q0; cT < sd.q0 + sd.m && cT <= rT; cT += step) {
+                  dst.push_back(UpdTask{(int32_t)s, rT, cT, atomic});
+                }
               }
-              if (!defer) {
+            } else {
+              for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += step) {
+                for (int32_t rT = cT; rT < sr.rowsBelow; rT += step) {
+                  dst.push_back(UpdTask{(int32_t)s, rT, cT, atomic});
+                }
+              }
+            }
+            anyDeferred = true;
+            const int32_t cb = s < (int64_t)plan.segColBlock.size() ? plan.segColBlock[s] : -1;
+            (late ? maxCbLate : maxCbMid) = std::max(late ? maxCbLate : maxCbMid, cb);
+          } else {
+            for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += step) {
+              for (int32_t rT = cT; rT < sr.rowsBelow; rT += step) {
+                plan.updTasks.push_back(UpdTask{(int32_t)s, rT, cT, atomic});
                 if (nowSeg != (int32_t)s) nowSegs++;
                 nowSeg = (int32_t)s;
                 if (sd.kind != kSegIntra || atomic) nowPlain = false;
@@ -796,6 +906,20 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         }
       };
       if (lr.defEnd > lr.defBegin) plan.hasDeferred = true;
+      if (ov && bucket.size() == 1 && plan.panels[bucket[0].panel].lump == ov->overlapLump) {
+        // overlapped elimination: the kernels of outer block b touch column blocks b (panel steps)
+        // and b + 1 (the block-wide "now" update); a deferred launch touches up to its furthest unit
+        const PanelDesc& pd = plan.panels[bucket[0].panel];
+        const int64_t c0 = pd.lda - pd.nRest - pd.nb;
+        const int64_t numBlocks = (pd.lda + kOuterWidth - 1) / kOuterWidth;
+        if (c0 % kOuterWidth == 0) {
+          lr.waitGather = ov->groupOfColBlock(std::min<int64_t>(c0 / kOuterWidth + 1, numBlocks - 1));
+        }
+        if (maxCbMid >= 0) lr.defWaitGatherMid = ov->groupOfColBlock(maxCbMid);
+        if (std::max(maxCbMid, maxCbLate) >= 0) {
+          lr.defWaitGatherEnd = ov->groupOfColBlock(std::max(maxCbMid, maxCbLate));
+        }
+      }
       if (bucket.size() == 1) {
         lr.directPanel = bucket[0].panel;
         if (nowSegs == 1 && nowPlain) {

@@ -120,6 +120,10 @@ struct LevelRange {
   int32_t rawNext = 0;
   int64_t waitDefLevel;          // index (within the same level list) of the level whose deferred
                                  // tiles must be complete before this level's update launch; -1
+  // OVERLAPPED ELIMINATION (ElimRangePlan::overlapLump): gather group that must be complete before
+  // this level's first launch on the execution stream / before its two deferred launches on the
+  // side stream (-1: none beyond what was already waited for)
+  int32_t waitGather = -1, defWaitGatherMid = -1, defWaitGatherEnd = -1;
 };
 
 // One work item of the gather-form sparse-elimination update: a target block (sj,si) of the
@@ -189,6 +193,21 @@ struct ElimRangePlan {
   int32_t rowLdsBytes = 0, rowLdsBytesF32 = 0;  // dynamic LDS of the launch (fp64 / fp32)
   int64_t ldsBegin = 0, ldsEnd = 0;   // items wider or taller than 16: LDS-staged kernel (K2g);
                                       // [itemBegin, itemEnd) go to the MFMA kernel (K2m)
+  // OVERLAP with the dense phase.  When every target of the range lies in the plan's single dense
+  // lump `overlapLump` (the bundle-adjustment shape: points eliminated onto one camera supernode),
+  // the MFMA items are grouped by the outer (256-column) block of their target column: group q =
+  // column blocks [groupColBlock[q], groupColBlock[q+1]) = items [groupItem[q], groupItem[q+1]).
+  // The groups run in order on a stream of their own while the dense chain already works on the
+  // column blocks whose groups are complete (LevelRange::waitGather / defWaitGather*).
+  int64_t overlapLump = -1;
+  std::vector<int32_t> groupColBlock;
+  std::vector<int64_t> groupItem;
+  std::vector<double> groupPairs;
+  int32_t groupOfColBlock(int64_t cb) const {
+    int32_t q = 0;
+    while (q + 2 < (int32_t)groupColBlock.size() && groupColBlock[q + 1] <= cb) q++;
+    return q;
+  }
 };
 
 struct HipPlanHost {
@@ -205,6 +224,7 @@ struct HipPlanHost {
   std::vector<PanelDesc> panels;
   std::vector<SrcDesc> srcs;
   std::vector<SegDesc> segs;
+  std::vector<int32_t> segColBlock;  // host only: target column block of a lookahead unit (else -1)
   std::vector<int64_t> chainOffTab;
   std::vector<int32_t> rowChain, rowLocal, rowColOff;  // per chain row of every dense lump
   std::vector<int32_t> rowGlobal;                      // ... and its row index in the full matrix

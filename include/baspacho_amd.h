@@ -225,7 +225,8 @@ typedef struct bsp_plan_stats {
       trsm_flops_merged,       /* ... of which inside chain-step launches (trsm + update + potrf) */
       potrf_flops_fused;       /* ... of which inside the previous level's update launch */
   int64_t num_launches, num_levels, num_panels, num_segs, num_upd_tasks, num_trsm_tasks,
-      chain_tab_entries, max_panels_in_level, num_atomic_upd_tasks;
+      chain_tab_entries, max_panels_in_level, num_atomic_upd_tasks,
+      num_gather_groups; /* > 0: sparse-elimination update split into groups that overlap the dense phase */
 } bsp_plan_stats;
 int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out);
 

@@ -319,6 +319,37 @@ def test_schedule_variants(monkeypatch, knob):
     assert np.linalg.norm((got - ref)[mask]) / np.linalg.norm(ref[mask]) < 1e-12
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_overlapped_elimination(monkeypatch, overlap, dtype):
+    """bundle-adjustment shape with a camera lump of eight outer blocks: the sparse-elimination
+    update runs in column-block groups on its own stream while the dense chain already factors the
+    column blocks whose groups are complete (BSP_ELIM_OVERLAP=0: one launch before the dense
+    phase); both against the oracle, single and batched"""
+    monkeypatch.setenv("BSP_ELIM_OVERLAP", overlap)
+    sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=210, num_pts=24000, band=30, seed=9)
+    sol = B.create_solver(B.Settings(), sizes, ss, [0, 24000])
+    st = sol.planStats()
+    assert sol.numLumps() == 24001, "cameras expected in one lump"
+    assert (st["num_gather_groups"] >= 3) == (overlap == "1")
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    mask = sol.lowerMask()
+    datas = [spd_data(sol, 11 + q, beta_factor=1.2) for q in range(3)]
+    refs = []
+    for d in datas:
+        r = d.copy()
+        cref.factor(sol.skel(), r, sol.sparseEliminationRanges())
+        refs.append(r)
+    for rep in range(3):   # (repeated: the overlap is a race if an event is missing)
+        got = _gpu_factor(sol, datas[0].astype(dtype)).astype(np.float64)
+        assert np.linalg.norm((got - refs[0])[mask]) / np.linalg.norm(refs[0][mask]) < tol, rep
+    devs = [to_dev(d.astype(dtype)) for d in datas]
+    sol.factor(devs)
+    for q in range(3):
+        got = devs[q].cpu().numpy().astype(np.float64)
+        assert np.linalg.norm((got - refs[q])[mask]) / np.linalg.norm(refs[q][mask]) < tol, q
+
+
 @pytest.mark.parametrize("ahead", ["0", "0.6", "100"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_lookahead_units_over_many_outer_blocks(monkeypatch, ahead, dtype):

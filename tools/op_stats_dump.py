@@ -29,6 +29,11 @@ def problems():
     sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=200, num_pts=20000, band=24, seed=3)
     yield "bal", sizes, ss, [0, 20000]
     yield "tridiag", np.full(1200, 3, dtype=np.int64), T.block_tridiagonal(1200), []
+    # wide fronts, so that the flop terms (n^3, n^2 k, m n k) are sampled and not only the fixed costs
+    yield "flat_wide", np.full(6000, 3, dtype=np.int64), T.gen_flat(6000, 1.5e-3, 41), []
+    yield "grid_wide", np.full(110 * 110, 3, dtype=np.int64), T.gen_grid(110, 110, 1.0, 3, 43), []
+    sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=420, num_pts=60000, band=40, seed=5)
+    yield "bal_wide", sizes, ss, [0, 60000]
 
 
 def main():
