@@ -498,11 +498,20 @@ def probe_mfma_f64_tflops():
 
 
 def debug_read_trace(max_records=8192):
-    """in-situ kernel clock records (library built with BSP_KTRACE=1), array [n, 4]"""
-    out = np.zeros((max_records, 4), dtype=np.int64)
+    """in-situ kernel clock records (library built with BSP_KTRACE=1), array [n, 8]"""
+    out = np.zeros((max_records, 8), dtype=np.int64)
     n = ctypes.c_int(0)
     _check(_lib.load().bsp_debug_read_trace(out.ctypes.data_as(ctypes.c_void_p), max_records,
                                             ctypes.byref(n)))
+    return out[:n.value]
+
+
+def debug_read_extents(max_launches=2048):
+    """per chain-step launch [first start, last start, last end, workgroup-0 end] (trace builds)"""
+    out = np.zeros((max_launches, 4), dtype=np.uint64)
+    n = ctypes.c_int(0)
+    _check(_lib.load().bsp_debug_read_extents(out.ctypes.data_as(ctypes.c_void_p), max_launches,
+                                              ctypes.byref(n)))
     return out[:n.value]
 
 

@@ -4,7 +4,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbaspacho_amd.so")
+# (BSP_LIB_PATH: developer override, e.g. a BSP_KTRACE=1 trace build kept beside the product library)
+LIB_PATH = os.environ.get("BSP_LIB_PATH") or os.path.join(_HERE, "libbaspacho_amd.so")
 
 _lib = None
 

@@ -465,6 +465,11 @@ int bsp_probe_mfma_f64(double* tflops) {
   BSP_CATCH
 }
 
+int bsp_debug_read_extents(unsigned long long* out, int max_launches, int* n) {
+  BSP_TRY
+  *n = hipBackendReadExtents(out, max_launches);
+  BSP_CATCH
+}
 int bsp_debug_read_trace(long long* out, int max_records, int* n_records) {
   BSP_TRY
   *n_records = hipBackendReadTrace(out, max_records);

@@ -43,6 +43,9 @@ void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof, bool inSitu 
 double hipBackendMfmaF64ProbeTflops();
 // in-situ kernel trace (BSP_KTRACE builds only; returns 0 records otherwise)
 int hipBackendReadTrace(long long* out, int maxRecords);
+// BSP_KTRACE + BSP_TRACE_TILE builds: per chain-step launch {first start, last start, last end,
+// workgroup-0 end} over all its workgroups (wall clock, 100 MHz); resets the table
+int hipBackendReadExtents(unsigned long long* out, int maxLaunches);
 
 // TESTING: make factor() take the reference-style per-op loop (potrf/trsm/saveSyrkGemm/
 // prepareAssemble/assemble/doElimination virtuals) instead of the fused path

@@ -276,6 +276,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_MERGED_BLOCK_LAST")) mergedBlockLast = e[0] != '0';
     if (const char* e = std::getenv("BSP_BULK_KERNEL")) bulkKernel = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_OVERLAP")) elimOverlap = e[0] != '0';
+    if (const char* e = std::getenv("BSP_BULK_YIELD")) bulkYield = e[0] != '0';
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -385,6 +386,15 @@ struct HipSymbolicCtx : SymbolicCtx {
     }
     return side;
   }
+  // word of device memory through which the chain's potrf workgroup tells the bulk tiles which CU
+  // it runs on (cooperative CU yield, hip_kernels.h)
+  unsigned* yieldWord() {
+    if (!yieldBuf.ptr) {
+      yieldBuf.resize(256);
+      hipCHECK(hipMemset(yieldBuf.ptr, 0, 256));
+    }
+    return reinterpret_cast<unsigned*>(yieldBuf.ptr);
+  }
   hipStream_t elimStream() {
     if (!elim) {
       int least = 0, greatest = 0;
@@ -413,6 +423,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   unsigned bulkExtraLds = 6 * 1024;
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
   hipStream_t side = nullptr, elim = nullptr;
+  bool bulkYield = true;       // bulk tiles pause on the CU of the chain's potrf workgroup (BSP_BULK_YIELD=0 disables)
   bool elimOverlap = false;    // sparse-elimination update overlapped with the dense phase (opt-in: BSP_ELIM_OVERLAP=1)
   bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
   bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
@@ -426,10 +437,11 @@ struct HipSymbolicCtx : SymbolicCtx {
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
   int device = -1;  // device of the first use (checkDevice)
+  int traceLaunchId = 0;  // ordinal of the chain-step launches (trace builds only)
   // scratch that outlives the per-call NumericCtx / SolveCtx objects (those are created and
   // destroyed around every factor() / solve(), Solver.cpp:176,223, while their kernels may still be
   // queued): sized on first use, only ever grown
-  DevBuf dinvScratch, rawScratch;
+  DevBuf dinvScratch, rawScratch, yieldBuf;
   PtrRing ptrRing;
   bool rowFormAttrSet[2] = {false, false};  // elimRowMfma dynamic-LDS attribute (fp64, fp32)
   std::map<std::pair<int64_t, int64_t>, std::pair<std::unique_ptr<DevBuf>, size_t>> addMvTileLists;
@@ -462,8 +474,10 @@ struct HipNumericCtx : NumericCtx<T> {
       // (32 KB of static LDS instead of updateTile's 34.8: 3 KB more padding keeps it at three
       //  workgroups per CU next to a chain workgroup)
       const unsigned pad = extraLds ? extraLds + 3072 : 0;
+      // (cooperative CU yield, hip_kernels.h: side-stream launches of a single matrix only)
+      const unsigned* yf = (extraLds && batchSize == 1 && sym.bulkYield) ? sym.yieldWord() : nullptr;
       hipk::updateTileBulk<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, pad,
-                                stream>>>(plan.updTasksFat.as<UpdTaskFat>() + begin, ref);
+                                stream>>>(plan.updTasksFat.as<UpdTaskFat>() + begin, ref, yf);
       return;
     }
     hipk::updateTile<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, extraLds, stream>>>(
@@ -631,7 +645,8 @@ struct HipNumericCtx : NumericCtx<T> {
           hipk::chainStep<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
               plan.host.panels[lr.directPanel], plan.host.segs[lr.directSeg], (int)nUpd, nextPanel,
               fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
-              memOff, kMem);
+              memOff, kMem, (lookahead && batchSize == 1 && sym.bulkYield) ? sym.yieldWord() : nullptr,
+              sym.traceLaunchId++);
           potrfFused = fuse;
         } else if (fuse) {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
@@ -1341,13 +1356,30 @@ struct HipOps : Ops {
 
 OpsPtr hipOps() { return OpsPtr(new HipOps); }
 
+int hipBackendReadExtents(unsigned long long* out, int maxLaunches) {
+#if defined(BSP_KTRACE) && defined(BSP_TRACE_TILE)
+  hipCHECK(hipDeviceSynchronize());
+  const int n = std::min(maxLaunches, 2048);
+  hipCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(hipk::bspLaunchExtent), sizeof(unsigned long long) * 4 * n));
+  // reset: minima to the largest value, maxima to zero
+  std::vector<unsigned long long> init(2048 * 4, 0ull);
+  for (int i = 0; i < 2048; i++) init[4 * i] = ~0ull;
+  hipCHECK(hipMemcpyToSymbol(HIP_SYMBOL(hipk::bspLaunchExtent), init.data(), sizeof(unsigned long long) * 4 * 2048));
+  return n;
+#else
+  (void)out;
+  (void)maxLaunches;
+  return 0;
+#endif
+}
+
 int hipBackendReadTrace(long long* out, int maxRecords) {
 #ifdef BSP_KTRACE
   unsigned n = 0;
   hipCHECK(hipDeviceSynchronize());
   hipCHECK(hipMemcpyFromSymbol(&n, HIP_SYMBOL(hipk::bspTraceCount), sizeof n));
   const int cnt = (int)std::min<unsigned>(n, (unsigned)std::min(maxRecords, 8192));
-  hipCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(hipk::bspTrace), sizeof(long long) * 4 * cnt));
+  hipCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(hipk::bspTrace), sizeof(long long) * hipk::kTraceW * cnt));
   n = 0;
   hipCHECK(hipMemcpyToSymbol(HIP_SYMBOL(hipk::bspTraceCount), &n, sizeof n));
   return cnt;

@@ -45,6 +45,37 @@ __device__ __forceinline__ GP<T> pickData(const DataRef<T>& d) {
 __device__ __forceinline__ void atomicSub(GP<double> p, double v) { unsafeAtomicAdd((double*)p, -v); }
 __device__ __forceinline__ void atomicSub(GP<float> p, float v) { unsafeAtomicAdd((float*)p, -v); }
 
+// COOPERATIVE CU YIELD.  fp64 MFMA and fp64 VALU instructions go through the same pipe of a SIMD,
+// and an MFMA in flight is not pre-empted: while a bulk-update wave runs its K loop on a SIMD, every
+// dependent fp64 instruction of the panel Cholesky's pivot chain waits for the MFMA ahead of it
+// (in-situ trace, tools/trace_potrf.py: median step unchanged, 90th percentile 3.5x -- the chain
+// workgroup's loop took 40 k clocks beside the bulk tiles against 28 k alone).  Neither stream
+// priorities nor CU masks keep the bulk tiles off the chain's CU, so the chain workgroup says where
+// it is: it publishes the identity of its CU in a word of device memory, and bulk waves that find
+// themselves on that CU sleep (bounded) until the word changes.  Three bulk workgroups pause for
+// the ~15 us of a potrf; the critical path gets its pipe back.
+__device__ __forceinline__ unsigned cuKey() {
+  // HW_REG_HW_ID (4): CU_ID[11:8] SH_ID[12] SE_ID[15:13]; HW_REG_XCC_ID (20): XCC_ID[3:0]
+  const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+  return 0x80000000u | (xcc << 8) | hw;
+}
+__device__ __forceinline__ void yieldPublish(unsigned* flag, unsigned key) {
+  if (flag && threadIdx.x == 0) {
+    __hip_atomic_store((GP<unsigned>)flag, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ unsigned yieldPeek(const unsigned* flag) {
+  return __hip_atomic_load((GP<const unsigned>)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// bounded: at most ~48 x (sleep + one load) = a few tens of microseconds, whatever happens to the word
+__device__ __forceinline__ void yieldWhile(const unsigned* flag, unsigned key) {
+  for (int spin = 0; spin < 48; spin++) {
+    __builtin_amdgcn_s_sleep(64);
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)yieldPeek(flag)) != key) break;
+  }
+}
+
 __device__ __forceinline__ void waveSync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -728,19 +759,62 @@ __global__ __launch_bounds__(256) void elimGatherTiny(const ElimGatherItem* item
 #if defined(BSP_KTRACE)
 // in-situ trace build (build.sh with BSP_KTRACE=1): every launch of a stamped kernel appends one
 // record of 4 clock values; read back with hipBackendReadTrace()
-__device__ long long bspTrace[8192 * 4];
+constexpr int kTraceW = 8;  // clock values per record (slots 0-3: kernel phases, 4-7: inside a potrf step)
+__device__ long long bspTrace[8192 * kTraceW];
 __device__ unsigned bspTraceCount;
 __shared__ unsigned bspTraceSlot;
+#ifdef BSP_TRACE_TILE
+#define BSP_STEP_STAMPS(slot) ((slot) < 4)
+#define BSP_CLOCK() wall_clock64()  // device-wide constant-rate counter (the shader clocks of
+                                    // different XCDs are not aligned): 100 MHz
+#else
+#define BSP_STEP_STAMPS(slot) true
+#define BSP_CLOCK() clock64()
+#endif
+#ifndef BSP_TRACE_TID
+#define BSP_TRACE_TID 0  // thread that writes the in-step stamps (slots 4-7): 0, 64, 128, 192 = wave 0..3
+#endif
 #define BSP_STAMP(slot)                                                        \
-  if (threadIdx.x == 0 && blockIdx.x == 0) {                                   \
+  if (threadIdx.x == ((slot) >= 4 ? BSP_TRACE_TID : 0) && blockIdx.x == 0 && BSP_STEP_STAMPS(slot)) { \
     if ((slot) == 0) bspTraceSlot = atomicAdd(&bspTraceCount, 1u) & 8191u;     \
-    bspTrace[bspTraceSlot * 4 + (slot)] = clock64();                           \
+    bspTrace[bspTraceSlot * kTraceW + (slot)] = BSP_CLOCK();                   \
+  }
+// BSP_TRACE_TILE builds: per chain-step launch (ordinal passed by the host), the earliest / latest
+// start and the latest end over ALL its workgroups (wall clock), besides workgroup 0's record
+__device__ unsigned long long bspLaunchExtent[2048 * 4];  // start min, start max, end max, wg0 end
+#define BSP_EXTENT_BEGIN(id)                                                                   \
+  if (threadIdx.x == 0) {                                                                      \
+    const unsigned long long t_ = wall_clock64();                                              \
+    atomicMin(&bspLaunchExtent[((id) & 2047) * 4 + 0], t_);                                     \
+    atomicMax(&bspLaunchExtent[((id) & 2047) * 4 + 1], t_);                                     \
+  }
+#define BSP_EXTENT_END(id, wg0)                                                                \
+  if (threadIdx.x == 0) {                                                                      \
+    const unsigned long long t_ = wall_clock64();                                              \
+    atomicMax(&bspLaunchExtent[((id) & 2047) * 4 + 2], t_);                                     \
+    if (wg0) bspLaunchExtent[((id) & 2047) * 4 + 3] = t_;                                       \
+  }
+// BSP_TRACE_TILE builds: the LAST tile workgroup of a chain-step launch writes a record of its own
+// (slots 4-7: start / after solve / after multiply / end; slots 0-3 stay zero), and the in-step
+// stamps of workgroup 0 are off
+#define BSP_STAMP_TILE(slot)                                                   \
+  if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.x != 0) {    \
+    if ((slot) == 4) bspTraceSlot = atomicAdd(&bspTraceCount, 1u) & 8191u;     \
+    bspTrace[bspTraceSlot * kTraceW + (slot)] = BSP_CLOCK();                   \
   }
 #elif defined(BSP_KDEBUG)
 #define BSP_STAMP(slot) if (threadIdx.x == 0 && blockIdx.x == 0) bspDebugStamps[slot] = clock64()
 __device__ long long bspDebugStamps[16];
 #else
 #define BSP_STAMP(slot)
+#endif
+#if !defined(BSP_KTRACE) || !defined(BSP_TRACE_TILE)
+#undef BSP_STAMP_TILE
+#define BSP_STAMP_TILE(slot)
+#undef BSP_EXTENT_BEGIN
+#undef BSP_EXTENT_END
+#define BSP_EXTENT_BEGIN(id)
+#define BSP_EXTENT_END(id, wg0)
 #endif
 
 // NT = tiles per dimension (NT = 4: 64x64 block, 256 threads).  A 256x256 single-workgroup variant
@@ -870,6 +944,7 @@ __device__ __forceinline__ void potrfTiles(GP<T> A, int nb, int lda, T (*blk)[4]
   auto step = [&](auto Jc) __attribute__((always_inline)) {
     const int J = Jc;  // integral_constant: a compile-time constant after inlining
     if (J >= nSteps) return;
+    if (J == 6) { BSP_STAMP(4); }
     const int j0 = 4 * J, tjJ = J >> 2;
     T(*raw)[4] = blk + (J % 3) * N;
     // (1) pivot block + own row
@@ -880,62 +955,75 @@ __device__ __forceinline__ void potrfTiles(GP<T> A, int nb, int lda, T (*blk)[4]
             p33 = raw[j0 + 3][3];
     const T r0 = raw[i][0], r1 = raw[i][1], r2 = raw[i][2], r3 = raw[i][3];
     const T i0 = fastRsqrt(p00);
-    const T l00 = p00 * i0, l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+    const T l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
     const T q11 = p11 - l10 * l10;
     const T i1 = fastRsqrt(q11);
-    const T l11 = q11 * i1, l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+    const T l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
     const T q22 = p22 - l20 * l20 - l21 * l21;
     const T i2 = fastRsqrt(q22);
-    const T l22 = q22 * i2, l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+    const T l32 = (p32 - l30 * l20 - l31 * l21) * i2;
     const T q33 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
     const T i3 = fastRsqrt(q33);
-    const T l33 = q33 * i3;
     const bool below = i >= j0 + 4;
-    // own row solved against the pivot block (zero for rows that are done or inside the block)
-    T c0 = r0 * i0;
-    T c1 = (r1 - c0 * l10) * i1;
-    T c2 = (r2 - c0 * l20 - c1 * l21) * i2;
-    T c3 = (r3 - c0 * l30 - c1 * l31 - c2 * l32) * i3;
-    c0 = below ? c0 : T(0);
-    c1 = below ? c1 : T(0);
-    c2 = below ? c2 : T(0);
-    c3 = below ? c3 : T(0);
-    const T solved = g == 0 ? c0 : g == 1 ? c1 : g == 2 ? c2 : c3;
-    sol[i][g] = solved;
+    // own row solved against the pivot block.  For a row INSIDE the pivot block the same recurrence
+    // reproduces its entries of L (u_g = l(i, 4J+g) for g <= i - j0, operation for operation what
+    // the redundant 4x4 factorization above computes), so the value to store is u_g for every
+    // live row -- no select between "solved" and "in-pivot" values, whose nest of divergent
+    // branches cost a fifth of the step.  What is published for the updates is zero for rows that
+    // are done or inside the block.
+    const T u0 = r0 * i0;
+    const T u1 = (r1 - u0 * l10) * i1;
+    const T u2 = (r2 - u0 * l20 - u1 * l21) * i2;
+    const T u3 = (r3 - u0 * l30 - u1 * l31 - u2 * l32) * i3;
+    const T c0 = below ? u0 : T(0), c1 = below ? u1 : T(0), c2 = below ? u2 : T(0),
+            c3 = below ? u3 : T(0);
+    const T u01 = (g & 1) ? u1 : u0, u23 = (g & 1) ? u3 : u2;
+    const T ufin = (g & 2) ? u23 : u01;
+    sol[i][g] = below ? ufin : T(0);
+    if (J == 6) { BSP_STAMP(5); }
     // (the previous step's MFMAs have had the whole pivot chain to complete: no stall here)
     if (J + 2 < nSteps) publish(J + 2);  // state: rank-4 updates of steps < J
-    {
-      const int di = i - j0;  // row inside the pivot block when 0..3
-      const T lrow0 = di == 0 ? l00 : di == 1 ? l10 : di == 2 ? l20 : l30;
-      const T lrow1 = di == 1 ? l11 : di == 2 ? l21 : l31;
-      const T lrow2 = di == 2 ? l22 : l32;
-      const T inPiv = g == 0 ? lrow0 : g == 1 ? lrow1 : g == 2 ? lrow2 : l33;
-      if (i < nb && j0 + g < nb && di >= g) {
-        const T fin = below ? solved : inPiv;
-        A[(int64_t)i * lda + j0 + g] = fin;
-        if (Ld && (i >> 4) == tjJ) Ld[i * kInvLd + ((j0 + g) & 15)] = fin;
-      }
+    if (i < nb && j0 + g < nb && i - j0 >= g) {
+      A[(int64_t)i * lda + j0 + g] = ufin;
+      if (Ld && (i >> 4) == tjJ) Ld[i * kInvLd + ((j0 + g) & 15)] = ufin;
     }
     ldsBarrier();
-    // (2) bring the next two column blocks up to date, rank-4 update of every live tile
-#pragma unroll
-    for (int ahead = 1; ahead <= 2; ahead++) {
-      if (J + ahead < nSteps) {
-        T(*nx)[4] = blk + ((J + ahead) % 3) * N;
-        const int jr = j0 + 4 * ahead + g;
-        nx[i][g] -= c0 * sol[jr][0] + c1 * sol[jr][1] + c2 * sol[jr][2] + c3 * sol[jr][3];
-      }
-    }
+    if (J == 6) { BSP_STAMP(6); }
+    // (2) bring the next two column blocks up to date, rank-4 update of every live tile.  Every LDS
+    // read of the section is issued before the first use (one round trip instead of four): rows
+    // past the end are clamped, ring slots that are not live are read and written as they are
+    // (nothing reads them as a pivot block again; a conditional store would pull its loads into
+    // the branch).
     {
+      T(*nx1)[4] = blk + ((J + 1) % 3) * N;
+      T(*nx2)[4] = blk + ((J + 2) % 3) * N;
+      const int jr1 = min(j0 + 4 + g, N - 1), jr2 = min(j0 + 8 + g, N - 1);
+      T s1[4], s2[4], sb[NT];
+#pragma unroll
+      for (int k = 0; k < 4; k++) s1[k] = sol[jr1][k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) s2[k] = sol[jr2][k];
+      const T n1 = nx1[i][g], n2 = nx2[i][g];
       const T sa = -sol[16 * w + li][lk];
 #pragma unroll
+      for (int tj = 0; tj < NT; tj++) sb[tj] = sol[16 * tj + li][lk];
+      nx1[i][g] = n1 - (c0 * s1[0] + c1 * s1[1] + c2 * s1[2] + c3 * s1[3]);
+      nx2[i][g] = n2 - (c0 * s2[0] + c1 * s2[1] + c2 * s2[2] + c3 * s2[3]);
+      // tile columns left of the pivot are final (compile-time).  Tiles above the diagonal
+      // (tj > w) get a zero operand instead of a branch: a branch would pull the operand reads
+      // behind it -- a second LDS round trip on the serial path -- and the wave with all tiles live
+      // sets the pace of the step anyway.  The MFMAs run while the wave sits in the barrier and in
+      // the LDS reads of the next step: fp64 MFMA and fp64 VALU share one pipe, so a variant with
+      // ONE barrier per step (next pivot block kept in registers, computed redundantly by every
+      // thread) only moved the wait for them in front of the next pivot chain (measured: 1920
+      // against 1730 clocks per step).
+#pragma unroll
       for (int tj = 0; tj < NT; tj++) {
-        if (tj <= w && tj >= tjJ) {  // wave-uniform; tile columns left of the pivot are final
-          acc[tj] = Mfma<T>::run(sa, sol[16 * tj + li][lk], acc[tj]);
-        }
+        if (tj >= tjJ) acc[tj] = Mfma<T>::run(tj <= w ? sa : T(0), sb[tj], acc[tj]);
       }
     }
     ldsBarrier();
+    if (J == 6) { BSP_STAMP(7); }
   };
 
   // (compile-time step index: tile and column-block indices are constants -- a rolled loop
@@ -1433,11 +1521,10 @@ struct BulkSwizzle {
     return r * kUpdChunk + E * ((k / E) ^ key(r)) + (k % E);
   }
 };
-// As, Bs: kTile * kUpdChunk values each, 16-byte aligned.  rawOut / nbNext: see
-// updateTileDirectBody (chain staging buffer of the next panel's rows).
+// As, Bs: kTile * kUpdChunk values each, 16-byte aligned.
 template <typename T>
 __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T* As, T* Bs,
-                                             GP<T> rawOut = nullptr, int nbNext = 0) {
+                                             const unsigned* yieldFlag = nullptr) {
   constexpr int KC = kUpdChunk, E = BulkSwizzle<T>::E, SLOTS = KC / E, RPI = 64 / SLOTS;
   constexpr int NI = kTile / (4 * RPI);  // wave instructions per operand and wave
   typedef __attribute__((address_space(1))) const void* GV;
@@ -1462,26 +1549,22 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
     srcA[it] = P + (int64_t)min(t.rowTile + r, t.rowsBelow - 1) * lda + E * slot;
     srcB[it] = P + (int64_t)min(t.colTile + r, t.segEnd - 1) * lda + E * slot;
   }
-  // old target values (masked-off entries are clamped onto valid ones)
+  // The old target values are NOT requested before the K loop (their 32 registers would be live
+  // through it): the kernel stays within 96 registers, so that a chain workgroup (224) fits on a
+  // CU beside three of these.  With 120 the chain's workgroups queued behind the remaining rounds
+  // of a bulk launch (17 us per chain launch on average, 100+ us in the worst launches:
+  // tools/trace_extents.py).  No-return atomics for every tile (no old values at all) cost the
+  // bulk 11 % (3.74 -> 4.15 ms serialised).
   GP<T> tgt = data + t.tgtBase;
-  T old[16];
-  if (!t.atomic) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int qc = min(t.colTile + wc + (q & 1) * 16 + li, t.segEnd - 1);
-#pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        const int qr = min(t.rowTile + wr + (q >> 1) * 16 + Mfma<T>::row(lane, reg), t.rowsBelow - 1);
-        old[q * 4 + reg] = tgt[(int64_t)qr * t.tgtStride + qc];
-      }
-    }
-  }
   const int oa0 = BulkSwizzle<T>::at(wr + li, lk), oa1 = BulkSwizzle<T>::at(wr + 16 + li, lk);
   const int ob0 = BulkSwizzle<T>::at(wc + li, lk), ob1 = BulkSwizzle<T>::at(wc + 16 + li, lk);
   const int ka0 = BulkSwizzle<T>::key(wr + li), ka1 = BulkSwizzle<T>::key(wr + 16 + li);
   const int kb0 = BulkSwizzle<T>::key(wc + li), kb1 = BulkSwizzle<T>::key(wc + 16 + li);
+  const unsigned myCu = yieldFlag ? cuKey() : 0u;
   for (int kBase = 0; kBase < K; kBase += KC) {
     if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
+    // (cooperative CU yield: the word is fetched with the chunk and looked at after it has landed)
+    const unsigned yf = yieldFlag ? yieldPeek(yieldFlag) : 0u;
 #pragma unroll
     for (int it = 0; it < NI; it++) {
       __builtin_amdgcn_global_load_lds((GV)(srcA[it] + kBase), (LV)(As + RPI * (4 * it + wave) * KC),
@@ -1496,6 +1579,9 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (yieldFlag && (unsigned)__builtin_amdgcn_readfirstlane((int)yf) == myCu) {
+      yieldWhile(yieldFlag, myCu);
+    }
     if (!skipUpper) {
 #pragma unroll
       for (int k0 = 0; k0 < KC; k0 += 4) {
@@ -1514,22 +1600,39 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
   }
   if (!skipUpper) {
     const Acc* accs[4] = {&acc00, &acc01, &acc10, &acc11};
+    if (t.atomic) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int qc = t.colTile + wc + (q & 1) * 16 + li;
+      for (int q = 0; q < 4; q++) {
+        const int qc = t.colTile + wc + (q & 1) * 16 + li;
 #pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        const int qr = t.rowTile + wr + (q >> 1) * 16 + Mfma<T>::row(lane, reg);
-        if (qc < t.segEnd && qr < t.rowsBelow && qr >= qc && qr >= t.rowMin) {
-          GP<T> p = tgt + (int64_t)qr * t.tgtStride + qc;
-          if (t.atomic) {
-            atomicSub(p, (*accs[q])[reg]);
-          } else {
-            const T val = old[q * 4 + reg] - (*accs[q])[reg];
-            *p = val;
-            if (rawOut && t.colTile == 0 && qc < nbNext && qr >= nbNext) {
-              rawOut[(int64_t)(qr - nbNext) * kTile + qc] = val;
-            }
+        for (int reg = 0; reg < 4; reg++) {
+          const int qr = t.rowTile + wr + (q >> 1) * 16 + Mfma<T>::row(lane, reg);
+          if (qc < t.segEnd && qr < t.rowsBelow && qr >= qc && qr >= t.rowMin) {
+            atomicSub(tgt + (int64_t)qr * t.tgtStride + qc, (*accs[q])[reg]);
+          }
+        }
+      }
+    } else {
+      // single writer: read - subtract - write, the 16 old values requested together AFTER the K
+      // loop (masked-off entries clamped onto valid ones)
+      T old[16];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int qc = min(t.colTile + wc + (q & 1) * 16 + li, t.segEnd - 1);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          const int qr = min(t.rowTile + wr + (q >> 1) * 16 + Mfma<T>::row(lane, reg), t.rowsBelow - 1);
+          old[q * 4 + reg] = tgt[(int64_t)qr * t.tgtStride + qc];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int qc = t.colTile + wc + (q & 1) * 16 + li;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          const int qr = t.rowTile + wr + (q >> 1) * 16 + Mfma<T>::row(lane, reg);
+          if (qc < t.segEnd && qr < t.rowsBelow && qr >= qc && qr >= t.rowMin) {
+            tgt[(int64_t)qr * t.tgtStride + qc] = old[q * 4 + reg] - (*accs[q])[reg];
           }
         }
       }
@@ -1538,11 +1641,13 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void updateTileBulk(const UpdTaskFat* tasks, DataRef<T> dref) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void updateTileBulk(
+    const UpdTaskFat* tasks, DataRef<T> dref,
+                                                      const unsigned* yieldFlag) {
   __shared__ __attribute__((aligned(16))) T As[kTile * kUpdChunk];
   __shared__ __attribute__((aligned(16))) T Bs[kTile * kUpdChunk];
   const UpdTaskFat t = tasks[blockIdx.x];
-  bulkTileBody<T>(t, pickData(dref), As, Bs);
+  bulkTileBody<T>(t, pickData(dref), As, Bs, yieldFlag);
 }
 
 // K5d  direct variant for the update tiles of a one-panel level that all belong to ONE
@@ -1906,8 +2011,9 @@ template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void chainStep(
     PanelDesc pd, SegDesc sd, int nTasks, PanelDesc next, int fuse, DataRef<T> dref,
     const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase,
-    int64_t memOff, int kMem) {
+    int64_t memOff, int kMem, unsigned* yieldFlag, int traceId) {
   __shared__ T XB[kTile * kXbLd];
+  BSP_EXTENT_BEGIN(traceId);
   static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd <= kTile * kXbLd, "potrf LDS fits in XB");
   using Acc = typename Mfma<T>::Acc;
   GP<T> data = pickData(dref);
@@ -1921,6 +2027,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (fuse && blockIdx.x == 0) {
     // tile (0,0) = the next panel's diagonal block: update it inside the potrf and factor it
     __builtin_amdgcn_s_setprio(3);
+    yieldPublish(yieldFlag, cuKey());  // bulk waves on this CU pause until the potrf is done
     T(*blk)[4] = reinterpret_cast<T(*)[4]>(XB);
     T(*sol)[4] = blk + 3 * kPanelWidth;
     T* Ld = XB + 4 * kPanelWidth * 4;
@@ -1944,11 +2051,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     BSP_STAMP(0);
     potrfTiles<T, 4>(data + next.diagOff, next.nb, next.lda, blk, sol, pre, Ld,
                      (GP<T>)dinvOutBase + (size_t)blockIdx.y * kDinvBatchStride);
+    yieldPublish(yieldFlag, 0u);
     BSP_STAMP(3);
+    BSP_EXTENT_END(traceId, true);
     return;
   }
 
   __builtin_amdgcn_s_setprio(BSP_TILE_PRIO);
+  BSP_STAMP_TILE(4);
   int idx = fuse ? 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1) : xcdContiguous(blockIdx.x, nTasks);
   int colTile = sd.q0, rowTile;
   for (;;) {
@@ -1970,6 +2080,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   ct.load(rawIn, Lkk, dinv, lda, nb, ri, rj, rowsBelow, segEnd, rowTile == colTile);
   // (column tile q0 covers every row tile once: its workgroups store X_i in place)
   ct.solve(nb, XB, colTile == sd.q0 ? P + (int64_t)(ct.actI ? ri : 0) * lda : nullptr);
+  BSP_STAMP_TILE(5);
   // (the old target values are fetched after the solve: these tiles are not on the critical path
   //  -- the potrf workgroup is -- and the registers are needed for the trsm operands)
   GP<T> tgt = data + sd.tgtBase;
@@ -1984,6 +2095,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   ct.multiply(XB, D);
+  BSP_STAMP_TILE(6);
   GP<T> rawOut = (GP<T>)rawOutBase + blockIdx.y * rawStride;
   const int nbNext = next.nb;
 #pragma unroll
@@ -2001,6 +2113,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
+  BSP_STAMP_TILE(7);
+  BSP_EXTENT_END(traceId, false);
 }
 
 // (A 128x128-tile variant of K5 -- 4x4 MFMA tiles per wave, 70 KB LDS, 2 workgroups per CU -- was

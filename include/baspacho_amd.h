@@ -249,9 +249,12 @@ int bsp_factor_profiled_insitu_f64(bsp_solver* s, double* dev_data, double ms[6]
 /* sustained v_mfma_f64_16x16x4_f64 rate of the current GPU (TFLOP/s), register-only probe */
 int bsp_probe_mfma_f64(double* tflops);
 
-/* Developer aid: in-situ kernel clock records of a library built with BSP_KTRACE=1 (4 values per
+/* Developer aid: in-situ kernel clock records of a library built with BSP_KTRACE=1 (8 values per
  * stamped kernel launch); a normal build reports 0 records. */
 int bsp_debug_read_trace(long long* out, int max_records, int* n_records);
+/* ... and, for builds with -DBSP_TRACE_TILE as well: per chain-step launch {first workgroup start,
+ * last workgroup start, last workgroup end, workgroup-0 end} in 10 ns units; reading resets. */
+int bsp_debug_read_extents(unsigned long long* out, int max_launches, int* n);
 
 /* Symbolic plan as one flat int64 buffer, so that rank 0 can analyse once and broadcast it
    (RCCL) to the ranks that factor the other matrices of a batch. */

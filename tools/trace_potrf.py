@@ -1,7 +1,10 @@
-"""In-situ clock trace of the chain potrf (needs a library built with BSP_KTRACE=1):
-per launch, clocks spent in load / 16-step loop / store, for a factor with and without the
-lookahead side stream."""
-import os, sys
+"""In-situ clock trace of the chain potrf (needs a library built with BSP_KTRACE=1, see build.sh:
+BSP_KTRACE=1 BSP_OUT=../libbaspacho_amd_trace.so BSP_BUILD_DIR=../_build_trace bash build.sh, then
+BSP_LIB_PATH=baspacho_amd/libbaspacho_amd_trace.so python tools/trace_potrf.py).
+Per stamped launch (workgroup 0 of the chain kernels), clocks spent in: load + pending update /
+16-step loop / inverses + store; and inside step 6 of the loop: pivot chain (LDS read -> sol
+written) / first barrier / thread-level update + MFMA + second barrier."""
+import sys
 sys.path.insert(0, ".")
 import numpy as np
 import torch
@@ -22,9 +25,18 @@ for it in range(3):
     sol.factor(buf)
     torch.cuda.synchronize()
     tr = bsp.debug_read_trace()
-d = np.diff(tr, axis=1) / 2400.0  # us at 2.4 GHz (s_memtime may tick at 100 MHz: check scale)
-print("records", len(tr))
-print("idx   load    loop   store   total")
-for i in range(0, min(len(d), 48)):
-    print("%3d %7.1f %7.1f %7.1f %7.1f" % (i, d[i, 0], d[i, 1], d[i, 2], d[i].sum()))
-print("mean", d.mean(axis=0), d.sum(axis=1).mean())
+tr = tr[(tr[:, 0] > 0) & (tr[:, 3] > 0)]
+d = np.diff(tr[:, :4], axis=1)
+print("records", len(tr), "(clock units as clock64() counts them)")
+print("mean load/pre %.0f  loop %.0f  tail %.0f  total %.0f" % (*d.mean(axis=0), d.sum(axis=1).mean()))
+ok = tr[:, 4] > 0
+s = tr[ok]
+print("step 6: pivot chain %.0f  barrier-1 %.0f  update+mfma+barrier-2 %.0f  | whole step %.0f  (loop/16 = %.0f)" % (
+    (s[:, 5] - s[:, 4]).mean(), (s[:, 6] - s[:, 5]).mean(), (s[:, 7] - s[:, 6]).mean(),
+    (s[:, 7] - s[:, 4]).mean(), d[:, 1].mean() / 16))
+for q in (10, 50, 90):
+    print("  p%d: chain %.0f  b1 %.0f  rest %.0f" % (q, np.percentile(s[:, 5] - s[:, 4], q),
+                                                   np.percentile(s[:, 6] - s[:, 5], q),
+                                                   np.percentile(s[:, 7] - s[:, 6], q)))
+# wall-clock check of the clock unit: total span of the trace against the factor time
+print("trace span (first stamp -> last stamp): %.0f clock units" % (tr[:, 3].max() - tr[:, 0].min()))
