@@ -277,12 +277,16 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_BULK_KERNEL")) bulkKernel = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_OVERLAP")) elimOverlap = e[0] != '0';
     if (const char* e = std::getenv("BSP_BULK_YIELD")) bulkYield = e[0] != '0';
+    if (const char* e = std::getenv("BSP_EARLY_DIAG")) earlyDiag = e[0] != '0';
+    if (const char* e = std::getenv("BSP_MERGE_DEF")) mergeDeferred = e[0] != '0';
+    if (const char* e = std::getenv("BSP_DUE_STREAM")) dueStream = e[0] != '0';
   }
 
   virtual ~HipSymbolicCtx() override {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
     if (elim) (void)hipStreamDestroy(elim);
+    if (sideDue) (void)hipStreamDestroy(sideDue);
   }
 
   virtual void setSparseElimRanges(const vector<int64_t>& ranges) override {
@@ -395,6 +399,14 @@ struct HipSymbolicCtx : SymbolicCtx {
     }
     return reinterpret_cast<unsigned*>(yieldBuf.ptr);
   }
+  hipStream_t dueSideStream() {
+    if (!sideDue) {
+      int least = 0, greatest = 0;
+      hipCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      hipCHECK(hipStreamCreateWithPriority(&sideDue, hipStreamNonBlocking, least));
+    }
+    return sideDue;
+  }
   hipStream_t elimStream() {
     if (!elim) {
       int least = 0, greatest = 0;
@@ -422,7 +434,10 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool lookaheadEnabled = true;
   unsigned bulkExtraLds = 6 * 1024;
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
-  hipStream_t side = nullptr, elim = nullptr;
+  hipStream_t side = nullptr, elim = nullptr, sideDue = nullptr;
+  bool dueStream = true;       // due lookahead units on a stream of their own (BSP_DUE_STREAM=0: one side stream)
+  bool mergeDeferred = false;  // BSP_MERGE_DEF=1: due + optional lookahead units of a block in one launch
+  bool earlyDiag = true;       // intra-block chain steps pre-apply their panel to the next block's tile (0,0) (BSP_EARLY_DIAG=0 disables)
   bool bulkYield = true;       // bulk tiles pause on the CU of the chain's potrf workgroup (BSP_BULK_YIELD=0 disables)
   bool elimOverlap = false;    // sparse-elimination update overlapped with the dense phase (opt-in: BSP_ELIM_OVERLAP=1)
   bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
@@ -500,16 +515,27 @@ struct HipNumericCtx : NumericCtx<T> {
                     LaunchTimer& timer, const vector<hipEvent_t>* gatherDone = nullptr) {
     const dim3 gy(1, (unsigned)batchSize, 1);
     const bool lookahead = lookaheadOn();
-    int waitedMain = -1, waitedSide = -1;  // gather groups the two streams already wait for
+    int waitedMain = -1, waitedSide = -1, waitedDue = -1;  // gather groups the streams already wait for
     auto waitGather = [&](hipStream_t st, int group, int& waited) {
       if (!gatherDone || group <= waited) return;
       group = std::min<int>(group, (int)gatherDone->size() - 1);
       if (group > waited) hipCHECK(hipStreamWaitEvent(st, (*gatherDone)[group], 0));
       waited = group;
     };
-    vector<hipEvent_t> defDone(levels.size(), nullptr);
+    vector<hipEvent_t> defDone(levels.size(), nullptr);  // due units of a level complete
+    vector<hipEvent_t> optDone(levels.size(), nullptr);  // ... its optional units (due-stream mode)
+    const bool dueStream = sym.dueStream && !sym.mergeDeferred;
+    // fork level of the same lump's previous block (-1: none)
+    auto prevFork = [&](int64_t f) -> int64_t { return f >= 0 ? levels[f].waitDefLevel : -1; };
+    auto waitDeferred = [&](int64_t f) {
+      // everything the side streams owe to the column block this level is about to touch
+      if (f < 0 || !defDone[f]) return;
+      hipCHECK(hipStreamWaitEvent(sym.stream, defDone[f], 0));
+      const int64_t pf = prevFork(f);
+      if (dueStream && pf >= 0 && optDone[pf]) hipCHECK(hipStreamWaitEvent(sym.stream, optDone[pf], 0));
+    };
     bool potrfFused = false;  // this level's potrf ran inside the previous level's update launch
-    bool sideUsed = false;
+    bool sideUsed = false, dueUsed = false;
     // inverted diagonal blocks of the chain panels: written by a panel's potrf, read by its trsm
     // (two slots per matrix, alternating from panel to panel)
     sym.dinvScratch.resize((size_t)batchSize * hipk::kDinvBatchStride * sizeof(BT));
@@ -523,6 +549,13 @@ struct HipNumericCtx : NumericCtx<T> {
       rawBase = const_cast<BT*>(sym.rawScratch.as<BT>());
     }
     bool rawValid = false;  // the previous level staged this level's panel rows
+    // early tile-(0,0) updates of the next outer block (LevelRange::extraDiag): how many panels of
+    // the current block have applied theirs, in order -- the block-last step's potrf workgroup
+    // applies the rest from memory
+    int extraApplied = 0;
+    bool extraBroken = false;
+    const bool earlyDiag = sym.earlyDiag && sym.mergedChain && sym.mergedBlockLast && sym.fusePotrf &&
+                           sym.directChain;
     for (size_t li = 0; li < levels.size(); li++) {
       const LevelRange& lr = levels[li];
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
@@ -582,7 +615,7 @@ struct HipNumericCtx : NumericCtx<T> {
       if (merged) splitK = 0;
       bool waitedDef = false;
       if (splitK && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
-        hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
+        waitDeferred(lr.waitDefLevel);
         waitedDef = true;
       }
       if (nT && !merged) {
@@ -604,7 +637,7 @@ struct HipNumericCtx : NumericCtx<T> {
       }
       // (a second wait on the same event would still cost a ~6 us bubble between the launches)
       if (!waitedDef && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
-        hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDefLevel], 0));
+        waitDeferred(lr.waitDefLevel);
       }
       const bool anyDef = lr.defEnd > lr.defBegin;
       auto forkSide = [&]() {
@@ -617,6 +650,44 @@ struct HipNumericCtx : NumericCtx<T> {
         // first the tiles the next block's own update must wait for, then (event) the rest:
         // the side stream keeps running them while the chain goes on, and the next block's
         // deferred tiles queue up right behind
+        if (sym.mergeDeferred && lr.defEnd > lr.defBegin) {
+          // (experiment: due and optional units of a block as ONE launch, due tiles first)
+          waitGather(sym.sideStream(), lr.defWaitGatherEnd, waitedSide);
+          timer.begin(kProfUpdate, sym.sideStream());
+          launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+          timer.end();
+          defDone[li] = sym.eventFromPool();
+          hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
+          sideUsed = true;
+          return;
+        }
+        if (dueStream) {
+          // due units on their own stream, beside the optional ones (both accumulate with atomics
+          // where they can meet: hip_plan.cpp, pushUnit).  They must not overtake the optional
+          // units forked two blocks ago, whose far columns are plain read-modify-write.
+          hipStream_t due = sym.dueSideStream();
+          hipCHECK(hipStreamWaitEvent(due, fork, 0));
+          const int64_t f2 = prevFork(prevFork((int64_t)li));
+          if (f2 >= 0 && optDone[f2]) hipCHECK(hipStreamWaitEvent(due, optDone[f2], 0));
+          if (lr.defMid > lr.defBegin) {
+            waitGather(due, lr.defWaitGatherMid, waitedDue);
+            timer.begin(kProfUpdate, due);
+            launchUpdate(plan, lr.defBegin, lr.defMid, ref, due, nullptr, 0, sym.bulkExtraLds);
+            timer.end();
+          }
+          defDone[li] = sym.eventFromPool();
+          hipCHECK(hipEventRecord(defDone[li], due));
+          if (lr.defEnd > lr.defMid) {
+            waitGather(sym.sideStream(), lr.defWaitGatherEnd, waitedSide);
+            timer.begin(kProfUpdate, sym.sideStream());
+            launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+            timer.end();
+          }
+          optDone[li] = sym.eventFromPool();
+          hipCHECK(hipEventRecord(optDone[li], sym.sideStream()));
+          sideUsed = dueUsed = true;
+          return;
+        }
         if (lr.defMid > lr.defBegin) {
           waitGather(sym.sideStream(), lr.defWaitGatherMid, waitedSide);
           timer.begin(kProfUpdate, sym.sideStream());
@@ -642,19 +713,42 @@ struct HipNumericCtx : NumericCtx<T> {
         timer.begin(direct && lr.directSeg >= 0 ? kProfChainUpdate : kProfUpdate);
         const unsigned nUpd = (unsigned)(lr.updEnd - updBegin);
         if (merged) {
-          hipk::chainStep<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
+          int kMem0 = kMem, extra = 0;
+          if (kMem == 0) {  // intra-block step
+            if (earlyDiag && lr.extraDiag && !extraBroken && fuse) {
+              extra = 1;
+              extraApplied++;
+            } else {
+              extraBroken = true;
+            }
+          } else {          // block-last step: the panels that applied theirs are done
+            kMem0 = std::max(0, kMem - kTile * extraApplied);
+            extraApplied = 0;
+            extraBroken = false;
+          }
+          hipk::chainStep<BT><<<dim3(nUpd + extra, gy.y), 256, 0, sym.stream>>>(
               plan.host.panels[lr.directPanel], plan.host.segs[lr.directSeg], (int)nUpd, nextPanel,
               fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
               memOff, kMem, (lookahead && batchSize == 1 && sym.bulkYield) ? sym.yieldWord() : nullptr,
-              sym.traceLaunchId++);
+              sym.traceLaunchId++, kMem0, extra);
           potrfFused = fuse;
         } else if (fuse) {
+          if (extraApplied > 0) {
+            throw std::runtime_error("HIP backend: internal error (early diagonal updates applied "
+                                     "before a step that is not merged)");
+          }
+          extraBroken = true;
           const SegDesc& sd = plan.host.segs[lr.directSeg];
           hipk::updateTileDirectPotrf<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
               plan.host.srcs[sd.src], sd, (int)nUpd, nextPanel, ref, splitK, dinvNext,
               stage ? rawNext : nullptr, 2 * rawSlot);
           potrfFused = true;
         } else if (direct && lr.directSeg >= 0) {
+          if (extraApplied > 0) {
+            throw std::runtime_error("HIP backend: internal error (early diagonal updates applied "
+                                     "before a step that is not merged)");
+          }
+          extraBroken = true;
           const SegDesc& sd = plan.host.segs[lr.directSeg];
           hipk::updateTileDirect<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
               plan.host.srcs[sd.src], sd, (int)nUpd, ref, stage ? rawNext : nullptr, nextPanel.nb,
@@ -679,9 +773,14 @@ struct HipNumericCtx : NumericCtx<T> {
         }
       }
     }
-    if (sideUsed) {  // join: everything on the side stream happens-before what follows
+    if (sideUsed) {  // join: everything on the side stream(s) happens-before what follows
       hipEvent_t join = sym.eventFromPool();
       hipCHECK(hipEventRecord(join, sym.sideStream()));
+      hipCHECK(hipStreamWaitEvent(sym.stream, join, 0));
+    }
+    if (dueUsed) {
+      hipEvent_t join = sym.eventFromPool();
+      hipCHECK(hipEventRecord(join, sym.dueSideStream()));
       hipCHECK(hipStreamWaitEvent(sym.stream, join, 0));
     }
     // (and everything on the elimination stream)

@@ -2011,7 +2011,13 @@ template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void chainStep(
     PanelDesc pd, SegDesc sd, int nTasks, PanelDesc next, int fuse, DataRef<T> dref,
     const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase,
-    int64_t memOff, int kMem, unsigned* yieldFlag, int traceId) {
+    int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag) {
+  // kMem0 <= kMem: source columns workgroup 0 still has to apply from memory to tile (0,0), the
+  // LAST kMem0 of the kMem ones -- the earlier panels of the block applied theirs already, each in
+  // its own step (extraDiag: one more workgroup, the diagonal tile just past the segment's columns
+  // = the next outer block's tile (0,0), rank-nb, with atomics: lookahead units of the side stream
+  // may be working on that tile too).  The block-last step's potrf workgroup then starts from a
+  // plain rank-nb update like every other step instead of a rank-256 one (10-25 us per block).
   __shared__ T XB[kTile * kXbLd];
   BSP_EXTENT_BEGIN(traceId);
   static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd <= kTile * kXbLd, "potrf LDS fits in XB");
@@ -2033,11 +2039,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     T* Ld = XB + 4 * kPanelWidth * 4;
     ChainTile<T> ct;
     const int ri = 16 * w + n;
-    if (kMem == 0) ct.load(rawIn, Lkk, dinv, lda, nb, ri, ri, rowsBelow, segEnd, true);
+    if (kMem0 == 0) ct.load(rawIn, Lkk, dinv, lda, nb, ri, ri, rowsBelow, segEnd, true);
     auto pre = [&](Acc* acc) {
       Acc D[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-      if (kMem > 0) {
-        ChainTile<T>::multiplyMem(data + memOff, lda, kMem, 0, 0, rowsBelow, segEnd, true, XB, D);
+      if (kMem0 > 0) {
+        ChainTile<T>::multiplyMem(data + memOff + (kMem - kMem0), lda, kMem0, 0, 0, rowsBelow, segEnd,
+                                  true, XB, D);
         ct.load(rawIn, Lkk, dinv, lda, nb, ri, ri, rowsBelow, segEnd, true);
       }
       ct.solve(nb, XB, P + (int64_t)ri * lda);
@@ -2059,17 +2066,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   __builtin_amdgcn_s_setprio(BSP_TILE_PRIO);
   BSP_STAMP_TILE(4);
+  const bool extra = extraDiag && (int)blockIdx.x == nTasks;  // (grid = nTasks + 1 then)
   int idx = fuse ? 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1) : xcdContiguous(blockIdx.x, nTasks);
   int colTile = sd.q0, rowTile;
-  for (;;) {
-    const int cnt = (rowsBelow - colTile + kTile - 1) / kTile;
-    if (idx < cnt) {
-      rowTile = colTile + kTile * idx;
-      break;
+  if (extra) {
+    rowTile = colTile = segEnd;
+  } else {
+    for (;;) {
+      const int cnt = (rowsBelow - colTile + kTile - 1) / kTile;
+      if (idx < cnt) {
+        rowTile = colTile + kTile * idx;
+        break;
+      }
+      idx -= cnt;
+      colTile += kTile;
     }
-    idx -= cnt;
-    colTile += kTile;
   }
+  const int colEnd = extra ? segEnd + kTile : segEnd;  // columns this tile may write
   const int ri = rowTile + 16 * w + n, rj = colTile + 16 * w + n;
   Acc D[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   if (kMem > 0) {
@@ -2077,7 +2090,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                               rowTile == colTile, XB, D);
   }
   ChainTile<T> ct;
-  ct.load(rawIn, Lkk, dinv, lda, nb, ri, rj, rowsBelow, segEnd, rowTile == colTile);
+  ct.load(rawIn, Lkk, dinv, lda, nb, ri, rj, rowsBelow, colEnd, rowTile == colTile);
   // (column tile q0 covers every row tile once: its workgroups store X_i in place)
   ct.solve(nb, XB, colTile == sd.q0 ? P + (int64_t)(ct.actI ? ri : 0) * lda : nullptr);
   BSP_STAMP_TILE(5);
@@ -2087,7 +2100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   T old[16];
 #pragma unroll
   for (int t = 0; t < 4; t++) {
-    const int qc = min(colTile + 16 * t + n, segEnd - 1);
+    const int qc = min(colTile + 16 * t + n, colEnd - 1);
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
       const int qr = min(rowTile + 16 * w + Mfma<T>::row(lane, reg), rowsBelow - 1);
@@ -2104,11 +2117,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
       const int qr = rowTile + 16 * w + Mfma<T>::row(lane, reg);
-      if (qc < segEnd && qr < rowsBelow && qr >= qc && qr >= sd.rowMin) {
-        const T val = old[t * 4 + reg] - D[t][reg];
-        tgt[(int64_t)qr * sd.tgtStride + qc] = val;
-        if (rawOutBase && colTile == 0 && qc < nbNext && qr >= nbNext) {
-          rawOut[(int64_t)(qr - nbNext) * kTile + qc] = val;
+      if (qc < colEnd && qr < rowsBelow && qr >= qc && qr >= sd.rowMin) {
+        if (extra) {
+          atomicSub(tgt + (int64_t)qr * sd.tgtStride + qc, D[t][reg]);
+        } else {
+          const T val = old[t * 4 + reg] - D[t][reg];
+          tgt[(int64_t)qr * sd.tgtStride + qc] = val;
+          if (rawOutBase && colTile == 0 && qc < nbNext && qr >= nbNext) {
+            rawOut[(int64_t)(qr - nbNext) * kTile + qc] = val;
+          }
         }
       }
     }

@@ -582,8 +582,18 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
               // about the same time -- a single pass of rank 256 x pending would leave the launch
               // waiting for its few longest tiles); several units on one target in one launch
               // accumulate with atomics (sd.pad = 1)
+              // DUE STREAM (default; BSP_DUE_STREAM=0: one side stream as before): the due units
+              // (c = b + 2) run on a stream of their own beside the optional ones instead of in
+              // front of them.  Units of different launches that may then overlap on one column
+              // block accumulate with atomics: every due unit, and the optional units that reach
+              // the column block the NEXT block's due units go to (c = b + 3).
+              static const bool dueStream = [] {
+                const char* e = std::getenv("BSP_DUE_STREAM");
+                return !(e && e[0] == '0');
+              }();
               auto pushUnit = [&](int64_t c, int32_t outerKind) {
-                const int32_t multi = pendingFrom[c] < b ? 1 : 0;
+                const int32_t multi =
+                    (pendingFrom[c] < b || (dueStream && (outerKind == 2 || c == b + 3))) ? 1 : 0;
                 for (int64_t sb = pendingFrom[c]; sb <= b; sb++) {
                   SrcDesc fs = sr;
                   fs.off = g.diagOff + blockEnd * n + sb * kOuterWidth;
@@ -851,13 +861,17 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             if (rowMajor) {
               for (int32_t rT = sd.q0; rT < sr.rowsBelow; rT += step) {
                 for (int32_t cT = sd.q0; cT < sd.q0 + sd.m && cT <= rT; cT += step) {
-                  dst.push_back(UpdTask{(int32_t)s, rT, cT, atomic});
+                  // (the top-left tile of a column block is its tile (0,0): the chain may be
+                  //  applying early rank-64 updates to it at the same time, LevelRange::extraDiag)
+                  const int32_t a = (atomic || (rT == sd.q0 && cT == sd.q0)) ? 1 : 0;
+                  dst.push_back(UpdTask{(int32_t)s, rT, cT, a});
                 }
               }
             } else {
               for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += step) {
                 for (int32_t rT = cT; rT < sr.rowsBelow; rT += step) {
-                  dst.push_back(UpdTask{(int32_t)s, rT, cT, atomic});
+                  const int32_t a = (atomic || (rT == sd.q0 && cT == sd.q0)) ? 1 : 0;
+                  dst.push_back(UpdTask{(int32_t)s, rT, cT, a});
                 }
               }
             }
@@ -933,6 +947,16 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         if (chain && lr.directSeg >= 0) {
           const SegDesc& sd = plan.segs[lr.directSeg];
           const PanelDesc& next = plan.panels[buckets[bi + 1][0].panel];
+          {
+            // intra-block step (rank-nb, its own block's remaining columns) with a full 64-column
+            // tile (0,0) of a following block inside the lump
+            const PanelDesc& pd0 = plan.panels[bucket[0].panel];
+            const SrcDesc& sr0 = plan.srcs[sd.src];
+            if (!sd.outer && sd.kind == kSegIntra && sd.q0 == 0 && sr0.K == pd0.nb &&
+                pd0.nb == kPanelWidth && pd0.nRest - sd.m >= kTile) {
+              lr.extraDiag = 1;
+            }
+          }
           // (a narrower next panel does not fill tile 0: its rows below the panel would be missed)
           if (sd.q0 == 0 && sd.rowMin == 0 && sd.tgtBase == next.diagOff &&
               sd.tgtStride == next.lda) {

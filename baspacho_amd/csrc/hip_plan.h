@@ -124,6 +124,10 @@ struct LevelRange {
   // this level's first launch on the execution stream / before its two deferred launches on the
   // side stream (-1: none beyond what was already waited for)
   int32_t waitGather = -1, defWaitGatherMid = -1, defWaitGatherEnd = -1;
+  // intra-block step of a chain whose outer block is followed by another one: the step may also
+  // apply its panel's rank-nb update to the NEXT block's tile (0,0) (chainStep, extraDiag), so that
+  // the block-last step's potrf workgroup does not have to apply the whole block from memory
+  int32_t extraDiag = 0;
 };
 
 // One work item of the gather-form sparse-elimination update: a target block (sj,si) of the
