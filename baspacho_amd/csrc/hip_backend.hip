@@ -399,11 +399,14 @@ struct HipSymbolicCtx : SymbolicCtx {
     }
     return reinterpret_cast<unsigned*>(yieldBuf.ptr);
   }
+  // (BSP_DUE_PRIO=1: highest stream priority for the due units -- measured: no effect)
   hipStream_t dueSideStream() {
     if (!sideDue) {
       int least = 0, greatest = 0;
       hipCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      hipCHECK(hipStreamCreateWithPriority(&sideDue, hipStreamNonBlocking, least));
+      const char* e = std::getenv("BSP_DUE_PRIO");
+      const bool high = e && e[0] == '1';  // (measured: no effect either way)
+      hipCHECK(hipStreamCreateWithPriority(&sideDue, hipStreamNonBlocking, high ? greatest : least));
     }
     return sideDue;
   }
@@ -667,7 +670,7 @@ struct HipNumericCtx : NumericCtx<T> {
           // units forked two blocks ago, whose far columns are plain read-modify-write.
           hipStream_t due = sym.dueSideStream();
           hipCHECK(hipStreamWaitEvent(due, fork, 0));
-          const int64_t f2 = prevFork(prevFork((int64_t)li));
+          const int64_t f2 = lr.optWaitLevel;
           if (f2 >= 0 && optDone[f2]) hipCHECK(hipStreamWaitEvent(due, optDone[f2], 0));
           if (lr.defMid > lr.defBegin) {
             waitGather(due, lr.defWaitGatherMid, waitedDue);
@@ -683,8 +686,10 @@ struct HipNumericCtx : NumericCtx<T> {
             launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
             timer.end();
           }
-          optDone[li] = sym.eventFromPool();
-          hipCHECK(hipEventRecord(optDone[li], sym.sideStream()));
+          if (lr.defEnd > lr.defMid) {  // (an early-due level has no optional units)
+            optDone[li] = sym.eventFromPool();
+            hipCHECK(hipEventRecord(optDone[li], sym.sideStream()));
+          }
           sideUsed = dueUsed = true;
           return;
         }

@@ -499,8 +499,16 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     int32_t count = 0;
     const int64_t n = g.width;
     vector<int64_t> pendingFrom;  // per column block of this lump (lookahead schedule, see below)
+    static const bool earlyDue = [] {
+      const char* e = std::getenv("BSP_EARLY_DUE");
+      const char* d = std::getenv("BSP_DUE_STREAM");
+      // (opt-in: measured 7.26-7.40 ms against 7.15-7.21 on BAL-871 -- the K = 192 + 64 split
+      //  costs the side streams more than the earlier start gives back)
+      return (e && e[0] == '1') && !(d && d[0] == '0');
+    }();
     for (int64_t blockStart = 0; blockStart < n; blockStart += kOuterWidth) {
       const int64_t blockEnd = std::min<int64_t>(n, blockStart + kOuterWidth);
+      int64_t earlyDueCols = 0;  // leading columns of this block whose due unit (c = b + 2) went early
       for (int64_t c0 = blockStart; c0 < blockEnd; c0 += kPanelWidth, count++) {
         const int32_t nb = (int32_t)std::min<int64_t>(kPanelWidth, blockEnd - c0);
         PanelDesc pd;
@@ -535,6 +543,41 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           s.tgtBase = g.diagOff + (c0 + nb) * n + (c0 + nb);
           s.tgtStride = (int32_t)n;
           plan.segs.push_back(s);
+        }
+        // EARLY DUE: the due unit of this block (to column block b + 2) is what the chain waits for
+        // at the end of the NEXT block, and it is launched beside a saturated GPU.  Its first 192
+        // source columns are final one chain step before the block is complete: they go now, and
+        // only the last panel's 64 columns are left for the block boundary (both accumulate with
+        // atomics; same stream, in order).
+        if (earlyDue && blockEnd - blockStart == kOuterWidth && c0 + nb == blockEnd - kPanelWidth &&
+            nb == kPanelWidth) {
+          const int64_t b = blockStart / kOuterWidth;
+          const int64_t numBlocks = (n + kOuterWidth - 1) / kOuterWidth;
+          const int64_t c = b + 2;
+          if (c < numBlocks && (int64_t)pendingFrom.size() == numBlocks && pendingFrom[c] == b) {
+            SrcDesc fs{};
+            fs.off = g.diagOff + blockEnd * n + blockStart;
+            fs.lda = (int32_t)n;
+            fs.K = (int32_t)(kOuterWidth - kPanelWidth);
+            fs.nRest = (int32_t)(n - blockEnd);
+            fs.rowsBelow = (int32_t)(fs.nRest + g.rowsBelow);
+            fs.lumpRowBase = lumpRowBase;
+            plan.srcs.push_back(fs);
+            SegDesc u{};
+            u.src = (int32_t)plan.srcs.size() - 1;
+            u.kind = kSegIntra;
+            u.outer = 4;
+            u.lump = (int32_t)l;
+            u.q0 = (int32_t)(c * kOuterWidth - blockEnd);
+            u.m = (int32_t)std::min<int64_t>(kOuterWidth, n - c * kOuterWidth);
+            u.tgtBase = g.diagOff + blockEnd * n + blockEnd;
+            u.tgtStride = (int32_t)n;
+            u.pad = 1;
+            plan.segs.push_back(u);
+            plan.segColBlock.resize(plan.segs.size(), -1);
+            plan.segColBlock.back() = (int32_t)c;
+            earlyDueCols = fs.K;
+          }
         }
         if (c0 + nb == blockEnd) {  // the outer block is complete
           SrcDesc sr{};
@@ -598,6 +641,11 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                   SrcDesc fs = sr;
                   fs.off = g.diagOff + blockEnd * n + sb * kOuterWidth;
                   fs.K = (int32_t)(std::min<int64_t>(blockEnd, (sb + 1) * kOuterWidth) - sb * kOuterWidth);
+                  if (sb == b && c == b + 2 && earlyDueCols > 0) {
+                    // (the block's leading columns went ahead one chain step earlier: EARLY DUE)
+                    fs.off += earlyDueCols;
+                    fs.K -= (int32_t)earlyDueCols;
+                  }
                   plan.srcs.push_back(fs);
                   SegDesc u = s;
                   u.src = (int32_t)plan.srcs.size() - 1;
@@ -806,6 +854,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
   // ---- emit task lists level by level
   auto emitLevels = [&](const vector<vector<PanelBuild>>& buckets, vector<LevelRange>& out) {
     std::map<int32_t, int64_t> lastDeferredLevel;  // lump -> level index that deferred tiles
+    std::map<int32_t, std::vector<int64_t>> blockForks;  // lump -> its block-boundary fork levels
     for (const auto& bucket : buckets) {
       LevelRange lr;
       lr.panelBegin = (int64_t)plan.levelPanels.size();
@@ -852,7 +901,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             // operand A_i once for all of them and keeps the unit's few column operands B_j (<= 0.5
             // MB) in its L2.  Column-major order handed the column tiles of a row to four different
             // XCDs, i.e. every 128 KB row operand crossed the fabric four times.
-            const bool late = sd.outer == 3;
+            const bool late = sd.outer == 3;  // (2: due at the block boundary, 4: early due)
             vector<UpdTask>& dst = late ? deferredLate : deferred;
             static const bool rowMajor = [] {
               const char* e = std::getenv("BSP_BULK_ROW_MAJOR");
@@ -888,7 +937,19 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
               }
             }
           }
-          if (anyDeferred) lastDeferredLevel[sd.lump] = levelIdx;
+          if (anyDeferred) {
+            // due units must not overtake the optional units forked two block boundaries ago
+            auto& forks = blockForks[sd.lump];
+            if (sd.outer == 4) {  // early due (one step before the boundary): not a fork of its own
+              if (forks.size() >= 2) lr.optWaitLevel = std::max(lr.optWaitLevel, forks[forks.size() - 2]);
+            } else {
+              if (forks.empty() || forks.back() != levelIdx) {
+                if (forks.size() >= 2) lr.optWaitLevel = std::max(lr.optWaitLevel, forks[forks.size() - 2]);
+                forks.push_back(levelIdx);
+              }
+              lastDeferredLevel[sd.lump] = levelIdx;
+            }
+          }
           const double R = double(sr.rowsBelow - sd.q0), m = double(sd.m);
           plan.updElems += m * R - m * (m - 1) / 2;
           plan.updFlops += 2.0 * sr.K * (m * R - m * (m - 1) / 2);

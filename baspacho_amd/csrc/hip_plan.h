@@ -128,6 +128,9 @@ struct LevelRange {
   // apply its panel's rank-nb update to the NEXT block's tile (0,0) (chainStep, extraDiag), so that
   // the block-last step's potrf workgroup does not have to apply the whole block from memory
   int32_t extraDiag = 0;
+  // due-stream mode: level whose OPTIONAL lookahead units (forked two outer blocks earlier: plain
+  // read-modify-write on far columns) must be complete before this level's due units start; -1
+  int64_t optWaitLevel = -1;
 };
 
 // One work item of the gather-form sparse-elimination update: a target block (sj,si) of the
