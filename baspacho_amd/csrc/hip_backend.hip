@@ -484,9 +484,11 @@ struct HipNumericCtx : NumericCtx<T> {
   // ask for 6 KB so that only THREE of their workgroups fit on a CU (3 x 41 KB), leaving 37 KB for
   // a workgroup of the critical-path kernels (trsm needs 33.5 KB); with four resident bulk
   // workgroups the trsm of the next panel was starved for the whole bulk update (273 us vs 17 us).
+  // atomicMask: which bits of a task's `atomic` field count (bit 1 = "launches of two side streams
+  // may meet": only in due-stream mode)
   void launchUpdate(DevPlan& plan, int64_t begin, int64_t end, hipk::DataRef<BT> ref,
                     hipStream_t stream, BT* altTarget = nullptr, int64_t altStride = 0,
-                    unsigned extraLds = 0) {
+                    unsigned extraLds = 0, int atomicMask = 1) {
     if (sym.bulkKernel && altTarget == nullptr && end < (int64_t)plan.slowPrefix.size() &&
         plan.slowPrefix[end] == plan.slowPrefix[begin]) {
       // (32 KB of static LDS instead of updateTile's 34.8: 3 KB more padding keeps it at three
@@ -495,13 +497,13 @@ struct HipNumericCtx : NumericCtx<T> {
       // (cooperative CU yield, hip_kernels.h: side-stream launches of a single matrix only)
       const unsigned* yf = (extraLds && batchSize == 1 && sym.bulkYield) ? sym.yieldWord() : nullptr;
       hipk::updateTileBulk<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, pad,
-                                stream>>>(plan.updTasksFat.as<UpdTaskFat>() + begin, ref, yf);
+                                stream>>>(plan.updTasksFat.as<UpdTaskFat>() + begin, ref, yf, atomicMask);
       return;
     }
     hipk::updateTile<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, extraLds, stream>>>(
         plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(), plan.updTasks.as<UpdTask>() + begin,
         plan.chainOffTab.as<int64_t>(), plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(),
-        plan.rowColOff.as<int32_t>(), ref, altTarget, altStride);
+        plan.rowColOff.as<int32_t>(), ref, altTarget, altStride, atomicMask);
   }
 
   // One level = potrf -> trsm -> update on the execution stream.  Deferred (lookahead) tiles go to
@@ -527,7 +529,11 @@ struct HipNumericCtx : NumericCtx<T> {
     };
     vector<hipEvent_t> defDone(levels.size(), nullptr);  // due units of a level complete
     vector<hipEvent_t> optDone(levels.size(), nullptr);  // ... its optional units (due-stream mode)
-    const bool dueStream = sym.dueStream && !sym.mergeDeferred;
+    // (fp32: its atomics cost more than the second stream returns -- BAL-871 5.86 against 5.22 ms,
+    //  BAL-1723 20.5 against 18.8 -- so single-precision calls keep the one-side-stream order, and
+    //  the tasks' "two streams may meet" bit is masked off)
+    const bool dueStream = sym.dueStream && !sym.mergeDeferred && sizeof(BT) == 8;
+    const int sideMask = dueStream ? 3 : 1;
     // fork level of the same lump's previous block (-1: none)
     auto prevFork = [&](int64_t f) -> int64_t { return f >= 0 ? levels[f].waitDefLevel : -1; };
     auto waitDeferred = [&](int64_t f) {
@@ -657,7 +663,7 @@ struct HipNumericCtx : NumericCtx<T> {
           // (experiment: due and optional units of a block as ONE launch, due tiles first)
           waitGather(sym.sideStream(), lr.defWaitGatherEnd, waitedSide);
           timer.begin(kProfUpdate, sym.sideStream());
-          launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+          launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds, sideMask);
           timer.end();
           defDone[li] = sym.eventFromPool();
           hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
@@ -675,7 +681,7 @@ struct HipNumericCtx : NumericCtx<T> {
           if (lr.defMid > lr.defBegin) {
             waitGather(due, lr.defWaitGatherMid, waitedDue);
             timer.begin(kProfUpdate, due);
-            launchUpdate(plan, lr.defBegin, lr.defMid, ref, due, nullptr, 0, sym.bulkExtraLds);
+            launchUpdate(plan, lr.defBegin, lr.defMid, ref, due, nullptr, 0, sym.bulkExtraLds, sideMask);
             timer.end();
           }
           defDone[li] = sym.eventFromPool();
@@ -683,7 +689,7 @@ struct HipNumericCtx : NumericCtx<T> {
           if (lr.defEnd > lr.defMid) {
             waitGather(sym.sideStream(), lr.defWaitGatherEnd, waitedSide);
             timer.begin(kProfUpdate, sym.sideStream());
-            launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+            launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds, sideMask);
             timer.end();
           }
           if (lr.defEnd > lr.defMid) {  // (an early-due level has no optional units)
@@ -696,7 +702,7 @@ struct HipNumericCtx : NumericCtx<T> {
         if (lr.defMid > lr.defBegin) {
           waitGather(sym.sideStream(), lr.defWaitGatherMid, waitedSide);
           timer.begin(kProfUpdate, sym.sideStream());
-          launchUpdate(plan, lr.defBegin, lr.defMid, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+          launchUpdate(plan, lr.defBegin, lr.defMid, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds, sideMask);
           timer.end();
         }
         defDone[li] = sym.eventFromPool();
@@ -704,7 +710,7 @@ struct HipNumericCtx : NumericCtx<T> {
         if (lr.defEnd > lr.defMid) {
           waitGather(sym.sideStream(), lr.defWaitGatherEnd, waitedSide);
           timer.begin(kProfUpdate, sym.sideStream());
-          launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds);
+          launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds, sideMask);
           timer.end();
         }
         sideUsed = true;
@@ -1555,7 +1561,7 @@ HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t up
   s.chainTabEntries = (int64_t)p.chainOffTab.size();
   s.maxPanelsInLevel = p.maxPanelsInLevel;
   int64_t atomicTasks = 0;
-  for (auto& t : p.updTasks) atomicTasks += t.atomic;
+  for (auto& t : p.updTasks) atomicTasks += t.atomic ? 1 : 0;
   s.numAtomicUpdTasks = atomicTasks;
   if (!p.elimRanges.empty() && p.elimRanges.back().overlapLump >= 0 && h->elimOverlap) {
     s.numGatherGroups = (int64_t)p.elimRanges.back().groupItem.size() - 1;

@@ -1333,7 +1333,8 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
                                                   const UpdTask* tasks, const int64_t* chainOffTab,
                                                   const int32_t* rowChain, const int32_t* rowLocal,
                                                   const int32_t* rowColOff, DataRef<T> dref,
-                                                  T* altTarget = nullptr, int64_t altStride = 0) {
+                                                  T* altTarget = nullptr, int64_t altStride = 0,
+                                                  int atomicMask = 3) {
   // altTarget: write the (negated) product into a separate buffer instead of `data`
   // (per-op saveSyrkGemm: the frontal temp buffer, one slice per batch entry)
   constexpr int KC = kUpdChunk, LD = KC + 2;
@@ -1474,7 +1475,7 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
         ptr[t * 4 + reg] = tbase + rowBase[rIn] + co;
       }
     }
-    if (task.atomic) {
+    if (task.atomic & atomicMask) {
 #pragma unroll
       for (int t = 0; t < 4; t++) {
 #pragma unroll
@@ -1524,7 +1525,7 @@ struct BulkSwizzle {
 // As, Bs: kTile * kUpdChunk values each, 16-byte aligned.
 template <typename T>
 __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T* As, T* Bs,
-                                             const unsigned* yieldFlag = nullptr) {
+                                             const unsigned* yieldFlag = nullptr, int atomicMask = 3) {
   constexpr int KC = kUpdChunk, E = BulkSwizzle<T>::E, SLOTS = KC / E, RPI = 64 / SLOTS;
   constexpr int NI = kTile / (4 * RPI);  // wave instructions per operand and wave
   typedef __attribute__((address_space(1))) const void* GV;
@@ -1585,7 +1586,9 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
     if (!skipUpper) {
 #pragma unroll
       for (int k0 = 0; k0 < KC; k0 += 4) {
-        // (row r, column k0 + lk): slot (k0 + lk) / E moves by k0 / E under the XOR key
+        // (row r, column k0 + lk): slot (k0 + lk) / E moves by k0 / E under the XOR key.  (Reading
+        //  the operands of step s+1 before the MFMAs of step s -- two register sets, pinned with a
+        //  sched_barrier -- was measured slower: 4.02 against 3.8 ms for the serialised bulk.)
         const int s = k0 / E;
         const T a0 = As[oa0 + E * (((lk / E + s) ^ ka0) - ((lk / E) ^ ka0))];
         const T a1 = As[oa1 + E * (((lk / E + s) ^ ka1) - ((lk / E) ^ ka1))];
@@ -1600,7 +1603,7 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
   }
   if (!skipUpper) {
     const Acc* accs[4] = {&acc00, &acc01, &acc10, &acc11};
-    if (t.atomic) {
+    if (t.atomic & atomicMask) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int qc = t.colTile + wc + (q & 1) * 16 + li;
@@ -1642,12 +1645,11 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
 
 template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void updateTileBulk(
-    const UpdTaskFat* tasks, DataRef<T> dref,
-                                                      const unsigned* yieldFlag) {
+    const UpdTaskFat* tasks, DataRef<T> dref, const unsigned* yieldFlag, int atomicMask) {
   __shared__ __attribute__((aligned(16))) T As[kTile * kUpdChunk];
   __shared__ __attribute__((aligned(16))) T Bs[kTile * kUpdChunk];
   const UpdTaskFat t = tasks[blockIdx.x];
-  bulkTileBody<T>(t, pickData(dref), As, Bs, yieldFlag);
+  bulkTileBody<T>(t, pickData(dref), As, Bs, yieldFlag, atomicMask);
 }
 
 // K5d  direct variant for the update tiles of a one-panel level that all belong to ONE

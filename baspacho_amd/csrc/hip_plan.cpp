@@ -572,7 +572,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             u.m = (int32_t)std::min<int64_t>(kOuterWidth, n - c * kOuterWidth);
             u.tgtBase = g.diagOff + blockEnd * n + blockEnd;
             u.tgtStride = (int32_t)n;
-            u.pad = 1;
+            u.pad = 2;
             plan.segs.push_back(u);
             plan.segColBlock.resize(plan.segs.size(), -1);
             plan.segColBlock.back() = (int32_t)c;
@@ -635,8 +635,11 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                 return !(e && e[0] == '0');
               }();
               auto pushUnit = [&](int64_t c, int32_t outerKind) {
-                const int32_t multi =
-                    (pendingFrom[c] < b || (dueStream && (outerKind == 2 || c == b + 3))) ? 1 : 0;
+                // bit 0: several units on this target in one launch; bit 1: the target may be met
+                // by a launch of the OTHER side stream (due-stream mode; the kernels take a mask, so
+                // a call that orders the launches on one stream ignores this bit)
+                const int32_t multi = (pendingFrom[c] < b ? 1 : 0) |
+                                      ((dueStream && (outerKind == 2 || c == b + 3)) ? 2 : 0);
                 for (int64_t sb = pendingFrom[c]; sb <= b; sb++) {
                   SrcDesc fs = sr;
                   fs.off = g.diagOff + blockEnd * n + sb * kOuterWidth;
@@ -885,7 +888,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         for (int64_t s = panelSegBegin[pb.panel]; s < panelSegEnd[pb.panel]; s++) {
           const SegDesc& sd = plan.segs[s];
           const SrcDesc& sr = plan.srcs[sd.src];
-          const int32_t atomic = (sd.kind == kSegBoard && hits[sd.tgtBase] > 1) || sd.pad ? 1 : 0;
+          // (bit 1: only when launches of two side streams can meet, see pushUnit)
+          const int32_t atomic = ((sd.kind == kSegBoard && hits[sd.tgtBase] > 1) || (sd.pad & 1) ? 1 : 0) |
+                                 (sd.pad & 2);
           if (sd.outer == 1) {
             // this block-wide update touches columns that the previous block's deferred tiles
             // of the same lump also touch: they must have completed
@@ -912,14 +917,14 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                 for (int32_t cT = sd.q0; cT < sd.q0 + sd.m && cT <= rT; cT += step) {
                   // (the top-left tile of a column block is its tile (0,0): the chain may be
                   //  applying early rank-64 updates to it at the same time, LevelRange::extraDiag)
-                  const int32_t a = (atomic || (rT == sd.q0 && cT == sd.q0)) ? 1 : 0;
+                  const int32_t a = atomic | ((rT == sd.q0 && cT == sd.q0) ? 1 : 0);
                   dst.push_back(UpdTask{(int32_t)s, rT, cT, a});
                 }
               }
             } else {
               for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += step) {
                 for (int32_t rT = cT; rT < sr.rowsBelow; rT += step) {
-                  const int32_t a = (atomic || (rT == sd.q0 && cT == sd.q0)) ? 1 : 0;
+                  const int32_t a = atomic | ((rT == sd.q0 && cT == sd.q0) ? 1 : 0);
                   dst.push_back(UpdTask{(int32_t)s, rT, cT, a});
                 }
               }

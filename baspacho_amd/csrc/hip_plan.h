@@ -70,7 +70,8 @@ struct UpdTask {
   int32_t seg;
   int32_t rowTile;  // first below-row index of the tile rows
   int32_t colTile;  // first below-row index of the tile cols
-  int32_t atomic;   // 1: several panels of this level hit the same target lump
+  int32_t atomic;   // bit 0: several writers in one launch (panels of a level, units of a launch);
+                    // bit 1: writers of two side streams may meet (kernels mask it off otherwise)
 };
 
 // Self-contained form of an UpdTask of an intra-lump segment whose source width is a multiple of
