@@ -235,6 +235,38 @@ struct LaunchTimer {
   }
 };
 
+// The auxiliary streams of the lookahead schedule are shared by every Solver of the process, one
+// set per device, created on first use and kept for the life of the process.  HIP multiplexes its
+// streams onto a handful of hardware queues (4 by default): with streams of their own, a second
+// Solver's side streams landed on the queue of the execution stream and its lookahead work ran
+// behind the chain instead of beside it (64 x GRID 17.4 instead of 14.5 ms, the fp32 BAL-1723 factor
+// 26 instead of 19 ms, while another Solver was merely alive: tools/exp_order.py).  One factor() at a
+// time per Solver is the contract (Solver.h); two Solvers factoring concurrently share these
+// streams and are merely ordered on them.
+struct SharedStreams {
+  hipStream_t side = nullptr, due = nullptr, elim = nullptr;
+};
+inline SharedStreams& sharedStreams() {
+  static std::mutex mu;
+  static std::map<int, SharedStreams> perDevice;
+  int dev = 0;
+  hipCHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  SharedStreams& st = perDevice[dev];
+  if (!st.side) {
+    int least = 0, greatest = 0;
+    hipCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // lowest priority; neither stream priorities nor CU masks separate the bulk tiles from the
+    // chain on this stack (hipExtStreamCreateWithCUMask is not honoured: a masked saturating kernel
+    // ran on all 256 CUs, tools/throttle_probe.hip), what does is s_setprio inside the chain kernels
+    hipCHECK(hipStreamCreateWithPriority(&st.side, hipStreamNonBlocking, least));
+    const char* e = std::getenv("BSP_DUE_PRIO");  // (=1: highest priority for the due units -- measured: no effect)
+    hipCHECK(hipStreamCreateWithPriority(&st.due, hipStreamNonBlocking, (e && e[0] == '1') ? greatest : least));
+    hipCHECK(hipStreamCreateWithPriority(&st.elim, hipStreamNonBlocking, least));
+  }
+  return st;
+}
+
 // per-op statistics of the per-op boundary (OpStat, Utils.h:48-121 of the reference): HIP events
 // around the launches of one op, read back synchronously -- only while stats are enabled
 struct OpTimer {
@@ -284,9 +316,6 @@ struct HipSymbolicCtx : SymbolicCtx {
 
   virtual ~HipSymbolicCtx() override {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
-    if (side) (void)hipStreamDestroy(side);
-    if (elim) (void)hipStreamDestroy(elim);
-    if (sideDue) (void)hipStreamDestroy(sideDue);
   }
 
   virtual void setSparseElimRanges(const vector<int64_t>& ranges) override {
@@ -378,18 +407,8 @@ struct HipSymbolicCtx : SymbolicCtx {
   virtual SolveCtxBase* createSolveCtxForType(std::type_index tIdx, int nRHS,
                                               int batchSize) override;
 
-  // side stream + event pool of the lookahead schedule (created on first use).  Lowest priority;
-  // neither stream priorities nor CU masks separate the bulk tiles from the chain on this stack
-  // (hipExtStreamCreateWithCUMask is not honoured: a masked saturating kernel ran on all 256 CUs,
-  // tools/throttle_probe.hip), what does is s_setprio inside the chain kernels.
-  hipStream_t sideStream() {
-    if (!side) {
-      int least = 0, greatest = 0;
-      hipCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      hipCHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least));
-    }
-    return side;
-  }
+  // side streams (shared, see sharedStreams) + event pool of the lookahead schedule
+  hipStream_t sideStream() { return sharedStreams().side; }
   // word of device memory through which the chain's potrf workgroup tells the bulk tiles which CU
   // it runs on (cooperative CU yield, hip_kernels.h)
   unsigned* yieldWord() {
@@ -399,25 +418,8 @@ struct HipSymbolicCtx : SymbolicCtx {
     }
     return reinterpret_cast<unsigned*>(yieldBuf.ptr);
   }
-  // (BSP_DUE_PRIO=1: highest stream priority for the due units -- measured: no effect)
-  hipStream_t dueSideStream() {
-    if (!sideDue) {
-      int least = 0, greatest = 0;
-      hipCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      const char* e = std::getenv("BSP_DUE_PRIO");
-      const bool high = e && e[0] == '1';  // (measured: no effect either way)
-      hipCHECK(hipStreamCreateWithPriority(&sideDue, hipStreamNonBlocking, high ? greatest : least));
-    }
-    return sideDue;
-  }
-  hipStream_t elimStream() {
-    if (!elim) {
-      int least = 0, greatest = 0;
-      hipCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      hipCHECK(hipStreamCreateWithPriority(&elim, hipStreamNonBlocking, least));
-    }
-    return elim;
-  }
+  hipStream_t dueSideStream() { return sharedStreams().due; }
+  hipStream_t elimStream() { return sharedStreams().elim; }
   hipEvent_t eventFromPool() {
     if (nextEvent == events.size()) {
       hipEvent_t e;
@@ -437,7 +439,6 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool lookaheadEnabled = true;
   unsigned bulkExtraLds = 6 * 1024;
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
-  hipStream_t side = nullptr, elim = nullptr, sideDue = nullptr;
   bool dueStream = true;       // due lookahead units on a stream of their own (BSP_DUE_STREAM=0: one side stream)
   bool mergeDeferred = false;  // BSP_MERGE_DEF=1: due + optional lookahead units of a block in one launch
   bool earlyDiag = true;       // intra-block chain steps pre-apply their panel to the next block's tile (0,0) (BSP_EARLY_DIAG=0 disables)
