@@ -312,6 +312,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_EARLY_DIAG")) earlyDiag = e[0] != '0';
     if (const char* e = std::getenv("BSP_MERGE_DEF")) mergeDeferred = e[0] != '0';
     if (const char* e = std::getenv("BSP_DUE_STREAM")) dueStream = e[0] != '0';
+    if (const char* e = std::getenv("BSP_DUE_SPLIT")) dueSplit = e[0] != '0';
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -441,6 +442,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
   bool dueStream = true;       // due lookahead units on a stream of their own (BSP_DUE_STREAM=0: one side stream)
   bool mergeDeferred = false;  // BSP_MERGE_DEF=1: due + optional lookahead units of a block in one launch
+  bool dueSplit = false;       // opt-in BSP_DUE_SPLIT=1: due units in two launches (first column tile / the rest), the chain's block-last step adds to the rest with atomics
   bool earlyDiag = true;       // intra-block chain steps pre-apply their panel to the next block's tile (0,0) (BSP_EARLY_DIAG=0 disables)
   bool bulkYield = true;       // bulk tiles pause on the CU of the chain's potrf workgroup (BSP_BULK_YIELD=0 disables)
   bool elimOverlap = false;    // sparse-elimination update overlapped with the dense phase (opt-in: BSP_ELIM_OVERLAP=1)
@@ -530,6 +532,7 @@ struct HipNumericCtx : NumericCtx<T> {
     };
     vector<hipEvent_t> defDone(levels.size(), nullptr);  // due units of a level complete
     vector<hipEvent_t> optDone(levels.size(), nullptr);  // ... its optional units (due-stream mode)
+    vector<hipEvent_t> due0Done(levels.size(), nullptr); // ... the first column tile of its due units
     // (fp32: its atomics cost more than the second stream returns -- BAL-871 5.86 against 5.22 ms,
     //  BAL-1723 20.5 against 18.8 -- so single-precision calls keep the one-side-stream order, and
     //  the tasks' "two streams may meet" bit is masked off)
@@ -537,10 +540,12 @@ struct HipNumericCtx : NumericCtx<T> {
     const int sideMask = dueStream ? 3 : 1;
     // fork level of the same lump's previous block (-1: none)
     auto prevFork = [&](int64_t f) -> int64_t { return f >= 0 ? levels[f].waitDefLevel : -1; };
-    auto waitDeferred = [&](int64_t f) {
+    // firstTileOnly (DUE SPLIT): the caller only needs the first column tile of the due units
+    // complete (it accumulates into the others with atomics)
+    auto waitDeferred = [&](int64_t f, bool firstTileOnly = false) {
       // everything the side streams owe to the column block this level is about to touch
       if (f < 0 || !defDone[f]) return;
-      hipCHECK(hipStreamWaitEvent(sym.stream, defDone[f], 0));
+      hipCHECK(hipStreamWaitEvent(sym.stream, (firstTileOnly && due0Done[f]) ? due0Done[f] : defDone[f], 0));
       const int64_t pf = prevFork(f);
       if (dueStream && pf >= 0 && optDone[pf]) hipCHECK(hipStreamWaitEvent(sym.stream, optDone[pf], 0));
     };
@@ -646,8 +651,14 @@ struct HipNumericCtx : NumericCtx<T> {
         timer.end();
       }
       // (a second wait on the same event would still cost a ~6 us bubble between the launches)
+      // DUE SPLIT: a merged block-last step waits for the first column tile of the due units only
+      const bool nowAtomic = merged && kMem > 0 && lookahead && dueStream && lr.waitDefLevel >= 0 &&
+                             due0Done[lr.waitDefLevel] != nullptr;
       if (!waitedDef && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
-        waitDeferred(lr.waitDefLevel);
+        waitDeferred(lr.waitDefLevel, nowAtomic);
+      }
+      if (lookahead && lr.waitDue1Level >= 0 && defDone[lr.waitDue1Level]) {
+        hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDue1Level], 0));
       }
       const bool anyDef = lr.defEnd > lr.defBegin;
       auto forkSide = [&]() {
@@ -681,9 +692,20 @@ struct HipNumericCtx : NumericCtx<T> {
           if (f2 >= 0 && optDone[f2]) hipCHECK(hipStreamWaitEvent(due, optDone[f2], 0));
           if (lr.defMid > lr.defBegin) {
             waitGather(due, lr.defWaitGatherMid, waitedDue);
-            timer.begin(kProfUpdate, due);
-            launchUpdate(plan, lr.defBegin, lr.defMid, ref, due, nullptr, 0, sym.bulkExtraLds, sideMask);
-            timer.end();
+            if (sym.dueSplit && lr.defMid0 > lr.defBegin && lr.defMid > lr.defMid0) {
+              timer.begin(kProfUpdate, due);
+              launchUpdate(plan, lr.defBegin, lr.defMid0, ref, due, nullptr, 0, sym.bulkExtraLds, sideMask);
+              timer.end();
+              due0Done[li] = sym.eventFromPool();
+              hipCHECK(hipEventRecord(due0Done[li], due));
+              timer.begin(kProfUpdate, due);
+              launchUpdate(plan, lr.defMid0, lr.defMid, ref, due, nullptr, 0, sym.bulkExtraLds, sideMask);
+              timer.end();
+            } else {
+              timer.begin(kProfUpdate, due);
+              launchUpdate(plan, lr.defBegin, lr.defMid, ref, due, nullptr, 0, sym.bulkExtraLds, sideMask);
+              timer.end();
+            }
           }
           defDone[li] = sym.eventFromPool();
           hipCHECK(hipEventRecord(defDone[li], due));
@@ -742,7 +764,7 @@ struct HipNumericCtx : NumericCtx<T> {
               plan.host.panels[lr.directPanel], plan.host.segs[lr.directSeg], (int)nUpd, nextPanel,
               fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
               memOff, kMem, (lookahead && batchSize == 1 && sym.bulkYield) ? sym.yieldWord() : nullptr,
-              sym.traceLaunchId++, kMem0, extra);
+              sym.traceLaunchId++, kMem0, extra, nowAtomic ? 1 : 0);
           potrfFused = fuse;
         } else if (fuse) {
           if (extraApplied > 0) {

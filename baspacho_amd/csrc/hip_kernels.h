@@ -2013,7 +2013,10 @@ template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void chainStep(
     PanelDesc pd, SegDesc sd, int nTasks, PanelDesc next, int fuse, DataRef<T> dref,
     const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase,
-    int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag) {
+    int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag,
+    int nowAtomic) {
+  // nowAtomic (block-last step, DUE SPLIT): the tiles right of the segment's first column tile are
+  // subtracted with atomics -- the due units of those columns may still be running on the side
   // kMem0 <= kMem: source columns workgroup 0 still has to apply from memory to tile (0,0), the
   // LAST kMem0 of the kMem ones -- the earlier panels of the block applied theirs already, each in
   // its own step (extraDiag: one more workgroup, the diagonal tile just past the segment's columns
@@ -2120,7 +2123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int reg = 0; reg < 4; reg++) {
       const int qr = rowTile + 16 * w + Mfma<T>::row(lane, reg);
       if (qc < colEnd && qr < rowsBelow && qr >= qc && qr >= sd.rowMin) {
-        if (extra) {
+        if (extra || (nowAtomic && colTile > sd.q0)) {
           atomicSub(tgt + (int64_t)qr * sd.tgtStride + qc, D[t][reg]);
         } else {
           const T val = old[t * 4 + reg] - D[t][reg];

@@ -870,7 +870,14 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       const bool chain = bucket.size() == 1 && bi + 1 < buckets.size() &&
                          buckets[bi + 1].size() == 1 &&
                          plan.panels[buckets[bi + 1][0].panel].lump == plan.panels[bucket[0].panel].lump;
-      vector<UpdTask> deferred, deferredLate;
+      vector<UpdTask> deferred, deferred1, deferredLate;  // due (first column tile) / due (rest) / optional
+      static const bool dueSplit = [] {
+        // (opt-in: measured 7.32 against 7.23 ms on BAL-871 -- the extra small launch per block
+        //  costs more than the shorter wait returns)
+        const char* e = std::getenv("BSP_DUE_SPLIT");
+        const char* d = std::getenv("BSP_DUE_STREAM");
+        return (e && e[0] == '1') && !(d && d[0] == '0');
+      }();
       int32_t maxCbMid = -1, maxCbLate = -1;  // furthest target column block of the deferred units
       int32_t nowSegs = 0, nowSeg = -1;  // segments with non-deferred 64x64 tiles in this level
       bool nowPlain = true;              // ... all intra-lump, non-atomic, untouched order
@@ -907,7 +914,10 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             // MB) in its L2.  Column-major order handed the column tiles of a row to four different
             // XCDs, i.e. every 128 KB row operand crossed the fabric four times.
             const bool late = sd.outer == 3;  // (2: due at the block boundary, 4: early due)
-            vector<UpdTask>& dst = late ? deferredLate : deferred;
+            const bool split = dueSplit && sd.outer == 2;
+            auto dstOf = [&](int32_t cT) -> vector<UpdTask>& {
+              return late ? deferredLate : (split && cT != sd.q0 ? deferred1 : deferred);
+            };
             static const bool rowMajor = [] {
               const char* e = std::getenv("BSP_BULK_ROW_MAJOR");
               return !(e && e[0] == '0');
@@ -918,14 +928,14 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                   // (the top-left tile of a column block is its tile (0,0): the chain may be
                   //  applying early rank-64 updates to it at the same time, LevelRange::extraDiag)
                   const int32_t a = atomic | ((rT == sd.q0 && cT == sd.q0) ? 1 : 0);
-                  dst.push_back(UpdTask{(int32_t)s, rT, cT, a});
+                  dstOf(cT).push_back(UpdTask{(int32_t)s, rT, cT, a});
                 }
               }
             } else {
               for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += step) {
                 for (int32_t rT = cT; rT < sr.rowsBelow; rT += step) {
                   const int32_t a = atomic | ((rT == sd.q0 && cT == sd.q0) ? 1 : 0);
-                  dst.push_back(UpdTask{(int32_t)s, rT, cT, a});
+                  dstOf(cT).push_back(UpdTask{(int32_t)s, rT, cT, a});
                 }
               }
             }
@@ -965,6 +975,8 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       lr.updEnd = (int64_t)plan.updTasks.size();
       lr.defBegin = lr.updEnd;
       plan.updTasks.insert(plan.updTasks.end(), deferred.begin(), deferred.end());
+      lr.defMid0 = (int64_t)plan.updTasks.size();
+      plan.updTasks.insert(plan.updTasks.end(), deferred1.begin(), deferred1.end());
       lr.defMid = (int64_t)plan.updTasks.size();
       plan.updTasks.insert(plan.updTasks.end(), deferredLate.begin(), deferredLate.end());
       lr.defEnd = (int64_t)plan.updTasks.size();
@@ -986,6 +998,16 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         }
       };
       if (lr.defEnd > lr.defBegin) plan.hasDeferred = true;
+      if (bucket.size() == 1) {
+        // first panel of an outer block: the column tiles 1..3 of this block received their due
+        // units from the fork two block boundaries back (DUE SPLIT)
+        const PanelDesc& pd = plan.panels[bucket[0].panel];
+        auto it = blockForks.find(pd.lump);
+        if ((pd.lda - pd.nRest - pd.nb) % kOuterWidth == 0 && it != blockForks.end() && it->second.size() >= 2) {
+          const int64_t f = it->second[it->second.size() - 2];
+          if (out[f].defMid > out[f].defMid0) lr.waitDue1Level = f;
+        }
+      }
       if (ov && bucket.size() == 1 && plan.panels[bucket[0].panel].lump == ov->overlapLump) {
         // overlapped elimination: the kernels of outer block b touch column blocks b (panel steps)
         // and b + 1 (the block-wide "now" update); a deferred launch touches up to its furthest unit
@@ -1039,7 +1061,8 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         }
       }
       xcdOrder(lr.updBegin, lr.updEnd);
-      xcdOrder(lr.defBegin, lr.defMid);
+      xcdOrder(lr.defBegin, lr.defMid0);
+      xcdOrder(lr.defMid0, lr.defMid);
       xcdOrder(lr.defMid, lr.defEnd);
       plan.maxPanelsInLevel = std::max<int64_t>(plan.maxPanelsInLevel, lr.panelEnd - lr.panelBegin);
       plan.numLaunches += 1 + (lr.trsmEnd > lr.trsmBegin) + (lr.updEnd > lr.updBegin) +
@@ -1154,7 +1177,7 @@ HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly,
         addSeg(sr, n - blockEnd, offA + blockEnd * ld + blockEnd);
       }
       lr.updEnd = (int64_t)plan.updTasks.size();
-      lr.defBegin = lr.defMid = lr.defEnd = lr.updEnd;
+      lr.defBegin = lr.defMid0 = lr.defMid = lr.defEnd = lr.updEnd;
       plan.levels.push_back(lr);
     }
   }

@@ -103,6 +103,13 @@ struct LevelRange {
   // [defBegin, defMid): the deferred tiles in the columns of the outer block AFTER the next one,
   // i.e. the only ones the next block's own update launch must wait for; they run first
   int64_t defMid = 0;
+  // DUE SPLIT (due-stream mode): [defBegin, defMid0) = the due tiles of the FIRST column tile of
+  // column block b + 2 -- what the next block's last step needs complete (it stages those columns
+  // for the block after and factors their tile (0,0)); [defMid0, defMid) = column tiles 1..3, which
+  // that step only adds to (with atomics) and which have to be complete one step later, when block
+  // b + 2 starts (waitDue1Level).  defMid0 == defMid: no split.
+  int64_t defMid0 = 0;
+  int64_t waitDue1Level = -1;  // level whose [defMid0, defMid) tiles this level needs complete
   // DIRECT chain kernels (hip_kernels.h): set when the level holds one panel; directSeg >= 0 when
   // its non-deferred tiles [updBegin, updEnd) are exactly the tiles of that one intra segment
   int32_t directPanel = -1, directSeg = -1;

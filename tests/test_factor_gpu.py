@@ -297,7 +297,7 @@ def test_lump_widths_around_panel_and_block_boundaries(dtype):
                                   "BSP_SPLIT_DIAG=0", "BSP_ELIM_FACTOR_DESC=0",
                                   "BSP_MERGED_CHAIN=0", "BSP_BULK_KERNEL=0", "BSP_EARLY_FORK=0",
                                   "BSP_MERGED_BLOCK_LAST=0", "BSP_EARLY_DIAG=0", "BSP_BULK_YIELD=0",
-                                  "BSP_BULK_ROW_MAJOR=0", "BSP_DUE_STREAM=0", "BSP_EARLY_DUE=1"])
+                                  "BSP_BULK_ROW_MAJOR=0", "BSP_DUE_STREAM=0", "BSP_EARLY_DUE=1", "BSP_DUE_SPLIT=1"])
 def test_schedule_variants(monkeypatch, knob):
     """every optimisation of the launch schedule can be switched off (the environment is read
     when the solver is created); each fallback must still factor correctly"""
