@@ -899,11 +899,18 @@ struct HipNumericCtx : NumericCtx<T> {
             plan.elimPairOffI.as<uint32_t>(), ref, (int)nWide);
         timer.end();
       }
-      const int64_t nTiny = er.tinyEnd - er.tinyBegin;
+      const int64_t nTiny9 = er.tiny9End - er.tinyBegin, nTiny = er.tinyEnd - er.tiny9End;
+      if (nTiny9 > 0) {  // 7 items per wave, 28 per workgroup
+        timer.begin(kProfElimUpdate);
+        hipk::elimGatherTiny<BT, 9><<<dim3((unsigned)((nTiny9 + 27) / 28), gy), 256, 0, sym.stream>>>(
+            plan.elimItems.as<ElimGatherItem>() + er.tinyBegin, plan.elimPairOffJ.as<uint32_t>(),
+            plan.elimPairOffI.as<uint32_t>(), ref, (int)nTiny9);
+        timer.end();
+      }
       if (nTiny > 0) {
         timer.begin(kProfElimUpdate);
-        hipk::elimGatherTiny<BT><<<dim3((unsigned)((nTiny + 15) / 16), gy), 256, 0, sym.stream>>>(
-            plan.elimItems.as<ElimGatherItem>() + er.tinyBegin, plan.elimPairOffJ.as<uint32_t>(),
+        hipk::elimGatherTiny<BT, 16><<<dim3((unsigned)((nTiny + 15) / 16), gy), 256, 0, sym.stream>>>(
+            plan.elimItems.as<ElimGatherItem>() + er.tiny9End, plan.elimPairOffJ.as<uint32_t>(),
             plan.elimPairOffI.as<uint32_t>(), ref, (int)nTiny);
         timer.end();
       }

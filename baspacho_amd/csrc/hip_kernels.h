@@ -718,35 +718,91 @@ __global__ __launch_bounds__(1024) void elimRowMfma(const ElimRowItem* rowItems,
 }
 
 // K2t  the same gather for TINY target blocks (<= 16 elements, e.g. the 3x3 blocks of automatically
-// detected elimination ranges): four items per wave, 16 lanes each, operands straight from
-// global memory (a pair's blocks are a few dozen bytes).
-template <typename T>
+// detected elimination ranges), operands straight from global memory (a pair's blocks are a few
+// dozen bytes).  Such items hold 1.4 pairs on average (GRID 82x82) and the kernel is bound by the
+// number of scattered vector-memory instructions a CU can address, not by bytes (PMC: 22 loads
+// per wave, 1.8 TB/s), so everything is arranged to need few of them:
+//  * G lanes per item, G = 9 (everything about the item fits 9 lanes: 7 items per wave) or 16 (4);
+//  * the descriptor is read one dword per lane and handed round through the LDS crossbar;
+//  * lane e fetches element e of B_j and of B_i (one contiguous block per group and operand), the
+//    rows a lane needs come from its neighbours' registers;
+//  * the first pair's offsets ride in the descriptor, those of further pairs are read G at a time;
+//  * the target is read while the blocks are on their way.
+static_assert(sizeof(ElimGatherItem) == 40 && offsetof(ElimGatherItem, pairBegin) == 8 &&
+                  offsetof(ElimGatherItem, tgtStride) == 16 && offsetof(ElimGatherItem, rows) == 20 &&
+                  offsetof(ElimGatherItem, n) == 24 && offsetof(ElimGatherItem, flags) == 26 &&
+                  offsetof(ElimGatherItem, firstJ) == 28 && offsetof(ElimGatherItem, firstI) == 32,
+              "elimGatherTiny reads the descriptor as 9 dwords");
+template <typename T, int G>
 __global__ __launch_bounds__(256) void elimGatherTiny(const ElimGatherItem* items,
                                                       const uint32_t* offJ, const uint32_t* offI,
                                                       DataRef<T> dref, int numItems) {
-  const int lane = threadIdx.x & 63, sub = lane & 15;
-  const int idx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-  if (idx >= numItems) return;
-  const ElimGatherItem it = items[idx];
+  constexpr int IPW = 64 / G;
+  const int lane = threadIdx.x & 63, grp = lane / G, sub = lane - grp * G, gbase = grp * G;
+  const int idx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * IPW + grp;
+  if (grp >= IPW || idx >= numItems) return;  // whole groups leave; all exchanges are in-group
+  const uint32_t myW = reinterpret_cast<const uint32_t*>(items + idx)[min(sub, 8)];
+  auto field = [&](int k) { return (uint32_t)__shfl((int)myW, gbase + k, 64); };
+  const int64_t tgtOff = (int64_t)((uint64_t)field(0) | ((uint64_t)field(1) << 32));
+  const int pairBegin = (int)field(2), pairEnd = (int)field(3), tgtStride = (int)field(4);
+  const uint32_t rc = field(5), nf = field(6);
+  const int rows = int(rc & 0xffffu), cols = int(rc >> 16), n = int(nf & 0xffffu);
+  const int flags = int(nf >> 16);
   GP<T> data = pickData(dref);
-  const int cols = it.cols, n = it.n, total = int(it.rows) * cols;
+  const int total = rows * cols;
   const bool live = sub < total;
   const int e = live ? sub : 0;
   const int r = e / cols, q = e - r * cols;
-  T acc = T(0);
-  for (int p = it.pairBegin; p < it.pairEnd; p++) {
-    GP<const T> Bj = data + offJ[p] + r * n;
-    GP<const T> Bi = data + offI[p] + q * n;
+  const bool writes = live && !((flags & 2) && q > r);
+  const bool atomic = flags & 1;
+  GP<T> target = data + tgtOff + (int64_t)r * tgtStride + q;
+  const T old = (writes && !atomic) ? *target : T(0);
+  const int rn = r * n, qn = q * n;
+  // (G = 9: guaranteed by the plan; G = 16: sources wider than 16 / rows take the row loads)
+  const bool small = G == 9 || __all(rows * n <= 16 && cols * n <= 16);
+  const int ej = min(sub, rows * n - 1), ei = min(sub, cols * n - 1);
+  auto dot = [&](uint32_t oj, uint32_t oi) -> T {
     T d = T(0);
+    if (small) {  // wave-uniform
+      const T vj = data[oj + ej];
+      const T vi = data[oi + ei];
+      if (n <= 4) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int kk = min(k, n - 1);
+          const T a = __shfl(vj, gbase + rn + kk, 64);
+          const T b = __shfl(vi, gbase + qn + kk, 64);
+          d += k < n ? a * b : T(0);
+        }
+      } else {
+        for (int k = 0; k < n; k++) d += __shfl(vj, gbase + rn + k, 64) * __shfl(vi, gbase + qn + k, 64);
+      }
+      return d;
+    }
+    GP<const T> Bj = data + oj + rn;
+    GP<const T> Bi = data + oi + qn;
     for (int k = 0; k < n; k++) d += Bj[k] * Bi[k];
-    acc += d;
+    return d;
+  };
+  T acc = dot(field(7), field(8));
+  const int more = pairEnd - pairBegin - 1;
+  for (int base = 0; base < more; base += G) {
+    const int cnt = min(G, more - base);
+    const int pi = pairBegin + 1 + base + min(sub, cnt - 1);
+    const int myJ = (int)offJ[pi], myI = (int)offI[pi];
+    for (int t = 0; t < cnt; t += 2) {
+      const int t1 = min(t + 1, cnt - 1);
+      const T d0 = dot((uint32_t)__shfl(myJ, gbase + t, 64), (uint32_t)__shfl(myI, gbase + t, 64));
+      const T d1 = dot((uint32_t)__shfl(myJ, gbase + t1, 64), (uint32_t)__shfl(myI, gbase + t1, 64));
+      acc += d0;
+      if (t + 1 < cnt) acc += d1;
+    }
   }
-  if (live && !((it.flags & 2) && q > r)) {
-    GP<T> target = data + it.tgtOff + (int64_t)r * it.tgtStride + q;
-    if (it.flags & 1) {
+  if (writes) {
+    if (atomic) {
       atomicSub(target, acc);
     } else {
-      *target -= acc;
+      *target = old - acc;
     }
   }
 }

@@ -272,7 +272,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
       er.rowLdsBytesF32 = accElems * 4 + maxSlots * (int32_t)sizeof(ElimRowSlot);
       er.useRowForm = true;
       er.useGather = true;
-      er.itemBegin = er.itemEnd = er.tinyBegin = er.tinyEnd = er.ldsBegin = er.ldsEnd =
+      er.itemBegin = er.itemEnd = er.tinyBegin = er.tiny9End = er.tinyEnd = er.ldsBegin = er.ldsEnd =
           (int64_t)plan.elimItems.size();
       plan.elimTargetElems += targetElems;
       lap("row form");
@@ -321,6 +321,8 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
           plan.elimPairOffI.push_back(sorted[k].offI);
         }
         it.pairEnd = (int32_t)plan.elimPairOffJ.size();
+        it.firstJ = sorted[u].offJ;
+        it.firstI = sorted[u].offI;
         it.tgtStride = (int32_t)(sk.lumpStart[t + 1] - sk.lumpStart[t]);
         it.rows = (int16_t)rows;
         it.cols = (int16_t)(sk.spanStart[si + 1] - sk.spanStart[si]);
@@ -343,13 +345,14 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   // items whose target block has at most 16 elements (e.g. 3x3 blocks of automatically detected
   // ranges) go to the kernel that packs four items per wave: move them behind the others
   {
-    vector<ElimGatherItem> large, tiny, wide;
+    vector<ElimGatherItem> large, tiny, tiny9, wide;
     vector<int64_t> tagL;
     vector<int32_t> cbL;
     for (int64_t k = er.itemBegin; k < er.itemEnd; k++) {
       const ElimGatherItem& it = plan.elimItems[k];
       if (int(it.rows) * int(it.cols) <= 16) {
-        tiny.push_back(it);
+        const int big = std::max(int(it.rows), int(it.cols));
+        (big * std::max(big, int(it.n)) <= 9 ? tiny9 : tiny).push_back(it);
       } else if (it.rows > 16 || it.cols > 16) {
         wide.push_back(it);  // does not fit one 16x16 MFMA tile
       } else {
@@ -360,6 +363,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
     }
     auto dst = plan.elimItems.begin() + er.itemBegin;
     dst = std::copy(large.begin(), large.end(), dst);
+    dst = std::copy(tiny9.begin(), tiny9.end(), dst);
     dst = std::copy(tiny.begin(), tiny.end(), dst);
     std::copy(wide.begin(), wide.end(), dst);
     itemRowTag = tagL;
@@ -367,7 +371,8 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
     itemChunk.assign(large.size(), 0);
     er.itemEnd = er.itemBegin + (int64_t)large.size();
     er.tinyBegin = er.itemEnd;
-    er.tinyEnd = er.tinyBegin + (int64_t)tiny.size();
+    er.tiny9End = er.tinyBegin + (int64_t)tiny9.size();
+    er.tinyEnd = er.tiny9End + (int64_t)tiny.size();
     er.ldsBegin = er.tinyEnd;
     er.ldsEnd = er.ldsBegin + (int64_t)wide.size();
   }

@@ -152,6 +152,9 @@ struct ElimGatherItem {
   int16_t rows, cols; // |sj|, |si|
   int16_t n;          // width of the source lumps of this item
   int16_t flags;      // bit0: target shared with other items (atomic), bit1: diagonal block
+  uint32_t firstJ, firstI;  // offsets of the first pair (= elimPairOffJ/I[pairBegin]): most tiny
+                            // items hold one or two pairs, and reading the list costs a dependent
+                            // round trip (K2t)
 };
 constexpr int kGatherMaxElems = 256;   // rows*cols handled per wave (4 per lane)
 constexpr int kGatherMaxPairs = 2048;  // pairs per work item (longer lists are split)
@@ -203,6 +206,8 @@ struct ElimRangePlan {
   bool useGather = false;             // pair updates in gather form (atomic-free) ...
   int64_t itemBegin = 0, itemEnd = 0; // ... over these ElimGatherItems (one wave per item)
   int64_t tinyBegin = 0, tinyEnd = 0; // items with <= 16 target elements: 4 items per wave
+  int64_t tiny9End = 0;               // [tinyBegin, tiny9End): target and both source blocks <= 9
+                                      // elements (3x3 parameters): 7 items per wave
   bool useRowForm = false;            // pair updates in row form instead ...
   int64_t rowBegin = 0, rowEnd = 0;   // ... over these ElimRowItems (one workgroup per row)
   int32_t rowLdsBytes = 0, rowLdsBytesF32 = 0;  // dynamic LDS of the launch (fp64 / fp32)

@@ -53,8 +53,101 @@ struct QuotientGraph {
 
 }  // namespace
 
+// Chain contraction.  A node with at most two neighbours is a safe pivot for minimum degree (its
+// elimination adds at most one edge), but min-degree proper takes such nodes one END of a chain at
+// a time and hands back an elimination tree that is a path: one dependent step per node, which on
+// this device is one dependent launch (or in-kernel column step) per node.  Taking a maximal
+// INDEPENDENT set of them per round instead (odd-even / cyclic reduction on a chain) gives rounds
+// that halve the chain: every round is a set of independent small lumps, i.e. a sparse-elimination
+// range (elimination_tree.cpp, computeSparseElimRanges), and the depth is logarithmic.  The price is
+// the fill edge between the two neighbours of every pivot (2x the blocks of a block-tridiagonal
+// matrix).  Rounds stop when the set is too small to become a range.  Returns the pivots in order
+// and leaves the contracted graph in adj (dead nodes have alive[i] == 0).
+static std::vector<int64_t> contractChains(std::vector<std::vector<int32_t>>& adj,
+                                           std::vector<uint8_t>& alive, int64_t minRound) {
+  const int64_t n = (int64_t)adj.size();
+  std::vector<int64_t> order;
+  std::vector<int64_t> blockedAt(n, -1);
+  std::vector<int32_t> picked;
+  for (int64_t round = 0;; round++) {
+    picked.clear();
+    for (int64_t v = 0; v < n; v++) {
+      if (!alive[v] || adj[v].size() > 2 || blockedAt[v] == round) continue;
+      picked.push_back((int32_t)v);
+      for (int32_t u : adj[v]) blockedAt[u] = round;
+    }
+    if ((int64_t)picked.size() < minRound) break;
+    for (int32_t v : picked) {
+      alive[v] = 0;
+      for (int32_t u : adj[v]) {
+        auto& a = adj[u];
+        a.erase(std::find(a.begin(), a.end(), v));
+      }
+      if (adj[v].size() == 2) {
+        const int32_t a = adj[v][0], b = adj[v][1];
+        if (std::find(adj[a].begin(), adj[a].end(), b) == adj[a].end()) {
+          adj[a].push_back(b);
+          adj[b].push_back(a);
+        }
+      }
+      std::vector<int32_t>().swap(adj[v]);
+      order.push_back(v);
+    }
+  }
+  return order;
+}
+
+static std::vector<int64_t> minimumDegreeCore(const std::vector<int64_t>& ptrs,
+                                              const std::vector<int64_t>& inds);
+
 std::vector<int64_t> minimumDegreeOrdering(const std::vector<int64_t>& ptrs,
-                                           const std::vector<int64_t>& inds) {
+                                           const std::vector<int64_t>& inds,
+                                           int64_t chainContractionMinRound) {
+  const int64_t n = (int64_t)ptrs.size() - 1;
+  if (n <= 0) return {};
+  BASPACHO_CHECK_LT(n, (int64_t)INT32_MAX);
+  if (chainContractionMinRound <= 0) return minimumDegreeCore(ptrs, inds);
+
+  std::vector<std::vector<int32_t>> adj(n);
+  for (int64_t i = 0; i < n; i++) {
+    for (int64_t k = ptrs[i]; k < ptrs[i + 1]; k++) {
+      const int64_t j = inds[k];
+      BASPACHO_CHECK_LT(j, n);
+      if (j == i) continue;
+      adj[i].push_back((int32_t)j);
+      adj[j].push_back((int32_t)i);
+    }
+  }
+  for (auto& a : adj) {
+    std::sort(a.begin(), a.end());
+    a.erase(std::unique(a.begin(), a.end()), a.end());
+  }
+  std::vector<uint8_t> alive(n, 1);
+  std::vector<int64_t> perm = contractChains(adj, alive, chainContractionMinRound);
+  if (perm.empty()) return minimumDegreeCore(ptrs, inds);
+
+  // min-degree on what is left (with the fill edges of the contraction)
+  std::vector<int64_t> newId(n, -1), oldId;
+  for (int64_t i = 0; i < n; i++) {
+    if (alive[i]) {
+      newId[i] = (int64_t)oldId.size();
+      oldId.push_back(i);
+    }
+  }
+  std::vector<int64_t> rPtrs(1, 0), rInds;
+  for (int64_t i : oldId) {
+    for (int32_t j : adj[i]) {
+      if (j < i) rInds.push_back(newId[j]);  // lower triangle is enough, the core symmetrises
+    }
+    rPtrs.push_back((int64_t)rInds.size());
+  }
+  for (int64_t q : minimumDegreeCore(rPtrs, rInds)) perm.push_back(oldId[q]);
+  BASPACHO_CHECK_EQ((int64_t)perm.size(), n);
+  return perm;
+}
+
+static std::vector<int64_t> minimumDegreeCore(const std::vector<int64_t>& ptrs,
+                                              const std::vector<int64_t>& inds) {
   const int64_t n = (int64_t)ptrs.size() - 1;
   std::vector<int64_t> perm;
   perm.reserve(n);

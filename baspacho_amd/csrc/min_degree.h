@@ -16,7 +16,11 @@ namespace BaSpaCho {
 
 // ptrs/inds: any (half or full) pattern of a symmetric matrix; it is symmetrised internally.
 // returns perm with perm[k] = original index eliminated k-th.
+// chainContractionMinRound > 0: before min-degree, rounds of independent pivots with at most two
+// neighbours (odd-even reduction of chain-like parts, see min_degree.cpp) as long as a round
+// holds at least that many pivots; 0 = plain min-degree.
 std::vector<int64_t> minimumDegreeOrdering(const std::vector<int64_t>& ptrs,
-                                           const std::vector<int64_t>& inds);
+                                           const std::vector<int64_t>& inds,
+                                           int64_t chainContractionMinRound = 0);
 
 }  // namespace BaSpaCho

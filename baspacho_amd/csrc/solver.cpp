@@ -526,7 +526,7 @@ SolverPtr createSolver(const Settings& settings, const vector<int64_t>& paramSiz
   // fill-reducing ordering of what is left after the given eliminations
   SparseStructure bottom = ss.extractRightBottom(givenElimEnd);
   lap("elim fill + extract");
-  vector<int64_t> perm = bottom.fillReducingPermutation();
+  vector<int64_t> perm = bottom.fillReducingPermutation(/* contractChains */ true);
   lap("min-degree ordering");
   vector<int64_t> noCrossPoints;
   if (!elimLastIds.empty()) {  // stable partition: "last" ids go to the end

@@ -1,6 +1,7 @@
 #include "sparse_structure.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "bsp_utils.h"
 #include "min_degree.h"
@@ -157,8 +158,13 @@ SparseStructure SparseStructure::addFullEliminationFill() const {
   return out;
 }
 
-std::vector<int64_t> SparseStructure::fillReducingPermutation() const {
-  return minimumDegreeOrdering(ptrs, inds);
+std::vector<int64_t> SparseStructure::fillReducingPermutation(bool contractChains) const {
+  // 50 = the smallest set elimination_tree.cpp turns into a sparse-elimination range
+  static const bool enabled = [] {
+    const char* e = std::getenv("BSP_CHAIN_CONTRACTION");
+    return !(e && e[0] == '0');
+  }();
+  return minimumDegreeOrdering(ptrs, inds, contractChains && enabled ? 50 : 0);
 }
 
 SparseStructure SparseStructure::extractRightBottom(int64_t start) const {

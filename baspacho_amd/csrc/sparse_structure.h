@@ -43,7 +43,8 @@ struct SparseStructure {
   SparseStructure addFullEliminationFill() const;
 
   // perm[i] = old index that should move to position i (approximate minimum degree)
-  std::vector<int64_t> fillReducingPermutation() const;
+  // contractChains: createSolver's variant, odd-even rounds on chain-like parts first (min_degree.h)
+  std::vector<int64_t> fillReducingPermutation(bool contractChains = false) const;
 
   // pattern of the trailing principal sub-matrix from `start`
   SparseStructure extractRightBottom(int64_t start) const;

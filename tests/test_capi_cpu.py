@@ -144,3 +144,43 @@ def test_block_tridiagonal_config_c1():
     cref.factor(sol.skel(), data, sol.sparseEliminationRanges())
     L = np.tril(sol.densify(data))
     assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) < 1e-12
+
+
+def _chainlike(n, closures, seed):
+    """a pose chain (i, i+1) with a few loop closures and short side branches"""
+    rng = np.random.default_rng(seed)
+    rows = list(range(1, n))
+    cols = list(range(0, n - 1))
+    for _ in range(closures):
+        a, b = sorted(rng.choice(n, 2, replace=False))
+        if a != b:
+            rows.append(int(b))
+            cols.append(int(a))
+    return T.structure_from_pairs(n, np.array(rows, dtype=np.int64), np.array(cols, dtype=np.int64))
+
+
+@pytest.mark.parametrize("closures", [0, 7])
+def test_chain_contraction_gives_ranges_and_a_valid_factor(closures):
+    """createSolver's ordering takes independent sets of pivots with <= 2 neighbours first
+    (min_degree.cpp, contractChains): on a chain the elimination tree is then logarithmic, its
+    height classes become sparse-elimination ranges, and the factor is still that of P A P^T.
+    The public fillReducingPermutation (reference API, SparseStructure.h:96) stays plain min-degree."""
+    from oracle import cref
+    n = 900
+    ss = _chainlike(n, closures, 3)
+    sizes = np.full(n, 3, dtype=np.int64)
+    sol = B.create_solver(B.Settings(), sizes, ss)
+    ranges = sol.sparseEliminationRanges()
+    assert len(ranges) >= 4 and ranges[1] >= n // 2 - closures * 3
+    assert sorted(sol.paramToSpan().tolist()) == list(range(n))
+    # far fewer dependent steps than lumps
+    st = sol.planStats()
+    assert st["num_levels"] <= 12 + 3 * closures
+    data = T.random_data(sol.dataSize(), -1, 1, 37)
+    sol.damp(data, 0.0, sol.order() * 1.2)
+    A = sol.densify(data, fill_upper_half=True)
+    cref.factor(sol.skel(), data, ranges)
+    L = np.tril(sol.densify(data))
+    assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) < 1e-12
+    p = ss.fillReducingPermutation()
+    assert sorted(np.asarray(p).tolist()) == list(range(n))

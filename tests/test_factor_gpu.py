@@ -430,3 +430,31 @@ def test_per_op_wide_lump():
     d = to_dev(data)
     sol.factorPerOp(d)
     assert np.linalg.norm(lower_of(sol, d.cpu().numpy()) - L) < 1e-8
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_chain_like_structures(dtype):
+    """pose-chain shaped problems (block-tridiagonal + loop closures): createSolver's chain
+    contraction turns them into a few sparse-elimination ranges + a small dense tail; the device
+    factor must match the dense Cholesky of the permuted matrix and the oracle"""
+    rng = np.random.default_rng(4)
+    for n, closures, bs in [(400, 0, 3), (700, 5, 6), (300, 12, 2)]:
+        rows = list(range(1, n))
+        cols = list(range(0, n - 1))
+        for _ in range(closures):
+            a, b = sorted(rng.choice(n, 2, replace=False))
+            rows.append(int(b))
+            cols.append(int(a))
+        ss = T.structure_from_pairs(n, np.array(rows, dtype=np.int64), np.array(cols, dtype=np.int64))
+        sol = B.create_solver(B.Settings(), np.full(n, bs, dtype=np.int64), ss)
+        assert len(sol.sparseEliminationRanges()) >= 3
+        data = spd_data(sol, 21 + n, dtype=dtype)
+        L, _ = dense_lower_chol(sol, data)
+        got = _gpu_factor(sol, data)
+        # (relative: these matrices are 5-10x the order of the reference's random families, for
+        #  which its absolute tolerances were chosen)
+        nL = np.linalg.norm(L)
+        assert np.linalg.norm(lower_of(sol, got) - L) / nL < EPS[dtype][1] * 0.1, (n, closures)
+        ref = data.astype(np.float64)
+        cref.factor(sol.skel(), ref, sol.sparseEliminationRanges())
+        assert np.linalg.norm(lower_of(sol, got) - lower_of(sol, ref)) / nL < EPS[dtype][1] * 0.1
