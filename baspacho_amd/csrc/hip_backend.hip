@@ -59,8 +59,22 @@ struct DevBuf {
   const U* as() const { return reinterpret_cast<const U*>(ptr); }
 };
 
+// The launch sequence of one factor() over a plan, captured once as a hipGraph (see factorViaGraph).
+struct FactorGraph {
+  hipGraphExec_t exec = nullptr;
+  DevBuf slot;  // device array of the batch's data pointers: every kernel of the graph reads its matrix through it
+  const void *dinvPtr = nullptr, *rawPtr = nullptr;  // scratch of the SymbolicCtx the captured launches point into
+  int calls = 0;
+  FactorGraph() {}
+  FactorGraph(const FactorGraph&) = delete;
+  ~FactorGraph() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+  }
+};
+
 struct DevPlan {
   HipPlanHost host;
+  std::map<std::pair<int, int>, FactorGraph> graphs;  // by (sizeof scalar, batch size)
   DevBuf panels, srcs, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
       updTasks, updTasksFat, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc,
       elimPairSlot, elimRows, elimRowSlots;
@@ -175,7 +189,9 @@ struct PtrRing {
     dev.release();
     slotBytes = 0;
   }
-  const void* push(const void* src, size_t bytes, hipStream_t stream) {
+  // dstFixed: copy to that device address instead of the ring's own device slot (the pointer array a
+  // captured graph reads, below); the pinned staging slot still comes from the ring
+  const void* push(const void* src, size_t bytes, hipStream_t stream, void* dstFixed = nullptr) {
     if (bytes > slotBytes) {  // (first call, or a larger batch than ever before)
       if (slotBytes) hipCHECK(hipDeviceSynchronize());
       release();
@@ -188,7 +204,7 @@ struct PtrRing {
     next = (next + 1) % kSlots;
     if (used[s]) hipCHECK(hipEventSynchronize(ev[s]));
     std::memcpy(host + s * slotBytes, src, bytes);
-    char* d = reinterpret_cast<char*>(dev.ptr) + s * slotBytes;
+    char* d = dstFixed ? reinterpret_cast<char*>(dstFixed) : reinterpret_cast<char*>(dev.ptr) + s * slotBytes;
     hipCHECK(hipMemcpyAsync(d, host + s * slotBytes, bytes, hipMemcpyHostToDevice, stream));
     hipCHECK(hipEventRecord(ev[s], stream));
     used[s] = true;
@@ -245,6 +261,8 @@ struct LaunchTimer {
 // streams and are merely ordered on them.
 struct SharedStreams {
   hipStream_t side = nullptr, due = nullptr, elim = nullptr;
+  hipStream_t capture = nullptr;  // origin stream of graph captures (the caller's stream may be the
+                                  // legacy default stream, which cannot be captured)
 };
 inline SharedStreams& sharedStreams() {
   static std::mutex mu;
@@ -263,6 +281,7 @@ inline SharedStreams& sharedStreams() {
     const char* e = std::getenv("BSP_DUE_PRIO");  // (=1: highest priority for the due units -- measured: no effect)
     hipCHECK(hipStreamCreateWithPriority(&st.due, hipStreamNonBlocking, (e && e[0] == '1') ? greatest : least));
     hipCHECK(hipStreamCreateWithPriority(&st.elim, hipStreamNonBlocking, least));
+    hipCHECK(hipStreamCreateWithFlags(&st.capture, hipStreamNonBlocking));
   }
   return st;
 }
@@ -313,6 +332,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_MERGE_DEF")) mergeDeferred = e[0] != '0';
     if (const char* e = std::getenv("BSP_DUE_STREAM")) dueStream = e[0] != '0';
     if (const char* e = std::getenv("BSP_DUE_SPLIT")) dueSplit = e[0] != '0';
+    if (const char* e = std::getenv("BSP_GRAPH")) graphMode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -442,6 +462,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
   bool dueStream = true;       // due lookahead units on a stream of their own (BSP_DUE_STREAM=0: one side stream)
   bool mergeDeferred = false;  // BSP_MERGE_DEF=1: due + optional lookahead units of a block in one launch
+  int graphMode = 0;           // factor() as a captured hipGraph (BSP_GRAPH): 0 never (default: measured no faster, see factorViaGraph), 1 always, 2 launch-bound plans only
   bool dueSplit = false;       // opt-in BSP_DUE_SPLIT=1: due units in two launches (first column tile / the rest), the chain's block-last step adds to the rest with atomics
   bool earlyDiag = true;       // intra-block chain steps pre-apply their panel to the next block's tile (0,0) (BSP_EARLY_DIAG=0 disables)
   bool bulkYield = true;       // bulk tiles pause on the CU of the chain's potrf workgroup (BSP_BULK_YIELD=0 disables)
@@ -924,18 +945,79 @@ struct HipNumericCtx : NumericCtx<T> {
 
   virtual bool hasFusedFactor() const override { return !sym.forcePerOp; }
 
-  virtual void factorRange(T* data, int64_t startLump, int64_t upToLump) override {
-    DevPlan& plan = sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
-    hipk::DataRef<BT> ref = makeRef(data);
-    LaunchTimer timer(sym.stream, sym.profile);
+  // every launch of a factor over `plan`, in order, on sym.stream and the auxiliary streams
+  void enqueueFactor(DevPlan& plan, hipk::DataRef<BT> ref, LaunchTimer& timer) {
     sym.resetEventPool();
     vector<hipEvent_t> gatherDone;  // filled when the last range's update overlaps the dense phase
     for (const ElimRangePlan& er : plan.host.elimRanges) {
       launchElim(plan, er, ref, timer, &er == &plan.host.elimRanges.back() ? &gatherDone : nullptr);
     }
     launchLevels(plan, plan.host.levels, ref, timer, gatherDone.empty() ? nullptr : &gatherDone);
+  }
+
+  virtual void factorRange(T* data, int64_t startLump, int64_t upToLump) override {
+    DevPlan& plan = sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
+    if (factorViaGraph(plan, data)) return;
+    hipk::DataRef<BT> ref = makeRef(data);
+    LaunchTimer timer(sym.stream, sym.profile);
+    enqueueFactor(plan, ref, timer);
     hipCHECK(hipGetLastError());
     timer.finish();
+  }
+
+  // host array of the matrices' device pointers (one entry for a single matrix)
+  void dataPointers(T* data, vector<BT*>& out);
+
+  // factor() as ONE graph launch.  A launch-bound structure (GRID 82x82: 127 dependent launches of
+  // 10-20 us) leaves the device idle between kernels whenever the runtime's per-launch bookkeeping
+  // falls behind (rocprofv3: runs of 40-50 us gaps in the middle of a factor, 0.3-0.4 of 1.7 ms);
+  // a captured graph is submitted as a whole.  The sequence is captured on the plan's SECOND use
+  // (the first one allocates the scratch the launches point into), from an internal stream, with
+  // the auxiliary streams joining through the same events as in the plain schedule; the matrices
+  // are reached through a pointer array in device memory that is rewritten before every launch,
+  // so one graph serves every data buffer.  Returns false when the call should go the plain way.
+  // MEASURED (profiles/ab_graph.sh): no gain on this stack -- GRID 82x82 1.66-1.79 against 1.74-1.77
+  // ms, block-tridiagonal 0.195 against 0.183, small BAL 0.825 against 0.80, BAL-871 7.15 = 7.16,
+  // FLAT-50k 28.2 against 28.6, 64 x GRID 12.65 = 12.65: the runtime plays a graph back as the same
+  // packets on the same queues.  Kept opt-in (BSP_GRAPH=1 always, =2 launch-bound plans) and tested.
+  bool factorViaGraph(DevPlan& plan, T* data) {
+    if (sym.graphMode == 0 || sym.profile || sym.forcePerOp) return false;
+    if (sym.graphMode == 2 && !plan.host.launchBound()) return false;
+    FactorGraph& g = plan.graphs[{(int)sizeof(BT), batchSize}];
+    if (++g.calls == 1) return false;
+    if (g.exec && (g.dinvPtr != sym.dinvScratch.ptr || g.rawPtr != sym.rawScratch.ptr)) {
+      (void)hipGraphExecDestroy(g.exec);  // (another plan has grown the scratch since)
+      g.exec = nullptr;
+    }
+    if (!g.exec) {
+      g.slot.resize(std::max<size_t>((size_t)batchSize * sizeof(BT*), 256));
+      hipk::DataRef<BT> ref{nullptr, (BT* const*)g.slot.ptr};
+      hipStream_t user = sym.stream, cap = sharedStreams().capture;
+      hipCHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
+      sym.stream = cap;
+      hipGraph_t graph = nullptr;
+      try {
+        LaunchTimer timer(cap, nullptr);
+        enqueueFactor(plan, ref, timer);
+      } catch (...) {
+        sym.stream = user;
+        (void)hipStreamEndCapture(cap, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+      }
+      sym.stream = user;
+      hipCHECK(hipStreamEndCapture(cap, &graph));
+      hipError_t err = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      hipCHECK(err);
+      g.dinvPtr = sym.dinvScratch.ptr;
+      g.rawPtr = sym.rawScratch.ptr;
+    }
+    vector<BT*> ptrs;
+    dataPointers(data, ptrs);
+    sym.ptrRing.push(ptrs.data(), ptrs.size() * sizeof(BT*), sym.stream, g.slot.ptr);
+    hipCHECK(hipGraphLaunch(g.exec, sym.stream));
+    return true;
   }
 
   virtual void doElimination(const SymElimCtx& elimData, T* data, int64_t lumpsBegin,
@@ -1097,6 +1179,20 @@ hipk::DataRef<double> HipNumericCtx<double>::makeRef(double* data) {
 template <>
 hipk::DataRef<float> HipNumericCtx<float>::makeRef(float* data) {
   return {data, nullptr};
+}
+template <>
+void HipNumericCtx<double>::dataPointers(double* data, vector<double*>& out) { out = {data}; }
+template <>
+void HipNumericCtx<float>::dataPointers(float* data, vector<float*>& out) { out = {data}; }
+template <>
+void HipNumericCtx<vector<double*>>::dataPointers(vector<double*>* data, vector<double*>& out) {
+  BASPACHO_CHECK_EQ((int)data->size(), batchSize);
+  out = *data;
+}
+template <>
+void HipNumericCtx<vector<float*>>::dataPointers(vector<float*>* data, vector<float*>& out) {
+  BASPACHO_CHECK_EQ((int)data->size(), batchSize);
+  out = *data;
 }
 template <>
 hipk::DataRef<double> HipNumericCtx<vector<double*>>::makeRef(vector<double*>* data) {

@@ -267,6 +267,9 @@ struct HipPlanHost {
   double elimPairFlops = 0;  // 2 * n * (pair elements)
   double elimColElems = 0;   // numeric elements of the sparse-eliminated columns
   int64_t numLaunches = 0;
+  // launch-bound: on average a launch carries too little work to cover its own dispatch (the
+  // criterion for running factor() as a captured graph, hip_backend.hip)
+  bool launchBound() const { return numLaunches > 8 && flops < 100e6 * double(numLaunches); }
   int64_t maxPanelsInLevel = 0;
   int64_t maxChainRows = 0;  // max rows below a panel whose level sets rawNext (staging buffer rows)
   bool hasDeferred = false;  // some level carries lookahead (deferred) tiles

@@ -458,3 +458,50 @@ def test_chain_like_structures(dtype):
         ref = data.astype(np.float64)
         cref.factor(sol.skel(), ref, sol.sparseEliminationRanges())
         assert np.linalg.norm(lower_of(sol, got) - lower_of(sol, ref)) / nL < EPS[dtype][1] * 0.1
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_factor_as_captured_graph(monkeypatch, mode):
+    """BSP_GRAPH=1: from its second use on, factor() over a plan is one hipGraph launch (captured from
+    an internal stream, matrices reached through a device pointer array).  Every call must give the
+    factor of ITS buffer: different data per call, single + batched, fp64 + fp32, elimination ranges
+    + lookahead forks; =2 (default) takes the graph only for launch-bound plans."""
+    monkeypatch.setenv("BSP_GRAPH", mode)
+    import torch
+    ss = T.gen_grid(20, 20, 1.0, 2, 37)
+    sol = B.create_solver(B.Settings(), np.full(400, 3), ss)
+    for dtype in (np.float64, np.float32):
+        for rep in range(4):
+            data = spd_data(sol, 31 + rep, beta_factor=1.2, dtype=dtype)
+            L, A = dense_lower_chol(sol, data)
+            Lg = lower_of(sol, _gpu_factor(sol, data))
+            assert np.linalg.norm(Lg - L) / np.linalg.norm(L) < EPS[dtype][1] * 0.1, (dtype, rep)
+    # batched, a different set of buffers on every call
+    for rep in range(3):
+        datas = [spd_data(sol, 50 + 7 * rep + q, beta_factor=1.2) for q in range(5)]
+        devs = [to_dev(d) for d in datas]
+        sol.factor(devs)
+        for d, h in zip(devs, datas):
+            L, _ = dense_lower_chol(sol, h)
+            assert np.linalg.norm(lower_of(sol, d.cpu().numpy()) - L) / np.linalg.norm(L) < 1e-9
+    # a wide dense lump (chain steps + lookahead units on the auxiliary streams), given elimination range
+    sizes, ss2, _, _ = T.gen_bal_synthetic(num_cams=90, num_pts=3000, band=10, seed=3)
+    sol2 = B.create_solver(B.Settings(), sizes, ss2, [0, 3000])
+    for rep in range(3):
+        data = spd_data(sol2, 70 + rep, beta_factor=1.2)
+        ref = data.copy()
+        cref.factor(sol2.skel(), ref, sol2.sparseEliminationRanges())
+        got = _gpu_factor(sol2, data)
+        mask = sol2.lowerMask()
+        assert np.linalg.norm((got - ref)[mask]) / np.linalg.norm(ref[mask]) < 1e-12, rep
+    # on a non-default stream
+    st = torch.cuda.Stream()
+    sol.setStream(st)
+    with torch.cuda.stream(st):
+        data = spd_data(sol, 99, beta_factor=1.2)
+        L, _ = dense_lower_chol(sol, data)
+        d = to_dev(data)
+        sol.factor(d)
+        st.synchronize()
+        assert np.linalg.norm(lower_of(sol, d.cpu().numpy()) - L) / np.linalg.norm(L) < 1e-9
+    sol.setStream(torch.cuda.current_stream())
