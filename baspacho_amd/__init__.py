@@ -49,7 +49,8 @@ class _CPlanStats(ctypes.Structure):
                [(n, ctypes.c_int64) for n in
                 ["num_launches", "num_levels", "num_panels", "num_segs", "num_upd_tasks",
                  "num_trsm_tasks", "chain_tab_entries", "max_panels_in_level",
-                 "num_atomic_upd_tasks", "num_gather_groups"]]
+                 "num_atomic_upd_tasks", "num_gather_groups", "num_fork_levels"]] + \
+               [("deferred_flops", ctypes.c_double)]
 
 
 @dataclass

@@ -456,6 +456,8 @@ int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out) {
   out->max_panels_in_level = p.maxPanelsInLevel;
   out->num_atomic_upd_tasks = p.numAtomicUpdTasks;
   out->num_gather_groups = p.numGatherGroups;
+  out->num_fork_levels = p.numForkLevels;
+  out->deferred_flops = p.deferredFlops;
   BSP_CATCH
 }
 

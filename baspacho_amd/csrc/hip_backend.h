@@ -29,7 +29,9 @@ struct HipPlanStats {
          trsmFlops = 0, potrfFlops = 0, trsmFlopsMerged = 0, potrfFlopsFused = 0;
   int64_t numLaunches = 0, numLevels = 0, numPanels = 0, numSegs = 0, numUpdTasks = 0,
           numTrsmTasks = 0, chainTabEntries = 0, maxPanelsInLevel = 0, numAtomicUpdTasks = 0,
-          numGatherGroups = 0;  // > 0: the elimination update overlaps the dense phase
+          numGatherGroups = 0,  // > 0: the elimination update overlaps the dense phase
+          numForkLevels = 0;
+  double deferredFlops = 0;
 };
 
 // while `prof` is non-null every kernel launch of the context is bracketed by HIP events and

@@ -332,6 +332,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_MERGE_DEF")) mergeDeferred = e[0] != '0';
     if (const char* e = std::getenv("BSP_DUE_STREAM")) dueStream = e[0] != '0';
     if (const char* e = std::getenv("BSP_DUE_SPLIT")) dueSplit = e[0] != '0';
+    if (const char* e = std::getenv("BSP_LOOKAHEAD_MIN_GF")) lookaheadMinFlops = 1e9 * std::atof(e);
     if (const char* e = std::getenv("BSP_GRAPH")) graphMode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
   }
 
@@ -462,6 +463,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
   bool dueStream = true;       // due lookahead units on a stream of their own (BSP_DUE_STREAM=0: one side stream)
   bool mergeDeferred = false;  // BSP_MERGE_DEF=1: due + optional lookahead units of a block in one launch
+  double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
   int graphMode = 0;           // factor() as a captured hipGraph (BSP_GRAPH): 0 never (default: measured no faster, see factorViaGraph), 1 always, 2 launch-bound plans only
   bool dueSplit = false;       // opt-in BSP_DUE_SPLIT=1: due units in two launches (first column tile / the rest), the chain's block-last step adds to the rest with atomics
   bool earlyDiag = true;       // intra-block chain steps pre-apply their panel to the next block's tile (0,0) (BSP_EARLY_DIAG=0 disables)
@@ -543,7 +545,9 @@ struct HipNumericCtx : NumericCtx<T> {
   void launchLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::DataRef<BT> ref,
                     LaunchTimer& timer, const vector<hipEvent_t>* gatherDone = nullptr) {
     const dim3 gy(1, (unsigned)batchSize, 1);
-    const bool lookahead = lookaheadOn();
+    // (side streams only when the lookahead units are worth their forks, HipPlanHost::lookaheadPays;
+    //  otherwise the same launches go in line)
+    const bool lookahead = lookaheadOn() && plan.host.lookaheadPays(batchSize, sym.lookaheadMinFlops);
     int waitedMain = -1, waitedSide = -1, waitedDue = -1;  // gather groups the streams already wait for
     auto waitGather = [&](hipStream_t st, int group, int& waited) {
       if (!gatherDone || group <= waited) return;
@@ -1689,6 +1693,8 @@ HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t up
   int64_t atomicTasks = 0;
   for (auto& t : p.updTasks) atomicTasks += t.atomic ? 1 : 0;
   s.numAtomicUpdTasks = atomicTasks;
+  s.numForkLevels = p.numForkLevels;
+  s.deferredFlops = p.deferredFlops;
   if (!p.elimRanges.empty() && p.elimRanges.back().overlapLump >= 0 && h->elimOverlap) {
     s.numGatherGroups = (int64_t)p.elimRanges.back().groupItem.size() - 1;
   }

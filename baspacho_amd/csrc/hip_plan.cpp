@@ -973,6 +973,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           const double R = double(sr.rowsBelow - sd.q0), m = double(sd.m);
           plan.updElems += m * R - m * (m - 1) / 2;
           plan.updFlops += 2.0 * sr.K * (m * R - m * (m - 1) / 2);
+          if (anyDeferred) plan.deferredFlops += 2.0 * sr.K * (m * R - m * (m - 1) / 2);
         }
       }
       lr.panelEnd = (int64_t)plan.levelPanels.size();
@@ -1002,7 +1003,10 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           plan.updTasks[begin + p] = tmp[chunkStart[x] + k];
         }
       };
-      if (lr.defEnd > lr.defBegin) plan.hasDeferred = true;
+      if (lr.defEnd > lr.defBegin) {
+        plan.hasDeferred = true;
+        plan.numForkLevels++;
+      }
       if (bucket.size() == 1) {
         // first panel of an outer block: the column tiles 1..3 of this block received their due
         // units from the fork two block boundaries back (DUE SPLIT)

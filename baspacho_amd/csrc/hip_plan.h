@@ -273,6 +273,18 @@ struct HipPlanHost {
   int64_t maxPanelsInLevel = 0;
   int64_t maxChainRows = 0;  // max rows below a panel whose level sets rawNext (staging buffer rows)
   bool hasDeferred = false;  // some level carries lookahead (deferred) tiles
+  double deferredFlops = 0;  // flops of the lookahead units (what the side streams run)
+  int64_t numForkLevels = 0; // levels that fork lookahead units (one event round trip each)
+  // The lookahead schedule costs a cross-queue event round trip per fork and per wait (~40-50 us of
+  // idle execution stream each time the chain has caught up, rocprofv3 on GRID 82x82: 1.73 ms with
+  // the side streams, 1.46 with the same launches in line); it pays when the units it moves off the
+  // execution stream are worth more than that.  Per matrix; a batch multiplies the work per fork.
+  // (measured, on / off: GRID 82x82 0.04 GF per fork 1.73 / 1.46 ms, small BAL 0.04 GF 0.80 / 0.78,
+  //  64 x GRID 2.3 GF 12.60 / 12.50, BAL-871 4.8 GF 7.17 / 8.78, FLAT-50k 17 GF 28.6 / 31.9)
+  static constexpr double kMinDeferredFlopsPerFork = 3e9;
+  bool lookaheadPays(int batch = 1, double minFlopsPerFork = kMinDeferredFlopsPerFork) const {
+    return numForkLevels > 0 && deferredFlops * batch >= minFlopsPerFork * double(numForkLevels);
+  }
 };
 
 // Build the plan for factoring lumps [startLump, upToLump) (sparse-elimination ranges fully

@@ -226,7 +226,10 @@ typedef struct bsp_plan_stats {
       potrf_flops_fused;       /* ... of which inside the previous level's update launch */
   int64_t num_launches, num_levels, num_panels, num_segs, num_upd_tasks, num_trsm_tasks,
       chain_tab_entries, max_panels_in_level, num_atomic_upd_tasks,
-      num_gather_groups; /* > 0: sparse-elimination update split into groups that overlap the dense phase */
+      num_gather_groups, /* > 0: sparse-elimination update split into groups that overlap the dense phase */
+      num_fork_levels;   /* levels that hand lookahead units to the auxiliary streams */
+  double deferred_flops; /* flops of those units; the lookahead schedule is used when they are worth
+                            the forks (HipPlanHost::lookaheadPays) */
 } bsp_plan_stats;
 int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out);
 

@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "product_defaults: run with the product's own schedule choices")
 
 
 @pytest.fixture(scope="session")
@@ -27,3 +28,15 @@ def _built():
         _lib.build()
     from oracle import cref
     cref.build()
+
+
+@pytest.fixture(autouse=True)
+def _lookahead_on_small_problems(request, monkeypatch):
+    """The product hands lookahead units to the auxiliary streams only when they are worth the forks
+    (HipPlanHost::lookaheadPays): the small matrices of the parity tests would never reach that
+    schedule.  Tests therefore run with the threshold at 0 (side streams whenever a plan has
+    lookahead units; BSP_NO_LOOKAHEAD=1 in test_schedule_variants covers the in-line order);
+    tests/test_full_size_gpu.py and tests marked `product_defaults` keep the product's own choice."""
+    if request.node.module.__name__ == "test_full_size_gpu" or request.node.get_closest_marker("product_defaults"):
+        return
+    monkeypatch.setenv("BSP_LOOKAHEAD_MIN_GF", "0")

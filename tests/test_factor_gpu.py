@@ -505,3 +505,26 @@ def test_factor_as_captured_graph(monkeypatch, mode):
         st.synchronize()
         assert np.linalg.norm(lower_of(sol, d.cpu().numpy()) - L) / np.linalg.norm(L) < 1e-9
     sol.setStream(torch.cuda.current_stream())
+
+
+@pytest.mark.product_defaults
+def test_lookahead_choice_follows_the_plan():
+    """product defaults: a plan whose lookahead units are too small for their forks runs them in
+    line (GRID: 1.46 against 1.73 ms with side streams), a wide dense lump keeps the side streams;
+    both orders give the same factor"""
+    ss = T.gen_grid(40, 40, 1.0, 2, 37)
+    sol = B.create_solver(B.Settings(), np.full(1600, 3), ss)
+    st = sol.planStats()
+    assert st["num_fork_levels"] == 0 or st["deferred_flops"] / st["num_fork_levels"] < 3e9
+    data = spd_data(sol, 12, beta_factor=1.2)
+    ref = data.copy()
+    cref.factor(sol.skel(), ref, sol.sparseEliminationRanges())
+    got = _gpu_factor(sol, data)
+    mask = sol.lowerMask()
+    assert np.linalg.norm((got - ref)[mask]) / np.linalg.norm(ref[mask]) < 1e-12
+    # one dense lump of 7800 columns (the width of BAL-871's camera block): ~4.7 GF per fork
+    n = 2600
+    full = T.structure_from_pairs(n, *np.tril_indices(n, -1))
+    sol = B.create_solver(B.Settings(findSparseEliminationRanges=False), np.full(n, 3), full)
+    st = sol.planStats()
+    assert st["num_fork_levels"] > 0 and st["deferred_flops"] / st["num_fork_levels"] >= 3e9
