@@ -430,14 +430,19 @@ class Solver:
         _check(self._lib.bsp_plan_stats_full(self._h, ctypes.byref(st)))
         return {n: getattr(st, n) for n, _ in _CPlanStats._fields_}
 
-    def factorProfiled(self, data, in_situ=False):
+    def factorProfiled(self, data, in_situ=False, busy=False):
         """one factor() with every launch bracketed by HIP events; returns {kernel class: (total
         ms, launches)}.  in_situ=False: launches serialised on the execution stream (isolated
         kernel times); in_situ=True: the real two-stream schedule, each launch timed on the stream
-        it runs on"""
+        it runs on; busy=True adds, per class, the time during which at least one of its launches
+        was running (launches on different streams overlap)"""
         self._check_data(data)
         ms = (ctypes.c_double * 6)()
         ln = (ctypes.c_int64 * 6)()
+        if in_situ and busy:
+            bs = (ctypes.c_double * 6)()
+            _check(self._lib.bsp_factor_profiled_busy_f64(self._h, ctypes.c_void_p(_ptr_of(data)), ms, ln, bs))
+            return {k: (ms[i], ln[i], bs[i]) for i, k in enumerate(PROF_KINDS)}
         fn = self._lib.bsp_factor_profiled_insitu_f64 if in_situ else self._lib.bsp_factor_profiled_f64
         _check(fn(self._h, ctypes.c_void_p(_ptr_of(data)), ms, ln))
         return {k: (ms[i], ln[i]) for i, k in enumerate(PROF_KINDS)}

@@ -478,7 +478,8 @@ int bsp_debug_read_trace(long long* out, int max_records, int* n_records) {
   BSP_CATCH
 }
 
-static void factorProfiled(bsp_solver* s, double* d, bool inSitu, double ms[6], int64_t launches[6]) {
+static void factorProfiled(bsp_solver* s, double* d, bool inSitu, double ms[6], int64_t launches[6],
+                           double* busy = nullptr) {
   HipKernelProfile prof;
   SymbolicCtx& sym = s->solver->internalSymbolicContext();
   hipBackendSetProfile(sym, &prof, inSitu);
@@ -492,6 +493,7 @@ static void factorProfiled(bsp_solver* s, double* d, bool inSitu, double ms[6], 
   for (int i = 0; i < kProfNumKinds; i++) {
     ms[i] = prof.ms[i];
     launches[i] = prof.launches[i];
+    if (busy) busy[i] = prof.busyMs[i];
   }
 }
 int bsp_factor_profiled_f64(bsp_solver* s, double* d, double ms[6], int64_t launches[6]) {
@@ -502,6 +504,12 @@ int bsp_factor_profiled_f64(bsp_solver* s, double* d, double ms[6], int64_t laun
 int bsp_factor_profiled_insitu_f64(bsp_solver* s, double* d, double ms[6], int64_t launches[6]) {
   BSP_TRY
   factorProfiled(s, d, true, ms, launches);
+  BSP_CATCH
+}
+int bsp_factor_profiled_busy_f64(bsp_solver* s, double* d, double ms[6], int64_t launches[6],
+                                 double busy_ms[6]) {
+  BSP_TRY
+  factorProfiled(s, d, true, ms, launches, busy_ms);
   BSP_CATCH
 }
 

@@ -21,6 +21,10 @@ enum HipProfKind {
 struct HipKernelProfile {
   double ms[kProfNumKinds] = {0, 0, 0, 0, 0, 0};
   int64_t launches[kProfNumKinds] = {0, 0, 0, 0, 0, 0};
+  // time during which AT LEAST ONE launch of the class was running (launches of one class overlap
+  // when they go to different streams: their durations then add up to more than the time the class
+  // occupies the device)
+  double busyMs[kProfNumKinds] = {0, 0, 0, 0, 0, 0};
 };
 
 struct HipPlanStats {

@@ -239,11 +239,27 @@ struct LaunchTimer {
   void finish() {
     if (!prof) return;
     hipCHECK(hipStreamSynchronize(stream));  // (the side stream has been joined into it)
+    // per class: sum of the launch durations, and the union of their intervals (device time
+    // stamps relative to the first launch)
+    vector<std::pair<float, float>> spans[kProfNumKinds];
     for (auto& r : recs) {
-      float ms = 0;
+      float ms = 0, t0 = 0;
       hipCHECK(hipEventElapsedTime(&ms, r.a, r.b));
+      if (&r != &recs.front()) hipCHECK(hipEventElapsedTime(&t0, recs.front().a, r.a));
       prof->ms[r.kind] += ms;
       prof->launches[r.kind]++;
+      spans[r.kind].emplace_back(t0, t0 + ms);
+    }
+    for (int k = 0; k < kProfNumKinds; k++) {
+      std::sort(spans[k].begin(), spans[k].end());
+      float end = -1e30f;
+      for (auto& sp : spans[k]) {
+        if (sp.second <= end) continue;
+        prof->busyMs[k] += sp.second - std::max(sp.first, end);
+        end = sp.second;
+      }
+    }
+    for (auto& r : recs) {
       (void)hipEventDestroy(r.a);
       (void)hipEventDestroy(r.b);
     }

@@ -234,8 +234,13 @@ def roofline_block(sol, A_dev, flops, ms_per_step, workload):
     st = sol.planStats()
     out = {}
     prof_iso = sol.factorProfiled(A_dev.clone(), in_situ=False)
-    prof = sol.factorProfiled(A_dev.clone(), in_situ=True)
+    prof3 = sol.factorProfiled(A_dev.clone(), in_situ=True, busy=True)
+    prof = {k: (v[0], v[1]) for k, v in prof3.items()}
+    busy = {k: v[2] for k, v in prof3.items()}
     out["kernel_ms"] = {k: [round(v[0], 4), v[1]] for k, v in prof.items()}
+    # time during which at least one launch of the class was running (launches of a class that go
+    # to different streams overlap: their durations add up to more than this)
+    out["kernel_busy_ms"] = {k: round(v, 4) for k, v in busy.items()}
     out["kernel_ms_isolated"] = {k: [round(v[0], 4), v[1]] for k, v in prof_iso.items()}
     # algorithmic work of every kernel class, from the plan (DESIGN.md "Kernels"):
     #   update / chain_update: 2 K per lower-trapezoid target element (symmetric update)
@@ -271,6 +276,10 @@ def roofline_block(sol, A_dev, flops, ms_per_step, workload):
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
             "frac": round(rate / peak, 4),
             "frac_isolated": round(amount / (iso_ms * 1e-3) / scale / peak, 4) if iso_ms > 0 else None,
+            # the class's launches overlap one another when they run on two auxiliary streams: work
+            # over the time during which at least one of them is running
+            "frac_busy": round(amount / (busy[dom] * 1e-3) / scale / peak, 4) if busy[dom] > 0 else None,
+            "busy_ms": round(busy[dom], 4),
             "traffic": None, "launches": launches,
             "avg_launch_ms": round(ms / max(launches, 1), 5),
             "timing": "HIP events around every launch on the stream it runs on, lookahead "

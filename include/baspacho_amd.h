@@ -248,6 +248,10 @@ int bsp_factor_profiled_f64(bsp_solver* s, double* dev_data, double ms[6], int64
    on, i.e. what a kernel takes beside the others (= what a rocprofv3 kernel trace shows) */
 int bsp_factor_profiled_insitu_f64(bsp_solver* s, double* dev_data, double ms[6],
                                    int64_t launches[6]);
+/* ... and, per class, the time during which at least one of its launches was running (launches of
+   one class that go to different streams overlap: their durations add up to more than that) */
+int bsp_factor_profiled_busy_f64(bsp_solver* s, double* dev_data, double ms[6], int64_t launches[6],
+                                 double busy_ms[6]);
 
 /* sustained v_mfma_f64_16x16x4_f64 rate of the current GPU (TFLOP/s), register-only probe */
 int bsp_probe_mfma_f64(double* tflops);

@@ -84,9 +84,19 @@ for cls, ent in bench.get("kernel_rates", {}).items():
     mfma = "algorithmic_flops" in ent
     rate = work / (tot_ns * 1e-9) / (1e12 if mfma else 1e9)
     peak = 78.6 if mfma else 8000.0
+    # launches of a class on different streams overlap: time with at least one of them running
+    ev = sorted((r[1], r[2]) for r in sel if short(r[0]) in ks)
+    union, end = 0, -1
+    for a, b in ev:
+        if b > end:
+            union += b - max(a, end)
+            end = b
+    busy_ns = union / ncalls
     out[cls] = {"kernels": ks, "launches_per_factor": launches, "total_us_per_factor": round(tot_ns / 1e3, 1),
                 "avg_ns": round(tot_ns / launches, 0), "rate": round(rate, 3), "unit": "TFLOP/s" if mfma else "GB/s",
-                "frac": round(rate / peak, 4), "stats_file": "profiles/%s_kernel_stats.txt" % tag}
+                "frac": round(rate / peak, 4), "busy_us_per_factor": round(busy_ns / 1e3, 1),
+                "frac_busy": round(work / (busy_ns * 1e-9) / (1e12 if mfma else 1e9) / peak, 4),
+                "stats_file": "profiles/%s_kernel_stats.txt" % tag}
 path = os.path.join(here, "rocprof_roofline.json")
 try:
     doc = json.load(open(path))
@@ -94,6 +104,8 @@ except (OSError, ValueError):
     doc = {}
 doc[bench["config"]["workload"]] = out
 doc["_how"] = ("frac = algorithmic work of the class (bench.py kernel_rates) / (calls x avg_ns of its kernels in the "
-               "headline-only table of the stats file) / peak (78.6 TFLOP/s fp64 MFMA, 8000 GB/s HBM)")
+               "headline-only table of the stats file) / peak (78.6 TFLOP/s fp64 MFMA, 8000 GB/s HBM); frac_busy = the same "
+               "over the time during which at least one launch of the class is running (its launches overlap when "
+               "they run on two auxiliary streams)")
 json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1))

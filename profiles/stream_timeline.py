@@ -21,6 +21,19 @@ t0 = seg[0][1]
 tg = [r for r in seg if 'elimGather' in r[0]][-1][2]
 tend = max(r[2] for r in seg)
 print("factor %.3f ms: elimination %.3f ms, dense phase %.3f ms" % ((tend - t0) / 1e6, (tg - t0) / 1e6, (tend - tg) / 1e6))
+# launches of one kernel on different streams overlap: time during which at least one is running
+for kname in ("updateTileBulk", "chainStep"):
+    ev = sorted((r[1], r[2]) for r in seg if kname in r[0])
+    if not ev:
+        continue
+    union, end = 0, -1
+    for a, b in ev:
+        if b <= end:
+            continue
+        union += b - max(a, end)
+        end = b
+    print("%s: %d launches, %.3f ms of launch time, %.3f ms with at least one running" % (
+        kname, len(ev), sum(b - a for a, b in ev) / 1e6, union / 1e6))
 streams = sorted(set(r[3] for r in seg))
 main = None
 for s in streams:
