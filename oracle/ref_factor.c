@@ -29,6 +29,12 @@ static int64_t orc_bisect(const int64_t* a, int64_t size, int64_t needle) {
 #undef REAL
 #undef FN
 
+/* the scalar kernels on their own, for the MathUtilsTest analogue (tests/MathUtilsTest.cpp:21-75):
+   A row-major n x n with stride lda; v a row vector of n */
+void orc_cholesky_f64(double* A, int64_t lda, int64_t n) { chol_f64(A, lda, n); }
+void orc_solve_upper_t_f64(const double* L, int64_t lda, int64_t n, double* v) { solve_row_f64(L, lda, n, v); }
+void orc_solve_upper_f64(const double* L, int64_t lda, int64_t n, double* v) { solve_row_t_f64(L, lda, n, v); }
+
 /* Size-independent parity probe (test/measurement helper, no reference counterpart):
    out[0] = || L (L^T x) - A x ||_2, out[1] = || A x ||_2, with A (symmetric, lower triangle
    stored) and L applied as block-sparse operators laid out by the skeleton.  Strictly-upper

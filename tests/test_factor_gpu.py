@@ -528,3 +528,34 @@ def test_lookahead_choice_follows_the_plan():
     sol = B.create_solver(B.Settings(findSparseEliminationRanges=False), np.full(n, 3), full)
     st = sol.planStats()
     assert st["num_fork_levels"] > 0 and st["deferred_flops"] / st["num_fork_levels"] >= 3e9
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_in_register_cholesky_and_row_solves(dtype):
+    """MathUtilsTest on the device (tests/MathUtilsTest.cpp:21-75): the scalar
+    cholesky / solveUpperT of the reference live inside the sparse-elimination factor kernels here
+    (elimFactorTiny for lumps up to 4 wide, elimFactorSmall up to 16).  Independent lumps of every
+    width 1..16 with one block of rows below each, eliminated alone (doElimination), against numpy
+    per lump: diagonal block = chol(A_ll), rows below = A_rl L^-T; tolerance 1e-7 as the reference
+    (fp32: 1e-4)"""
+    tol = 1e-7 if dtype == np.float64 else 1e-4
+    for n in range(1, 17):
+        K, m = 70, 5          # K independent params of width n, one tail param of m rows
+        sizes = np.array([n] * K + [m], dtype=np.int64)
+        ss = T.structure_from_pairs(K + 1, np.full(K, K, dtype=np.int64), np.arange(K, dtype=np.int64))
+        sol = B.create_solver(B.Settings(findSparseEliminationRanges=False), sizes, ss, [0, K])
+        assert sol.sparseEliminationRanges().tolist() == [0, K]
+        data = spd_data(sol, 100 + n, dtype=dtype)
+        A = sol.densify(data.astype(np.float64), fill_upper_half=True)
+        d = to_dev(data)
+        sol.doElimination(d, 0)
+        got = sol.densify(d.cpu().numpy().astype(np.float64))
+        p2s = sol.paramToSpan()
+        ss_ = sol.skel()["spanStart"]
+        t0 = int(ss_[p2s[K]])
+        for k in range(K):
+            c0 = int(ss_[p2s[k]])
+            L = np.linalg.cholesky(A[c0:c0 + n, c0:c0 + n])
+            assert np.linalg.norm(np.tril(got[c0:c0 + n, c0:c0 + n]) - L) < tol, (n, k)
+            X = np.linalg.solve(L, A[t0:t0 + m, c0:c0 + n].T).T      # rows * L^-T
+            assert np.linalg.norm(got[t0:t0 + m, c0:c0 + n] - X) < tol, (n, k)

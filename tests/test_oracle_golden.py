@@ -174,3 +174,30 @@ def test_blas_baseline_matches_plain_oracle(seed):
     cref.factor(sk, a, sol.sparseEliminationRanges())
     cref.blas_factor(sk, b, sol.sparseEliminationRanges())
     assert np.linalg.norm(lower_of(sol, a) - lower_of(sol, b)) < 1e-9
+
+
+def test_oracle_math_utils():
+    """MathUtilsTest (tests/MathUtilsTest.cpp:21-75): the scalar cholesky / solveUpperT / solveUpper
+    of the oracle against numpy, same sizes, damping and tolerance (1e-7) as the reference"""
+    import ctypes
+    lib = cref.lib()
+    n = 10
+    dp = ctypes.POINTER(ctypes.c_double)
+    A = T.random_data(n * n, -1.0, 1.0, 37).reshape(n, n).copy()
+    A[np.arange(n), np.arange(n)] += n * 1.3
+    sym = np.tril(A) + np.tril(A, -1).T       # the kernels read the lower triangle
+    L = np.linalg.cholesky(sym)
+    got = A.copy()
+    lib.orc_cholesky_f64(got.ctypes.data_as(dp), ctypes.c_int64(n), ctypes.c_int64(n))
+    assert np.linalg.norm(np.tril(got) - L) < 1e-7
+    # solveUpperT: v <- v L^-T ; solveUpper: v <- v L^-1, L = lower triangle of a damped matrix
+    M = T.random_data(n * n, -1.0, 1.0, 37).reshape(n, n).copy()
+    M[np.arange(n), np.arange(n)] += n * 0.3
+    Lm = np.tril(M)
+    v = T.random_data(n, -1.0, 1.0, 39)
+    a = v.copy()
+    lib.orc_solve_upper_t_f64(M.ctypes.data_as(dp), ctypes.c_int64(n), ctypes.c_int64(n), a.ctypes.data_as(dp))
+    assert np.linalg.norm(a - np.linalg.solve(Lm, v)) < 1e-7          # v L^-T = (L^-1 v^T)^T
+    b = v.copy()
+    lib.orc_solve_upper_f64(M.ctypes.data_as(dp), ctypes.c_int64(n), ctypes.c_int64(n), b.ctypes.data_as(dp))
+    assert np.linalg.norm(b - np.linalg.solve(Lm.T, v)) < 1e-7        # v L^-1 = (L^-T v^T)^T
