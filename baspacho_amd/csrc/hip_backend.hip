@@ -77,6 +77,7 @@ struct DevPlan {
   std::map<std::pair<int, int>, FactorGraph> graphs;  // by (sizeof scalar, batch size)
   DevBuf panels, srcs, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
       updTasks, updTasksFat, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc,
+      elimPackSlot,
       elimPairSlot, elimRows, elimRowSlots;
   int64_t numUpdTasks = 0;
   vector<int64_t> slowPrefix;  // tasks [0, i) that updateTileBulk cannot take
@@ -135,6 +136,7 @@ struct DevPlan {
     }
     elimChainLump.upload(host.elimChainLump);
     elimLumpDesc.upload(host.elimLumpDesc);
+    elimPackSlot.upload(host.elimPackSlot);
     elimPairSlot.upload(host.elimPairSlot);
     elimRows.upload(host.elimRows);
     elimRowSlots.upload(host.elimRowSlots);
@@ -502,6 +504,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   // destroyed around every factor() / solve(), Solver.cpp:176,223, while their kernels may still be
   // queued): sized on first use, only ever grown
   DevBuf dinvScratch, rawScratch, yieldBuf;
+  DevBuf elimPackBuf;  // packed copy of the solved blocks of a sparse-elimination range (BSP_ELIM_PACK=1)
   PtrRing ptrRing;
   bool rowFormAttrSet[2] = {false, false};  // elimRowMfma dynamic-LDS attribute (fp64, fp32)
   std::map<std::pair<int64_t, int64_t>, std::pair<std::unique_ptr<DevBuf>, size_t>> addMvTileLists;
@@ -870,11 +873,26 @@ struct HipNumericCtx : NumericCtx<T> {
     if (nLumps <= 0) return;
     const unsigned gF = (unsigned)((nLumps + 3) / 4);
     timer.begin(kProfElimFactor);
+    // packed copy of the solved blocks for the gather update (ElimRangePlan::packRows)
+    const bool packed = er.packRows > 0 && er.maxWidth <= 4 && sym.elimFactorDesc && er.useGather &&
+                        !er.useRowForm;
+    if (er.packRows > 0 && !packed) {
+      throw std::runtime_error("HIP backend: this plan's sparse-elimination update reads packed operands "
+                               "(BSP_ELIM_PACK=1), which the selected kernels do not write");
+    }
+    const int64_t packStride = er.packSlots * kElimPackSlot;
+    BT* packBuf = nullptr;
+    if (packed) {
+      sym.elimPackBuf.resize((size_t)(packStride * batchSize) * sizeof(BT));
+      packBuf = reinterpret_cast<BT*>(sym.elimPackBuf.ptr);
+    }
     if (er.maxWidth <= 4 && sym.elimFactorDesc) {
       const int64_t perWg = 4 * hipk::kTinyPerWave;
       hipk::elimFactorTiny<BT><<<dim3((unsigned)((nLumps + perWg - 1) / perWg), gy), 256, 0,
                                 sym.stream>>>(
-          plan.elimLumpDesc.as<ElimLumpDesc>() + er.descBegin, ref, (int)nLumps);
+          plan.elimLumpDesc.as<ElimLumpDesc>() + er.descBegin, ref, (int)nLumps,
+          packed ? plan.elimPackSlot.as<int32_t>() + er.packSlotOff : nullptr, er.packRows, packBuf,
+          packStride);
     } else if (er.maxWidth <= 4) {
       hipk::elimFactorSmall<BT, 4><<<dim3(gF, gy), 256, 0, sym.stream>>>(sk, ref, er.lumpBegin,
                                                                         er.lumpEnd);
@@ -916,7 +934,7 @@ struct HipNumericCtx : NumericCtx<T> {
           timer.begin(kProfElimUpdate, sym.elimStream());
           hipk::elimGatherMfma<BT><<<dim3((unsigned)((n + 3) / 4), gy), 256, 0, sym.elimStream()>>>(
               plan.elimItems.as<ElimGatherItem>() + er.groupItem[q], plan.elimPairOffJ.as<uint32_t>(),
-              plan.elimPairOffI.as<uint32_t>(), ref, (int)n);
+              plan.elimPairOffI.as<uint32_t>(), ref, (int)n, packBuf, packStride);
           timer.end();
         }
         hipEvent_t done = sym.eventFromPool();
@@ -929,7 +947,7 @@ struct HipNumericCtx : NumericCtx<T> {
         timer.begin(kProfElimUpdate);
         hipk::elimGatherMfma<BT><<<dim3((unsigned)((nItems + 3) / 4), gy), 256, 0, sym.stream>>>(
             plan.elimItems.as<ElimGatherItem>() + er.itemBegin, plan.elimPairOffJ.as<uint32_t>(),
-            plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems);
+            plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems, packBuf, packStride);
         timer.end();
       }
       const int64_t nWide = er.ldsEnd - er.ldsBegin;

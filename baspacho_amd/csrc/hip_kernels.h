@@ -204,7 +204,11 @@ __global__ __launch_bounds__(256) void elimFactorSmall(SkelDev sk, DataRef<T> dr
 constexpr int kTinyPerWave = 4, kTinyPasses = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs, DataRef<T> dref,
-                                                      int numLumps) {
+                                                      int numLumps, const int32_t* packSlot = nullptr,
+                                                      int packRows = 0, T* packBuf = nullptr,
+                                                      int64_t packStride = 0) {
+  // packBuf: second copy of every solved below block, block b of lump idx at slot packSlot[idx] + b
+  // (kElimPackSlot elements each; all blocks have packRows rows): the operands of the gather update
   // kTinyPerWave lumps per wave (64 / kTinyPerWave lanes each), kTinyPasses rows per lane in
   // flight: the kernel is bound by the bytes in flight per wave slot, not by bandwidth
   constexpr int G = 64 / kTinyPerWave, NPASS = kTinyPasses;
@@ -216,6 +220,9 @@ __global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs,
   if (n > 4) return;  // (the caller checks the range's maximum width)
   GP<T> D = pickData(dref) + ld.diagOff;
   GP<T> B = D + n * n;
+  GP<T> packed = packBuf ? (GP<T>)packBuf + blockIdx.y * packStride +
+                               (int64_t)packSlot[idx] * kElimPackSlot
+                         : nullptr;
   // diagonal block (lower part), padded with the identity
   T a[4][4];
 #pragma unroll
@@ -285,6 +292,14 @@ __global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs,
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (j < n) row[j] = y[j];
+      }
+      if (packed) {
+        const int blk = r / packRows, rr = r - blk * packRows;
+        GP<T> prow = packed + blk * kElimPackSlot + rr * n;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (j < n) prow[j] = y[j];
+        }
       }
     }
   }
@@ -516,14 +531,22 @@ __global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, c
 template <typename T>
 __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* items,
                                                       const uint32_t* offJ, const uint32_t* offI,
-                                                      DataRef<T> dref, int numItems) {
+                                                      DataRef<T> dref, int numItems,
+                                                      const T* packBuf = nullptr,
+                                                      int64_t packStride = 0) {
+  // packBuf: the pair offsets point into the packed copy of the solved blocks (elimFactorTiny)
+#ifdef BSP_GATHER_U
+  constexpr int U = BSP_GATHER_U;
+#else
   constexpr int U = 8;
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
   const int idx = blockIdx.x * 4 + wave;
   if (idx >= numItems) return;
   const ElimGatherItem it = items[idx];
   GP<T> data = pickData(dref);
+  GP<const T> src = packBuf ? (GP<const T>)packBuf + blockIdx.y * packStride : (GP<const T>)data;
   const int rows = it.rows, cols = it.cols, n = it.n;
   using Acc = typename Mfma<T>::Acc;
   Acc acc = {0, 0, 0, 0};
@@ -542,8 +565,8 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
           const int t = min(t0 + u, cnt - 1);
           const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)myJ, t);
           const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)myI, t);
-          a[u] = data[oj + eA];
-          b[u] = data[oi + eB];
+          a[u] = src[oj + eA];
+          b[u] = src[oi + eB];
         }
         // (no branch per pair: pairs past the end of the list multiply zeros)
 #pragma unroll

@@ -89,12 +89,54 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
     for (int64_t c = sk.chainColPtr[t]; c < sk.chainColPtr[t + 1]; c++) chainOfSpan[sk.chainRowSpan[c]] = c;
     mappedLump = t;
   };
+  // PACKED OPERANDS (ElimRangePlan::packRows): lumps of width <= 4 (the descriptor-driven factor
+  // kernel writes the copy), every below block with the same number of rows h, 16 < h * h and
+  // h <= 16 (every item is then an MFMA item), h * width <= one slot.
+  er.packRows = 0;
+  std::vector<int32_t> packSlotOfLump;
+  {
+    const char* e = std::getenv("BSP_ELIM_PACK");
+    const char* r = std::getenv("BSP_GATHER_ROW_FORM");
+    const bool want = e && e[0] == '1' && !(r && r[0] == '1');
+    bool ok = want && er.lumpEnd > er.lumpBegin;
+    int64_t h = -1, slots = 0;
+    for (int64_t l = er.lumpBegin; ok && l < er.lumpEnd; l++) {
+      LumpCols g = lumpCols(sk, l);
+      ok = g.width <= 4;
+      packSlotOfLump.push_back((int32_t)slots);
+      for (int64_t c = g.chain0 + g.diagChains; ok && c < g.chain0 + g.nChains; c++) {
+        const int64_t sp = sk.chainRowSpan[c];
+        const int64_t rows = sk.spanStart[sp + 1] - sk.spanStart[sp];
+        if (h < 0) h = rows;
+        ok = rows == h && h * g.width <= kElimPackSlot;
+        slots++;
+      }
+    }
+    ok = ok && h > 0 && h <= 16 && h * h > 16 && slots * kElimPackSlot < (int64_t(1) << 31);
+    if (ok) {
+      er.packRows = (int32_t)h;
+      er.packSlots = slots;
+    } else {
+      packSlotOfLump.clear();
+    }
+  }
+  // (every exit that leaves the range without gather items must leave it unpacked too)
+  struct Unpack {
+    ElimRangePlan& er;
+    ~Unpack() {
+      if (!er.useGather || er.useRowForm) er.packRows = 0;
+    }
+  } unpackOnFailure{er};
   // enumerate(f): f(targetChain, si, width, offJ, offI) for every pair; false if unsupported
   auto enumerate = [&](auto&& f) -> bool {
     for (int64_t l = er.lumpBegin; l < er.lumpEnd; l++) {
       LumpCols g = lumpCols(sk, l);
       if (g.width > 255) return false;
       const int64_t cBegin = g.chain0 + g.diagChains, cEnd = g.chain0 + g.nChains;
+      const int64_t slot0 = er.packRows ? packSlotOfLump[l - er.lumpBegin] : 0;
+      auto srcOff = [&](int64_t c) {
+        return er.packRows ? (slot0 + (c - cBegin)) * kElimPackSlot : sk.chainData[c];
+      };
       for (int64_t i = cBegin; i < cEnd; i++) {
         const int64_t si = sk.chainRowSpan[i];
         const int64_t siSize = sk.spanStart[si + 1] - sk.spanStart[si];
@@ -104,7 +146,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
           const int64_t sj = sk.chainRowSpan[j];
           if ((sk.spanStart[sj + 1] - sk.spanStart[sj]) * siSize > kGatherMaxElems) return false;
           const int64_t tc = chainOfSpan[sj];
-          f(tc, si, g.width, sk.chainData[j], sk.chainData[i]);
+          f(tc, si, g.width, srcOff(j), srcOff(i));
         }
       }
     }
@@ -282,6 +324,8 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   plan.elimPairOffJ.reserve(plan.elimPairOffJ.size() + (size_t)nPairs);
   plan.elimPairOffI.reserve(plan.elimPairOffI.size() + (size_t)nPairs);
   er.itemBegin = (int64_t)plan.elimItems.size();
+  int64_t maxPairs = kGatherMaxPairs;
+  if (const char* e = std::getenv("BSP_GATHER_MAX_PAIRS")) maxPairs = std::max(8, atoi(e));
   vector<int64_t> itemRowTag;  // target chain of every emitted item
   vector<int32_t> itemChunk;   // source-data chunk of every emitted item
   vector<int32_t> itemColBlock;  // outer block of the target column inside its lump
@@ -309,7 +353,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
       while (u < q1) {  // split by source width and by length
         int64_t u1 = u;
         const uint32_t chunkOfU = sorted[u].offJ / kGatherChunkElems;
-        while (u1 < q1 && sorted[u1].width == sorted[u].width && u1 - u < kGatherMaxPairs &&
+        while (u1 < q1 && sorted[u1].width == sorted[u].width && u1 - u < maxPairs &&
                sorted[u1].offJ / kGatherChunkElems == chunkOfU) {
           u1++;
         }
@@ -342,6 +386,10 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   }
   er.itemEnd = (int64_t)plan.elimItems.size();
   er.useGather = true;
+  if (er.packRows) {
+    er.packSlotOff = (int64_t)plan.elimPackSlot.size();
+    plan.elimPackSlot.insert(plan.elimPackSlot.end(), packSlotOfLump.begin(), packSlotOfLump.end());
+  }
   // items whose target block has at most 16 elements (e.g. 3x3 blocks of automatically detected
   // ranges) go to the kernel that packs four items per wave: move them behind the others
   {

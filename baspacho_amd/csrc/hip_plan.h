@@ -156,8 +156,15 @@ struct ElimGatherItem {
                             // items hold one or two pairs, and reading the list costs a dependent
                             // round trip (K2t)
 };
+constexpr int kElimPackSlot = 32;      // elements per slot of the packed operand copy
 constexpr int kGatherMaxElems = 256;   // rows*cols handled per wave (4 per lane)
-constexpr int kGatherMaxPairs = 2048;  // pairs per work item (longer lists are split)
+// pairs per work item: longer lists are split (the pieces subtract from the target with atomics).
+// One wave walks an item 8 pairs per memory round trip, so a 2048-pair item (the diagonal targets
+// of a bundle-adjustment problem: every point a camera sees; 17 % of all pairs sit in 0.2 % of the
+// targets) took 256 round trips ~ 0.5 ms and whatever was left of them when the rest of the grid had
+// drained WAS the kernel's tail: BAL-871 1.73 ms at 2048, 1.49 at 512, 1.43 at 128, 1.42 at 64
+// (BSP_GATHER_MAX_PAIRS overrides; 2048+ restores the atomic-free, deterministic form).
+constexpr int kGatherMaxPairs = 128;
 constexpr uint32_t kGatherChunkElems = 0xffffffffu;  // optional slicing of the source columns into
                                                      // cache-sized passes: measured 2x SLOWER on
                                                      // BAL-871 (more items + atomics), so disabled
@@ -202,6 +209,14 @@ struct ElimRangePlan {
   int64_t chainLumpOff;          // offset into elimChainLump of chain `chainBegin`
   int32_t maxWidth;              // widest lump of the range
   int64_t descBegin = 0;         // offset into elimLumpDesc of lump `lumpBegin`
+  // PACKED OPERANDS (opt-in at plan time, see buildElimGather): every below-diagonal block of the
+  // range has packRows rows and fits a 32-element slot; the factor kernel then writes a second
+  // copy of each solved block at slot * kElimPackSlot of a scratch buffer, and the pair offsets of
+  // the gather items point there.  A 216-byte block of 9 x 3 doubles straddles 2.7 cache lines on
+  // average where it lies in the factor, exactly 2 in its slot.
+  int32_t packRows = 0;          // 0 = off
+  int64_t packSlotOff = 0;       // offset into HipPlanHost::elimPackSlot of lump `lumpBegin`
+  int64_t packSlots = 0;         // slots of the range
   std::vector<LevelRange> bigLevels;  // lumps wider than kElimSmallMax go through panels
   bool useGather = false;             // pair updates in gather form (atomic-free) ...
   int64_t itemBegin = 0, itemEnd = 0; // ... over these ElimGatherItems (one wave per item)
@@ -236,6 +251,7 @@ struct HipPlanHost {
   std::vector<int32_t> elimChainLump;  // lump of every chain inside elimination ranges
   std::vector<ElimLumpDesc> elimLumpDesc;  // every lump of every elimination range
   std::vector<ElimGatherItem> elimItems;
+  std::vector<int32_t> elimPackSlot;  // per eliminated lump of a packed range: slot of its first below block
   std::vector<uint32_t> elimPairOffJ, elimPairOffI;
   std::vector<uint16_t> elimPairSlot;  // row form: accumulator slot of every pair
   std::vector<ElimRowItem> elimRows;

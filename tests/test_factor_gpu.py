@@ -559,3 +559,40 @@ def test_in_register_cholesky_and_row_solves(dtype):
             assert np.linalg.norm(np.tril(got[c0:c0 + n, c0:c0 + n]) - L) < tol, (n, k)
             X = np.linalg.solve(L, A[t0:t0 + m, c0:c0 + n].T).T      # rows * L^-T
             assert np.linalg.norm(got[t0:t0 + m, c0:c0 + n] - X) < tol, (n, k)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_packed_elimination_operands(monkeypatch, dtype):
+    """BSP_ELIM_PACK=1: the factor kernel of a sparse-elimination range writes a second, slot-aligned
+    copy of every solved block and the gather update reads its operands there (a 9 x 3 block
+    straddles 2.7 cache lines in place, 2 in its slot).  Same factor as the oracle, single and
+    batched; a structure the packing does not apply to (blocks of different heights) is unaffected"""
+    monkeypatch.setenv("BSP_ELIM_PACK", "1")
+    sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=70, num_pts=7000, band=9, seed=13)
+    sol = B.create_solver(B.Settings(), sizes, ss, [0, 7000])
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    data = spd_data(sol, 11, beta_factor=1.2, dtype=dtype)
+    ref = data.astype(np.float64)
+    cref.factor(sol.skel(), ref, sol.sparseEliminationRanges())
+    mask = sol.lowerMask()
+    got = _gpu_factor(sol, data)
+    assert np.linalg.norm((got - ref)[mask]) / np.linalg.norm(ref[mask]) < tol
+    # batch of 3 (one slice of the packed buffer per matrix)
+    datas = [spd_data(sol, 20 + q, beta_factor=1.2, dtype=dtype) for q in range(3)]
+    devs = [to_dev(d) for d in datas]
+    sol.factor(devs)
+    for d, h in zip(devs, datas):
+        ref = h.astype(np.float64)
+        cref.factor(sol.skel(), ref, sol.sparseEliminationRanges())
+        assert np.linalg.norm((d.cpu().numpy() - ref)[mask]) / np.linalg.norm(ref[mask]) < tol
+    # doElimination alone
+    d = to_dev(datas[0])
+    sol.doElimination(d, 0)
+    ref = datas[0].astype(np.float64)
+    cref.do_elimination(sol.skel(), ref, 0, 7000)
+    assert np.linalg.norm((d.cpu().numpy() - ref)[mask]) / np.linalg.norm(ref[mask]) < tol
+    # mixed block heights: not packed, same answer
+    sol2, _, _ = solver_random(61, fill=0.03, elim=(0, 60), ranges=[0, 60])
+    data2 = spd_data(sol2, 3, dtype=dtype)
+    L, _ = dense_lower_chol(sol2, data2)
+    assert np.linalg.norm(lower_of(sol2, _gpu_factor(sol2, data2)) - L) < EPS[dtype][1]
