@@ -334,7 +334,8 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipSymbolicCtx(const CoalescedBlockMatrixSkel& skel_, const vector<int64_t>& permutation_)
       : skel(skel_), permutation(permutation_) {
     if (const char* e = std::getenv("BSP_NO_LOOKAHEAD")) lookaheadEnabled = e[0] == '0';
-    if (const char* e = std::getenv("BSP_BULK_EXTRA_LDS")) bulkExtraLds = (unsigned)atoi(e);
+    if (const char* e = std::getenv("BSP_BULK_EXTRA_LDS")) bulkExtraLds = dueExtraLds = (unsigned)atoi(e);
+    if (const char* e = std::getenv("BSP_DUE_EXTRA_LDS")) dueExtraLds = (unsigned)atoi(e);
     if (const char* e = std::getenv("BSP_FUSE_POTRF")) fusePotrf = e[0] != '0';
     if (const char* e = std::getenv("BSP_BLOCK_SOLVE")) blockSolve = e[0] != '0';
     if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
@@ -478,6 +479,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool profileInSitu = false;  // profile with the lookahead schedule left on (two streams)
   bool lookaheadEnabled = true;
   unsigned bulkExtraLds = 6 * 1024;
+  unsigned dueExtraLds = 6 * 1024;  // LDS padding of the due units' launches (BSP_DUE_EXTRA_LDS)
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
   bool dueStream = true;       // due lookahead units on a stream of their own (BSP_DUE_STREAM=0: one side stream)
   bool mergeDeferred = false;  // BSP_MERGE_DEF=1: due + optional lookahead units of a block in one launch
@@ -738,16 +740,16 @@ struct HipNumericCtx : NumericCtx<T> {
             waitGather(due, lr.defWaitGatherMid, waitedDue);
             if (sym.dueSplit && lr.defMid0 > lr.defBegin && lr.defMid > lr.defMid0) {
               timer.begin(kProfUpdate, due);
-              launchUpdate(plan, lr.defBegin, lr.defMid0, ref, due, nullptr, 0, sym.bulkExtraLds, sideMask);
+              launchUpdate(plan, lr.defBegin, lr.defMid0, ref, due, nullptr, 0, sym.dueExtraLds, sideMask);
               timer.end();
               due0Done[li] = sym.eventFromPool();
               hipCHECK(hipEventRecord(due0Done[li], due));
               timer.begin(kProfUpdate, due);
-              launchUpdate(plan, lr.defMid0, lr.defMid, ref, due, nullptr, 0, sym.bulkExtraLds, sideMask);
+              launchUpdate(plan, lr.defMid0, lr.defMid, ref, due, nullptr, 0, sym.dueExtraLds, sideMask);
               timer.end();
             } else {
               timer.begin(kProfUpdate, due);
-              launchUpdate(plan, lr.defBegin, lr.defMid, ref, due, nullptr, 0, sym.bulkExtraLds, sideMask);
+              launchUpdate(plan, lr.defBegin, lr.defMid, ref, due, nullptr, 0, sym.dueExtraLds, sideMask);
               timer.end();
             }
           }
