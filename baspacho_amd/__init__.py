@@ -340,12 +340,24 @@ class Solver:
             out[name] = np.concatenate([buf[:, :nsz], buf[:, 3:4]], axis=1)
         return out
 
+    def _factor_partial_batched(self, which, data, span_index):
+        for t in data:
+            self._check_data(t)
+        ptrs = (ctypes.c_void_p * len(data))(*[_ptr_of(t) for t in data])
+        _check(getattr(self._lib, "bsp_factor_partial_batched_" + _suffix(data[0]))(
+            self._h, ptrs, ctypes.c_int32(len(data)), ctypes.c_int64(span_index), ctypes.c_int32(which)))
+
     def factorUpTo(self, data, span_index):
+        """Solver::factorUpTo<T> / <std::vector<T*>> (list/tuple of tensors = batch)"""
+        if isinstance(data, (list, tuple)):
+            return self._factor_partial_batched(0, data, span_index)
         self._check_data(data)
         _check(getattr(self._lib, "bsp_factor_up_to_" + _suffix(data))(
             self._h, ctypes.c_void_p(_ptr_of(data)), ctypes.c_int64(span_index)))
 
     def factorFrom(self, data, span_index):
+        if isinstance(data, (list, tuple)):
+            return self._factor_partial_batched(1, data, span_index)
         self._check_data(data)
         _check(getattr(self._lib, "bsp_factor_from_" + _suffix(data))(
             self._h, ctypes.c_void_p(_ptr_of(data)), ctypes.c_int64(span_index)))
@@ -385,9 +397,19 @@ class Solver:
         self._solve("bsp_solve_lt_", mat, vec, stride, nRHS)
 
     def _solve_partial(self, which, mat, span_index, vec, stride, nrhs):
-        self._check_data(mat)
         if stride is None:
             stride = self.order()
+        if isinstance(mat, (list, tuple)):  # batch
+            assert isinstance(vec, (list, tuple)) and len(vec) == len(mat)
+            for t in mat:
+                self._check_data(t)
+            mats = (ctypes.c_void_p * len(mat))(*[_ptr_of(t) for t in mat])
+            vecs = (ctypes.c_void_p * len(vec))(*[_ptr_of(t) for t in vec])
+            _check(getattr(self._lib, "bsp_solve_partial_batched_" + _suffix(mat[0]))(
+                self._h, mats, vecs, ctypes.c_int32(len(mat)), ctypes.c_int64(stride),
+                ctypes.c_int32(nrhs), ctypes.c_int32(which), ctypes.c_int64(span_index)))
+            return
+        self._check_data(mat)
         _check(getattr(self._lib, "bsp_solve_partial_" + _suffix(mat))(
             self._h, ctypes.c_void_p(_ptr_of(mat)), ctypes.c_void_p(_ptr_of(vec)),
             ctypes.c_int64(stride), ctypes.c_int32(nrhs), ctypes.c_int32(which),

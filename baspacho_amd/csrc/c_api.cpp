@@ -386,6 +386,63 @@ static void solveBatched(bsp_solver* s, const T* const* mats, T* const* vecs, in
     throw std::runtime_error("bsp_solve_batched: which must be 0 (solve), 1 (L) or 2 (Lt)");
   }
 }
+// batched partial factor: which = 0 factorUpTo, 1 factorFrom
+template <typename T>
+static void factorPartialBatched(bsp_solver* s, T* const* ptrs, int32_t batch, int64_t span,
+                                 int32_t which) {
+  std::vector<T*> v(ptrs, ptrs + batch);
+  if (which == 0) {
+    s->solver->factorUpTo(&v, span);
+  } else if (which == 1) {
+    s->solver->factorFrom(&v, span);
+  } else {
+    throw std::runtime_error("bsp_factor_partial_batched: which must be 0 (UpTo) or 1 (From)");
+  }
+}
+int bsp_factor_partial_batched_f64(bsp_solver* s, double* const* ptrs, int32_t batch, int64_t span,
+                                   int32_t which) {
+  BSP_TRY
+  factorPartialBatched<double>(s, ptrs, batch, span, which);
+  BSP_CATCH
+}
+int bsp_factor_partial_batched_f32(bsp_solver* s, float* const* ptrs, int32_t batch, int64_t span,
+                                   int32_t which) {
+  BSP_TRY
+  factorPartialBatched<float>(s, ptrs, batch, span, which);
+  BSP_CATCH
+}
+// batched partial solves: which as bsp_solve_partial (0 LUpTo, 1 LtUpTo, 2 LFrom, 3 LtFrom)
+template <typename T>
+static void solvePartialBatched(bsp_solver* s, const T* const* mats, T* const* vecs, int32_t batch,
+                                int64_t stride, int32_t nrhs, int32_t which, int64_t span) {
+  std::vector<T*> m(batch), v(vecs, vecs + batch);
+  for (int32_t q = 0; q < batch; q++) m[q] = const_cast<T*>(mats[q]);
+  if (which == 0) {
+    s->solver->solveLUpTo(&m, span, &v, stride, nrhs);
+  } else if (which == 1) {
+    s->solver->solveLtUpTo(&m, span, &v, stride, nrhs);
+  } else if (which == 2) {
+    s->solver->solveLFrom(&m, span, &v, stride, nrhs);
+  } else if (which == 3) {
+    s->solver->solveLtFrom(&m, span, &v, stride, nrhs);
+  } else {
+    throw std::runtime_error("bsp_solve_partial_batched: which must be 0..3");
+  }
+}
+int bsp_solve_partial_batched_f64(bsp_solver* s, const double* const* mats, double* const* vecs,
+                                  int32_t batch, int64_t stride, int32_t nrhs, int32_t which,
+                                  int64_t span) {
+  BSP_TRY
+  solvePartialBatched<double>(s, mats, vecs, batch, stride, nrhs, which, span);
+  BSP_CATCH
+}
+int bsp_solve_partial_batched_f32(bsp_solver* s, const float* const* mats, float* const* vecs,
+                                  int32_t batch, int64_t stride, int32_t nrhs, int32_t which,
+                                  int64_t span) {
+  BSP_TRY
+  solvePartialBatched<float>(s, mats, vecs, batch, stride, nrhs, which, span);
+  BSP_CATCH
+}
 int bsp_solve_batched_f64(bsp_solver* s, const double* const* mats, double* const* vecs,
                           int32_t batch, int64_t stride, int32_t nrhs, int32_t which) {
   BSP_TRY

@@ -188,6 +188,19 @@ int bsp_solve_batched_f64(bsp_solver* s, const double* const* dev_mats, double* 
                           int32_t batch, int64_t stride, int32_t nrhs, int32_t which);
 int bsp_solve_batched_f32(bsp_solver* s, const float* const* dev_mats, float* const* dev_vecs,
                           int32_t batch, int64_t stride, int32_t nrhs, int32_t which);
+/* the batch forms of the partial operations (Solver.cpp:491-519 instantiates factorUpTo / factorFrom
+   / solveLUpTo / solveLtUpTo for std::vector<T*>; solveLFrom / solveLtFrom come with them here).
+   factor: which 0 = factorUpTo, 1 = factorFrom; solve: which as bsp_solve_partial_* */
+int bsp_factor_partial_batched_f64(bsp_solver* s, double* const* dev_ptrs, int32_t batch,
+                                   int64_t span_index, int32_t which);
+int bsp_factor_partial_batched_f32(bsp_solver* s, float* const* dev_ptrs, int32_t batch,
+                                   int64_t span_index, int32_t which);
+int bsp_solve_partial_batched_f64(bsp_solver* s, const double* const* dev_mats,
+                                  double* const* dev_vecs, int32_t batch, int64_t stride,
+                                  int32_t nrhs, int32_t which, int64_t span_index);
+int bsp_solve_partial_batched_f32(bsp_solver* s, const float* const* dev_mats, float* const* dev_vecs,
+                                  int32_t batch, int64_t stride, int32_t nrhs, int32_t which,
+                                  int64_t span_index);
 
 /* ---- BAL caller pipeline on the device (benchmarking/BaAtLargeOptimizer.cpp:100-131 computeStep,
    with the 9-parameter cameras of a BAL file: Rodrigues rotation, translation, f, k1, k2).  All

@@ -285,3 +285,49 @@ def test_mixed_precision_refinement():
     assert hist[0] < 1e-4  # the fp32 solve alone is already a decent solution
     A = sol.densify(data, fill_upper_half=True)
     assert np.linalg.norm(A @ x.cpu().numpy() - b) / np.linalg.norm(b) < 1e-10
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_batched_partial_factor_and_solves(dtype):
+    """the batch forms of the partial operations (Solver.cpp:491-519: factorUpTo / factorFrom /
+    solveLUpTo / solveLtUpTo for std::vector<T*>; solveLFrom / solveLtFrom with them): each entry of
+    a batch must come out as the single-matrix call on the same data does"""
+    sol, _, _ = solver_random(63, size=215, fill=0.03, elim=(0, 150), psize_seed=47, pmin=2, pmax=3)
+    sk = sol.skel()
+    ranges = sol.sparseEliminationRanges()
+    dense_from = int(ranges[-1]) if len(ranges) else 0
+    lump = (dense_from + sol.numLumps()) // 2
+    span = int(sk["lumpToSpan"][lump])
+    n, nrhs, nb = sol.order(), 2, 4
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    datas = [spd_data(sol, 30 + q, dtype=dtype) for q in range(nb)]
+    # factorUpTo + factorFrom, batched, against the single calls
+    single = []
+    for h in datas:
+        d = to_dev(h)
+        sol.factorUpTo(d, span)
+        mid = d.cpu().numpy().copy()
+        sol.factorFrom(d, span)
+        single.append((mid, d.cpu().numpy().copy()))
+    devs = [to_dev(h) for h in datas]
+    sol.factorUpTo(devs, span)
+    for q in range(nb):
+        ref = single[q][0]
+        assert np.linalg.norm(devs[q].cpu().numpy() - ref) / np.linalg.norm(ref) < tol, ("UpTo", q)
+    sol.factorFrom(devs, span)
+    for q in range(nb):
+        ref = single[q][1]
+        assert np.linalg.norm(devs[q].cpu().numpy() - ref) / np.linalg.norm(ref) < tol, ("From", q)
+    # partial solves on the factors
+    rhs = [T.random_data(n * nrhs, -1.0, 1.0, 70 + q).astype(dtype) for q in range(nb)]
+    for name in ("solveLUpTo", "solveLtUpTo", "solveLFrom", "solveLtFrom"):
+        refs = []
+        for q in range(nb):
+            v = to_dev(rhs[q])
+            getattr(sol, name)(devs[q], span, v, n, nrhs)
+            refs.append(v.cpu().numpy().astype(np.float64))
+        vs = [to_dev(r) for r in rhs]
+        getattr(sol, name)(devs, span, vs, n, nrhs)
+        for q in range(nb):
+            got = vs[q].cpu().numpy().astype(np.float64)
+            assert np.linalg.norm(got - refs[q]) / max(np.linalg.norm(refs[q]), 1e-30) < tol * 10, (name, q)
