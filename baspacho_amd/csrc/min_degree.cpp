@@ -1,6 +1,7 @@
 #include "min_degree.h"
 
 #include <algorithm>
+#include <unordered_set>
 
 #include "bsp_utils.h"
 
@@ -65,33 +66,56 @@ struct QuotientGraph {
 // and leaves the contracted graph in adj (dead nodes have alive[i] == 0).
 static std::vector<int64_t> contractChains(std::vector<std::vector<int32_t>>& adj,
                                            std::vector<uint8_t>& alive, int64_t minRound) {
+  // Adjacency lists keep their dead entries (skipped on the way, dropped by the caller) and live
+  // degrees are counted separately, so that a hub with 10^5 leaves costs its leaves nothing; the
+  // edge set for "is the fill edge new" is built on first use only (graphs without such pivots --
+  // grids, dense camera blocks -- never pay for it).
   const int64_t n = (int64_t)adj.size();
   std::vector<int64_t> order;
+  std::vector<int32_t> deg(n);
+  for (int64_t v = 0; v < n; v++) deg[v] = (int32_t)adj[v].size();
   std::vector<int64_t> blockedAt(n, -1);
-  std::vector<int32_t> picked;
+  struct Pick { int32_t v, a, b; };  // pivot and its (up to two) live neighbours, -1 = none
+  std::vector<Pick> picked;
+  std::unordered_set<uint64_t> edges;
+  bool haveEdges = false;
+  auto key = [](int32_t x, int32_t y) {
+    return (uint64_t)(uint32_t)std::min(x, y) << 32 | (uint32_t)std::max(x, y);
+  };
   for (int64_t round = 0;; round++) {
     picked.clear();
     for (int64_t v = 0; v < n; v++) {
-      if (!alive[v] || adj[v].size() > 2 || blockedAt[v] == round) continue;
-      picked.push_back((int32_t)v);
-      for (int32_t u : adj[v]) blockedAt[u] = round;
+      if (!alive[v] || deg[v] > 2 || blockedAt[v] == round) continue;
+      Pick p{(int32_t)v, -1, -1};
+      for (int32_t u : adj[v]) {
+        if (!alive[u]) continue;
+        (p.a < 0 ? p.a : p.b) = u;
+      }
+      picked.push_back(p);
+      if (p.a >= 0) blockedAt[p.a] = round;
+      if (p.b >= 0) blockedAt[p.b] = round;
     }
     if ((int64_t)picked.size() < minRound) break;
-    for (int32_t v : picked) {
-      alive[v] = 0;
-      for (int32_t u : adj[v]) {
-        auto& a = adj[u];
-        a.erase(std::find(a.begin(), a.end(), v));
-      }
-      if (adj[v].size() == 2) {
-        const int32_t a = adj[v][0], b = adj[v][1];
-        if (std::find(adj[a].begin(), adj[a].end(), b) == adj[a].end()) {
-          adj[a].push_back(b);
-          adj[b].push_back(a);
+    if (!haveEdges) {
+      for (int64_t v = 0; v < n; v++) {
+        for (int32_t u : adj[v]) {
+          if (u > v) edges.insert(key((int32_t)v, u));
         }
       }
-      std::vector<int32_t>().swap(adj[v]);
-      order.push_back(v);
+      haveEdges = true;
+    }
+    for (const Pick& p : picked) {
+      alive[p.v] = 0;
+      if (p.a >= 0) deg[p.a]--;
+      if (p.b >= 0) deg[p.b]--;
+      if (p.a >= 0 && p.b >= 0 && edges.insert(key(p.a, p.b)).second) {
+        adj[p.a].push_back(p.b);
+        adj[p.b].push_back(p.a);
+        deg[p.a]++;
+        deg[p.b]++;
+      }
+      std::vector<int32_t>().swap(adj[p.v]);
+      order.push_back(p.v);
     }
   }
   return order;
@@ -137,7 +161,7 @@ std::vector<int64_t> minimumDegreeOrdering(const std::vector<int64_t>& ptrs,
   std::vector<int64_t> rPtrs(1, 0), rInds;
   for (int64_t i : oldId) {
     for (int32_t j : adj[i]) {
-      if (j < i) rInds.push_back(newId[j]);  // lower triangle is enough, the core symmetrises
+      if (j < i && alive[j]) rInds.push_back(newId[j]);  // lower triangle is enough, the core symmetrises
     }
     rPtrs.push_back((int64_t)rInds.size());
   }
