@@ -23,22 +23,24 @@ const ComputationModel ComputationModel::model_Cuda117_2080Ti{
     {1.975089750288875748e-06, -1.339369810950508464e-10, -3.758728373628488434e-10,
      1.745285595679570848e-13}};
 
-// MI355X / level-scheduled HIP backend.  The flop terms assume ~20 TF/s fp64 MFMA on mid-size
-// fronts (2*m*n*k flops for syrk/gemm), VALU-rate potrf/trsm inside 64-wide panels, and ~1 TB/s
-// effective for the scatter.  The per-op fixed costs are a small share of one kernel boundary
-// (~1.5-2 us, MI355X_MICROARCH.md "boundary"): a level batches the ops of all its lumps into one
-// launch, so merging lumps buys much less launch overhead here than on a per-op backend, while
-// the fill it adds is paid in full.  Fixed costs were set from tools/model_sweep.py on an MI355X
-// (GRID 82x82: 2.21 ms at 5x these values -> 1.75 ms; FLAT-50k and the BAL Schur problem do not
-// move between 0.15x and 80x).
+// MI355X / level-scheduled HIP backend: the least-squares fit of the per-op samples taken on an
+// MI355X (tools/op_stats_dump.py -> profiles/r02_opstats_*.csv -> tools/fit_computation_model.py ->
+// profiles/r02_model_fit.json, the pipeline of Bench.cpp:72-124 + examples/OptimizeCompModel.cpp:64-275)
+// with every op's CONSTANT term multiplied by kLevelBatchingShare = 0.03: the samples time an op as a
+// launch of its own, while a level of the fused path batches the ops of all its lumps into one
+// launch, so the marginal fixed cost of one more lump is a small share of a kernel boundary and
+// the fill a merge adds is paid in full.  The share was chosen on the device (tools/model_eval.py,
+// profiles/r02_model_eval.txt): 64 x GRID 82x82 12.44 ms at the round-1 hand-set constants, 14.6 /
+// 11.84 / 11.42 / 11.37 at shares 0.3 / 0.1 / 0.03 / 0.01; FLAT-50k 28.5 -> 27.1; BAL-871 unchanged (its
+// camera block is merged by the dense-merge rule of elimination_tree.cpp whatever the model says).
 const ComputationModel ComputationModel::model_Hip_MI355X{
     // potrf: a + b n + c n^2 + d n^3
-    {4.0e-07, 1.5e-07, 1.0e-10, 1.7e-14},
+    {3.618102371671751e-08, 3.804901435864945e-07, 6.981640690980229e-11, 8.536479805489468e-16},
     // trsm: a + b n + c n^2 + (d + e n + f n^2) k
-    {3.0e-07, 2.0e-09, 0.0, 2.0e-10, 5.0e-12, 5.0e-14},
+    {1.709462696726716e-07, 1.114928057617138e-07, 4.611165305099729e-10, 5.116797002889815e-10, 1.341879640359843e-11, 0.000000000000000e+00},
     // syge: a + b u + c v + k (d + e u + f v)
-    {3.0e-07, 1.0e-10, 2.0e-12, 5.0e-10, 1.0e-12, 1.0e-13},
+    {2.083655120359462e-07, 7.425127963497075e-10, 1.910711883161907e-12, 6.123296965670030e-08, 2.127243764724589e-12, 2.085578751310278e-15},
     // asmbl: a + b br + c bc + d br bc
-    {1.0e-07, 2.0e-09, 2.0e-09, 1.0e-10}};
+    {1.819244623955457e-07, 0.000000000000000e+00, 1.854767815091107e-08, 1.095148499821501e-09}};
 
 }  // namespace BaSpaCho

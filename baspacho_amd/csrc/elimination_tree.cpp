@@ -1,6 +1,7 @@
 #include "elimination_tree.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <queue>
 
@@ -185,7 +186,12 @@ void EliminationTree::computeMerges() {
     if (childCount[p] == 1) {
       tMerged -= kChainLevelCost * (levelsOf(sk) + levelsOf(sp) - levelsOf(sk + sp));
     }
-    if (!(tMerged < tSeparate)) continue;
+    // Extension: a child whose rows are (nearly) all of its parent's column -- the nodes of a dense
+    // trailing block, e.g. the cameras of a Schur complement -- merges whatever the model says: the
+    // merged lump adds < 10 % of explicit zeros and is one chain of panels with lookahead, the
+    // split one pays a lump boundary (BAL-871 with a model of lower fixed costs: 8.5 against 7.7 ms)
+    const bool denseMerge = std::getenv("BSP_DENSE_MERGE_OFF") == nullptr && score(k, p) >= 0.9;
+    if (!(tMerged < tSeparate) && !denseMerge) continue;
     childCount[p] += childCount[k] - 1;
 
     const int64_t oldSizeP = nodeSize[p], oldMergedP = numMergedNodes[p];

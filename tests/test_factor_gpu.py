@@ -328,7 +328,7 @@ def test_overlapped_elimination(monkeypatch, overlap, dtype):
     column blocks whose groups are complete (BSP_ELIM_OVERLAP=0: one launch before the dense
     phase); both against the oracle, single and batched"""
     monkeypatch.setenv("BSP_ELIM_OVERLAP", overlap)
-    sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=210, num_pts=24000, band=30, seed=9)
+    sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=210, num_pts=24000, band=60, seed=9)
     sol = B.create_solver(B.Settings(), sizes, ss, [0, 24000])
     st = sol.planStats()
     assert sol.numLumps() == 24001, "cameras expected in one lump"
