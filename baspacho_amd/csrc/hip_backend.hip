@@ -1423,14 +1423,19 @@ struct HipSolveCtx : SolveCtx<T> {
       for (int64_t l = startLump; l < upToLump; l++) {
         const int64_t c0 = sk.chainColPtr[l], nCh = sk.chainColPtr[l + 1] - c0;
         const int64_t rows = sk.chainRowsTillEnd[c0 + nCh - 1];
+        const int64_t n = sk.lumpStart[l + 1] - sk.lumpStart[l];
         for (int64_t r = 0; r < rows; r += kTile) {
-          tiles.push_back(l);
-          tiles.push_back(r);
+          for (int64_t c = 0; c < n; c += hipk::kMvCols) {
+            if (r < n && c > r + kTile - 1) break;  // entirely above the diagonal
+            tiles.push_back(l);
+            tiles.push_back(r);
+            tiles.push_back(c);
+          }
         }
       }
       ent.first.reset(new DevBuf);
       ent.first->upload(tiles);
-      ent.second = tiles.size() / 2;
+      ent.second = tiles.size() / 3;
     }
     if (ent.second == 0) return;
     hipk::addMvKernel<BT><<<dim3((unsigned)ent.second, (unsigned)nRHS), 256, 0, sym.stream>>>(
