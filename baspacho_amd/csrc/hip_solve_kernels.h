@@ -327,21 +327,24 @@ __global__ __launch_bounds__(256) void solveTriPanel(const PanelDesc* panels,
   __syncthreads();
   if (tid >= 64) return;
   const int lane = tid;
-  T xi = lane < nb ? x[lane] : T(0);
+  // Row i (BACKWARD: column i) is divided by its own diagonal entry up front -- lane-local, off the
+  // dependent chain -- so that a step of the chain is one broadcast and one fma: lane j's value IS
+  // x_j when step j comes.
   const T inv = T(1) / Ls[lane * LD + lane];
+  T xi = (lane < nb ? x[lane] : T(0)) * inv;
   if (!BACKWARD) {
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-      const T lij = Ls[lane * LD + j];  // column j of L, lane = row
-      const T xj = laneBcast(xi * inv, j);
-      xi = lane == j ? xj : (lane > j ? xi - lij * xj : xi);
+      const T lij = Ls[lane * LD + j] * inv;  // column j of L, lane = row
+      const T xj = laneBcast(xi, j);
+      xi = lane > j ? xi - lij * xj : xi;
     }
   } else {
 #pragma unroll
     for (int j = NB - 1; j >= 0; j--) {
-      const T lji = Ls[j * LD + lane];  // row j of L, lane = column
-      const T xj = laneBcast(xi * inv, j);
-      xi = lane == j ? xj : (lane < j ? xi - lji * xj : xi);
+      const T lji = Ls[j * LD + lane] * inv;  // row j of L, lane = column
+      const T xj = laneBcast(xi, j);
+      xi = lane < j ? xi - lji * xj : xi;
     }
   }
   if (lane < nb) x[lane] = xi;
@@ -448,21 +451,23 @@ __device__ __forceinline__ void triSolve64(const T* Ls, T* xs, int nb) {
   constexpr int NB = kPanelWidth, LD = NB + 1;
   const int lane = threadIdx.x;
   if (lane >= 64) return;
-  T xi = lane < nb ? xs[lane] : T(0);
+  // (rows / columns pre-divided by their diagonal entry: one broadcast + one fma per step, see
+  //  solveTriPanel)
   const T inv = T(1) / Ls[lane * LD + lane];
+  T xi = (lane < nb ? xs[lane] : T(0)) * inv;
   if (!BACKWARD) {
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-      const T lij = Ls[lane * LD + j];
-      const T xj = laneBcast(xi * inv, j);
-      xi = lane == j ? xj : (lane > j ? xi - lij * xj : xi);
+      const T lij = Ls[lane * LD + j] * inv;
+      const T xj = laneBcast(xi, j);
+      xi = lane > j ? xi - lij * xj : xi;
     }
   } else {
 #pragma unroll
     for (int j = NB - 1; j >= 0; j--) {
-      const T lji = Ls[j * LD + lane];
-      const T xj = laneBcast(xi * inv, j);
-      xi = lane == j ? xj : (lane < j ? xi - lji * xj : xi);
+      const T lji = Ls[j * LD + lane] * inv;
+      const T xj = laneBcast(xi, j);
+      xi = lane < j ? xi - lji * xj : xi;
     }
   }
   if (lane < nb) xs[lane] = xi;
