@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, c
 // lane (i, k) = (lane & 15, lane >> 4) supplies B_j[i][k] and B_i[i][k], i.e. every lane issues one
 // 8-byte load per operand, the 64 lanes together read the two contiguous source blocks, and nothing
 // goes through LDS (K2g spends 13 LDS wave-instructions per pair and is LDS-bandwidth bound at
-// ~12 G pairs/s).  The sum over the pairs stays in the 4 accumulator registers; loads of 8 pairs
+// ~12 G pairs/s).  The sum over the pairs stays in the 4 accumulator registers; loads of U pairs
 // are issued before their MFMAs.
 template <typename T>
 __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* items,
@@ -535,10 +535,13 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
                                                       const T* packBuf = nullptr,
                                                       int64_t packStride = 0) {
   // packBuf: the pair offsets point into the packed copy of the solved blocks (elimFactorTiny)
+  // pairs whose operand loads are in flight together.  With items of at most 128 pairs the kernel is
+  // not bound by a wave's own round trips any more: 4 / 8 / 16 give 6.87-6.92 / 6.95-6.99 / 7.03 ms on
+  // BAL-871 (fewer registers, more waves ready to issue)
 #ifdef BSP_GATHER_U
   constexpr int U = BSP_GATHER_U;
 #else
-  constexpr int U = 8;
+  constexpr int U = 4;
 #endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
