@@ -136,6 +136,31 @@ def synth_scene(num_cams=12, num_pts=200, mean_track=4, seed=3, noise=0.5, pertu
     return BalProblem(cams, pts, oc, op, xy)
 
 
+def synth_scene_for(num_cams, num_pts, obs_cam, obs_pt, seed=3, noise=0.5, perturb=1e-2):
+    """a geometrically consistent scene for a GIVEN observation list (e.g. the co-visibility of
+    testing.gen_bal_synthetic at BAL-871 / BAL-1723 size): cameras on a wide arc around a point cloud,
+    every listed observation projected through the BAL camera model + pixel noise, parameters
+    perturbed off the truth.  Vectorised (no per-point loop); the Hessian J^T J of the result is a
+    real bundle-adjustment Hessian, not a diagonally dominant mock."""
+    rng = np.random.default_rng(seed)
+    ang = np.linspace(-1.2, 1.2, num_cams)
+    cams = np.zeros((num_cams, 9))
+    cams[:, 1] = ang
+    cams[:, 0] = 0.05 * rng.standard_normal(num_cams)
+    cams[:, 3] = 2.0 * np.sin(ang)
+    cams[:, 5] = -12.0 + rng.uniform(-0.5, 0.5, num_cams)
+    cams[:, 6] = 800.0 + rng.uniform(-20, 20, num_cams)
+    cams[:, 7] = 1e-2 * rng.standard_normal(num_cams)
+    cams[:, 8] = 1e-4 * rng.standard_normal(num_cams)
+    pts = rng.uniform(-2.0, 2.0, (num_pts, 3))
+    oc = np.ascontiguousarray(obs_cam, dtype=np.int64)
+    op = np.ascontiguousarray(obs_pt, dtype=np.int64)
+    xy = project(cams[oc], pts[op]) + noise * rng.standard_normal((len(oc), 2))
+    cams = cams + perturb * rng.standard_normal(cams.shape) * np.array([1, 1, 1, 1, 1, 1, 100, 1e-2, 1e-4])
+    pts = pts + perturb * rng.standard_normal(pts.shape)
+    return BalProblem(cams, pts, oc, op, xy)
+
+
 class DevicePipeline:
     """problem data resident on the GPU + the two device stages of a Gauss-Newton / LM iteration"""
 

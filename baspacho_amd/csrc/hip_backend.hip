@@ -345,12 +345,12 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_EARLY_FORK")) earlyFork = e[0] != '0';
     if (const char* e = std::getenv("BSP_MERGED_BLOCK_LAST")) mergedBlockLast = e[0] != '0';
     if (const char* e = std::getenv("BSP_BULK_KERNEL")) bulkKernel = e[0] != '0';
-    if (const char* e = std::getenv("BSP_ELIM_OVERLAP")) elimOverlap = e[0] != '0';
     if (const char* e = std::getenv("BSP_BULK_YIELD")) bulkYield = e[0] != '0';
     if (const char* e = std::getenv("BSP_EARLY_DIAG")) earlyDiag = e[0] != '0';
     if (const char* e = std::getenv("BSP_MERGE_DEF")) mergeDeferred = e[0] != '0';
-    if (const char* e = std::getenv("BSP_DUE_STREAM")) dueStream = e[0] != '0';
-    if (const char* e = std::getenv("BSP_DUE_SPLIT")) dueSplit = e[0] != '0';
+    // the plan builder's switches: read here, once per Solver, handed to every buildHipPlan call
+    // and recorded in the plan; launchLevels takes dueStream / dueSplit from the plan it runs
+    planOpts = HipPlanOptions::fromEnv();
     if (const char* e = std::getenv("BSP_LOOKAHEAD_MIN_GF")) lookaheadMinFlops = 1e9 * std::atof(e);
     if (const char* e = std::getenv("BSP_GRAPH")) graphMode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
   }
@@ -435,7 +435,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     auto it = plans.find(key);
     if (it == plans.end()) {
       std::unique_ptr<DevPlan> p(new DevPlan);
-      p->host = buildHipPlan(skel, ranges, startLump, upToLump);
+      p->host = buildHipPlan(skel, ranges, startLump, upToLump, planOpts);
       p->upload();
       it = plans.emplace(key, std::move(p)).first;
     }
@@ -481,14 +481,12 @@ struct HipSymbolicCtx : SymbolicCtx {
   unsigned bulkExtraLds = 6 * 1024;
   unsigned dueExtraLds = 6 * 1024;  // LDS padding of the due units' launches (BSP_DUE_EXTRA_LDS)
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
-  bool dueStream = true;       // due lookahead units on a stream of their own (BSP_DUE_STREAM=0: one side stream)
+  HipPlanOptions planOpts;     // the plan builder's switches (BSP_DUE_STREAM, BSP_DUE_SPLIT, BSP_BULK_ROW_MAJOR, ...)
   bool mergeDeferred = false;  // BSP_MERGE_DEF=1: due + optional lookahead units of a block in one launch
   double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
   int graphMode = 0;           // factor() as a captured hipGraph (BSP_GRAPH): 0 never (default: measured no faster, see factorViaGraph), 1 always, 2 launch-bound plans only
-  bool dueSplit = false;       // opt-in BSP_DUE_SPLIT=1: due units in two launches (first column tile / the rest), the chain's block-last step adds to the rest with atomics
   bool earlyDiag = true;       // intra-block chain steps pre-apply their panel to the next block's tile (0,0) (BSP_EARLY_DIAG=0 disables)
   bool bulkYield = true;       // bulk tiles pause on the CU of the chain's potrf workgroup (BSP_BULK_YIELD=0 disables)
-  bool elimOverlap = false;    // sparse-elimination update overlapped with the dense phase (opt-in: BSP_ELIM_OVERLAP=1)
   bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
   bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
@@ -582,7 +580,7 @@ struct HipNumericCtx : NumericCtx<T> {
     // (fp32: its atomics cost more than the second stream returns -- BAL-871 5.86 against 5.22 ms,
     //  BAL-1723 20.5 against 18.8 -- so single-precision calls keep the one-side-stream order, and
     //  the tasks' "two streams may meet" bit is masked off)
-    const bool dueStream = sym.dueStream && !sym.mergeDeferred && sizeof(BT) == 8;
+    const bool dueStream = plan.host.opts.dueStream && !sym.mergeDeferred && sizeof(BT) == 8;
     const int sideMask = dueStream ? 3 : 1;
     // fork level of the same lump's previous block (-1: none)
     auto prevFork = [&](int64_t f) -> int64_t { return f >= 0 ? levels[f].waitDefLevel : -1; };
@@ -738,7 +736,7 @@ struct HipNumericCtx : NumericCtx<T> {
           if (f2 >= 0 && optDone[f2]) hipCHECK(hipStreamWaitEvent(due, optDone[f2], 0));
           if (lr.defMid > lr.defBegin) {
             waitGather(due, lr.defWaitGatherMid, waitedDue);
-            if (sym.dueSplit && lr.defMid0 > lr.defBegin && lr.defMid > lr.defMid0) {
+            if (plan.host.opts.dueSplit && lr.defMid0 > lr.defBegin && lr.defMid > lr.defMid0) {
               timer.begin(kProfUpdate, due);
               launchUpdate(plan, lr.defBegin, lr.defMid0, ref, due, nullptr, 0, sym.dueExtraLds, sideMask);
               timer.end();
@@ -908,6 +906,10 @@ struct HipNumericCtx : NumericCtx<T> {
     timer.end();
     launchLevels(plan, er.bigLevels, ref, timer);
     const int64_t nChains = er.chainEnd - er.chainBegin;
+    // FAULT INJECTION (BSP_FAULT_DROP_ELIM_UPDATE=1, tests only): the whole sparse-elimination
+    // update is dropped -- the factor of everything the eliminated columns touch is then wrong, and
+    // the full-size parity tests must notice (tests/test_full_size_gpu.py)
+    if (plan.host.opts.dropElimUpdate) return;
     if (er.useRowForm) {
       const int64_t nRows = er.rowEnd - er.rowBegin;
       const int ldsBytes = sizeof(BT) == 8 ? er.rowLdsBytes : er.rowLdsBytesF32;
@@ -923,7 +925,7 @@ struct HipNumericCtx : NumericCtx<T> {
           plan.elimPairOffJ.as<uint32_t>(), plan.elimPairOffI.as<uint32_t>(),
           plan.elimPairSlot.as<uint16_t>(), ref, (uint32_t)(sym.skel.dataSize() - 1));
       timer.end();
-    } else if (er.useGather && er.overlapLump >= 0 && lookaheadOn() && sym.elimOverlap &&
+    } else if (er.useGather && er.overlapLump >= 0 && lookaheadOn() && plan.host.opts.elimOverlap &&
                gatherDoneOut != nullptr) {
       // OVERLAPPED with the dense phase: the groups (items by outer block of the target column)
       // run in order on a stream of their own; the caller hands the events to launchLevels
@@ -1708,7 +1710,7 @@ HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t up
   HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
   BASPACHO_CHECK_NOTNULL(h);
   // host-only: does not touch the device
-  HipPlanHost p = buildHipPlan(h->skel, h->sparseElimRanges, startLump, upToLump);
+  HipPlanHost p = buildHipPlan(h->skel, h->sparseElimRanges, startLump, upToLump, h->planOpts);
   HipPlanStats s;
   s.flops = p.flops;
   s.updElems = p.updElems;
@@ -1736,7 +1738,7 @@ HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t up
   s.numAtomicUpdTasks = atomicTasks;
   s.numForkLevels = p.numForkLevels;
   s.deferredFlops = p.deferredFlops;
-  if (!p.elimRanges.empty() && p.elimRanges.back().overlapLump >= 0 && h->elimOverlap) {
+  if (!p.elimRanges.empty() && p.elimRanges.back().overlapLump >= 0 && p.opts.elimOverlap) {
     s.numGatherGroups = (int64_t)p.elimRanges.back().groupItem.size() - 1;
   }
   return s;

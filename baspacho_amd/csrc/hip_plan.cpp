@@ -68,7 +68,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   er.useGather = false;
   er.overlapLump = -1;
   if (sk.dataSize() >= (int64_t(1) << 32)) return;
-  const bool timing = std::getenv("BSP_TIMING") != nullptr;
+  const bool timing = plan.opts.planTiming;
   auto tic = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (!timing) return;
@@ -95,9 +95,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   er.packRows = 0;
   std::vector<int32_t> packSlotOfLump;
   {
-    const char* e = std::getenv("BSP_ELIM_PACK");
-    const char* r = std::getenv("BSP_GATHER_ROW_FORM");
-    const bool want = e && e[0] == '1' && !(r && r[0] == '1');
+    const bool want = plan.opts.elimPack && !plan.opts.gatherRowForm;
     bool ok = want && er.lumpEnd > er.lumpBegin;
     int64_t h = -1, slots = 0;
     for (int64_t l = er.lumpBegin; ok && l < er.lumpEnd; l++) {
@@ -183,10 +181,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   //      instead of 7.0 GB) but back-to-back loads of neighbouring blocks each miss on the cache
   //      line they share, and 16 waves per CU (LDS is full of accumulators) hide less latency
   //      than the 32 of the item form.
-  const bool rowFormEnabled = [] {
-    const char* e = std::getenv("BSP_GATHER_ROW_FORM");
-    return e && e[0] == '1';
-  }();
+  const bool rowFormEnabled = plan.opts.gatherRowForm;
   if (rowFormEnabled) {
     bool ok = true;
     vector<ElimRowItem> rowItems;
@@ -324,8 +319,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
   plan.elimPairOffJ.reserve(plan.elimPairOffJ.size() + (size_t)nPairs);
   plan.elimPairOffI.reserve(plan.elimPairOffI.size() + (size_t)nPairs);
   er.itemBegin = (int64_t)plan.elimItems.size();
-  int64_t maxPairs = kGatherMaxPairs;
-  if (const char* e = std::getenv("BSP_GATHER_MAX_PAIRS")) maxPairs = std::max(8, atoi(e));
+  const int64_t maxPairs = std::max<int64_t>(8, plan.opts.gatherMaxPairs);
   vector<int64_t> itemRowTag;  // target chain of every emitted item
   vector<int32_t> itemChunk;   // source-data chunk of every emitted item
   vector<int32_t> itemColBlock;  // outer block of the target column inside its lump
@@ -517,9 +511,34 @@ struct PanelBuild {
 
 }  // namespace
 
+HipPlanOptions HipPlanOptions::fromEnv() {
+  HipPlanOptions o;
+  auto on = [](const char* name, bool dflt) {
+    const char* e = std::getenv(name);
+    return e ? e[0] != '0' : dflt;
+  };
+  auto optIn = [](const char* name) {
+    const char* e = std::getenv(name);
+    return e && e[0] == '1';
+  };
+  o.dueStream = on("BSP_DUE_STREAM", true);
+  o.earlyDue = optIn("BSP_EARLY_DUE") && o.dueStream;
+  o.dueSplit = optIn("BSP_DUE_SPLIT") && o.dueStream;
+  o.bulkRowMajor = on("BSP_BULK_ROW_MAJOR", true);
+  o.elimPack = optIn("BSP_ELIM_PACK");
+  o.gatherRowForm = optIn("BSP_GATHER_ROW_FORM");
+  o.elimOverlap = optIn("BSP_ELIM_OVERLAP");
+  o.planTiming = std::getenv("BSP_TIMING") != nullptr;
+  o.dropElimUpdate = optIn("BSP_FAULT_DROP_ELIM_UPDATE");
+  if (const char* e = std::getenv("BSP_GATHER_MAX_PAIRS")) o.gatherMaxPairs = std::max(8, atoi(e));
+  if (const char* e = std::getenv("BSP_BULK_AHEAD")) o.bulkAhead = std::atof(e);
+  return o;
+}
+
 HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_t>& elimRangesIn,
-                         int64_t startLump, int64_t upToLump) {
+                         int64_t startLump, int64_t upToLump, const HipPlanOptions& opts) {
   HipPlanHost plan;
+  plan.opts = opts;
   plan.startLump = startLump;
   plan.upToLump = upToLump;
   const int64_t nLumps = sk.numLumps();
@@ -528,8 +547,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
   // lookahead schedule (addPanels): assumed rate of the bulk update beside the chain, and the share
   // of the next block's estimated chain time handed to the side stream as optional work
   constexpr double kBulkFlopsPerUs = 33e6;
-  double bulkAhead = 0.6;
-  if (const char* e = std::getenv("BSP_BULK_AHEAD")) bulkAhead = std::atof(e);
+  const double bulkAhead = opts.bulkAhead;
 
   vector<vector<PanelBuild>> levelBuckets;       // dense levels
   auto bucketAt = [](vector<vector<PanelBuild>>& buckets, size_t lvl) -> vector<PanelBuild>& {
@@ -552,13 +570,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     int32_t count = 0;
     const int64_t n = g.width;
     vector<int64_t> pendingFrom;  // per column block of this lump (lookahead schedule, see below)
-    static const bool earlyDue = [] {
-      const char* e = std::getenv("BSP_EARLY_DUE");
-      const char* d = std::getenv("BSP_DUE_STREAM");
-      // (opt-in: measured 7.26-7.40 ms against 7.15-7.21 on BAL-871 -- the K = 192 + 64 split
-      //  costs the side streams more than the earlier start gives back)
-      return (e && e[0] == '1') && !(d && d[0] == '0');
-    }();
+    // (opt-in: measured 7.26-7.40 ms against 7.15-7.21 on BAL-871 -- the K = 192 + 64 split
+    //  costs the side streams more than the earlier start gives back)
+    const bool earlyDue = opts.earlyDue;
     for (int64_t blockStart = 0; blockStart < n; blockStart += kOuterWidth) {
       const int64_t blockEnd = std::min<int64_t>(n, blockStart + kOuterWidth);
       int64_t earlyDueCols = 0;  // leading columns of this block whose due unit (c = b + 2) went early
@@ -683,10 +697,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
               // front of them.  Units of different launches that may then overlap on one column
               // block accumulate with atomics: every due unit, and the optional units that reach
               // the column block the NEXT block's due units go to (c = b + 3).
-              static const bool dueStream = [] {
-                const char* e = std::getenv("BSP_DUE_STREAM");
-                return !(e && e[0] == '0');
-              }();
+              const bool dueStream = opts.dueStream;
               auto pushUnit = [&](int64_t c, int32_t outerKind) {
                 // bit 0: several units on this target in one launch; bit 1: the target may be met
                 // by a launch of the OTHER side stream (due-stream mode; the kernels take a mask, so
@@ -819,8 +830,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       const int64_t denseBegin0 = std::max(startLump, denseFrom);
       // (opt-in: measured on BAL-871 the update takes 2.4x as long beside the dense kernels and
       //  slows the chain by as much as it saves, 7.85 against 7.63 ms -- DESIGN.md "tried")
-      const char* e = std::getenv("BSP_ELIM_OVERLAP");
-      const bool enabled = e && e[0] == '1';
+      const bool enabled = opts.elimOverlap;
       if (enabled && re == denseFrom && denseBegin0 == denseFrom && upToLump == denseFrom + 1 &&
           upToLump <= nLumps && elimBigBuckets.back().empty() &&
           sk.lumpStart[denseFrom + 1] - sk.lumpStart[denseFrom] >= 6 * kOuterWidth) {
@@ -924,13 +934,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                          buckets[bi + 1].size() == 1 &&
                          plan.panels[buckets[bi + 1][0].panel].lump == plan.panels[bucket[0].panel].lump;
       vector<UpdTask> deferred, deferred1, deferredLate;  // due (first column tile) / due (rest) / optional
-      static const bool dueSplit = [] {
-        // (opt-in: measured 7.32 against 7.23 ms on BAL-871 -- the extra small launch per block
-        //  costs more than the shorter wait returns)
-        const char* e = std::getenv("BSP_DUE_SPLIT");
-        const char* d = std::getenv("BSP_DUE_STREAM");
-        return (e && e[0] == '1') && !(d && d[0] == '0');
-      }();
+      // (opt-in: measured 7.32 against 7.23 ms on BAL-871 -- the extra small launch per block
+      //  costs more than the shorter wait returns)
+      const bool dueSplit = opts.dueSplit;
       int32_t maxCbMid = -1, maxCbLate = -1;  // furthest target column block of the deferred units
       int32_t nowSegs = 0, nowSeg = -1;  // segments with non-deferred 64x64 tiles in this level
       bool nowPlain = true;              // ... all intra-lump, non-atomic, untouched order
@@ -971,10 +977,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             auto dstOf = [&](int32_t cT) -> vector<UpdTask>& {
               return late ? deferredLate : (split && cT != sd.q0 ? deferred1 : deferred);
             };
-            static const bool rowMajor = [] {
-              const char* e = std::getenv("BSP_BULK_ROW_MAJOR");
-              return !(e && e[0] == '0');
-            }();
+            const bool rowMajor = opts.bulkRowMajor;
             if (rowMajor) {
               for (int32_t rT = sd.q0; rT < sr.rowsBelow; rT += step) {
                 for (int32_t cT = sd.q0; cT < sd.q0 + sd.m && cT <= rT; cT += step) {

@@ -164,7 +164,7 @@ constexpr int kGatherMaxElems = 256;   // rows*cols handled per wave (4 per lane
 // targets) took 256 round trips ~ 0.5 ms and whatever was left of them when the rest of the grid had
 // drained WAS the kernel's tail: BAL-871 1.73 ms at 2048, 1.49 at 512, 1.43 at 128, 1.42 at 64
 // (BSP_GATHER_MAX_PAIRS overrides; 2048+ restores the atomic-free, deterministic form).
-constexpr int kGatherMaxPairs = 128;
+constexpr int kGatherMaxPairs = 128;  // default of HipPlanOptions::gatherMaxPairs
 constexpr uint32_t kGatherChunkElems = 0xffffffffu;  // optional slicing of the source columns into
                                                      // cache-sized passes: measured 2x SLOWER on
                                                      // BAL-871 (more items + atomics), so disabled
@@ -245,7 +245,30 @@ struct ElimRangePlan {
   }
 };
 
+// Every switch the plan builder honours, read ONCE (HipPlanOptions::fromEnv, called when a
+// SymbolicCtx is created) and recorded in the plan it produced: the launch code takes the
+// schedule-shaping ones (dueStream, dueSplit) from the plan it runs, never from a second read of
+// the environment, so the builder's "two streams may meet" bits and the launcher's choice of
+// streams cannot disagree.
+struct HipPlanOptions {
+  bool dueStream = true;      // BSP_DUE_STREAM: due lookahead units on a stream of their own
+  bool earlyDue = false;      // BSP_EARLY_DUE (opt-in; needs dueStream)
+  bool dueSplit = false;      // BSP_DUE_SPLIT (opt-in; needs dueStream)
+  bool bulkRowMajor = true;   // BSP_BULK_ROW_MAJOR: lookahead tiles in row-tile-major order
+  bool elimPack = false;      // BSP_ELIM_PACK (opt-in): packed operand copy for the gather
+  bool gatherRowForm = false; // BSP_GATHER_ROW_FORM (opt-in): row form of the elimination update
+  bool elimOverlap = false;   // BSP_ELIM_OVERLAP (opt-in): gather groups beside the dense phase
+  bool planTiming = false;    // BSP_TIMING: stderr laps of the gather plan
+  bool dropElimUpdate = false; // BSP_FAULT_DROP_ELIM_UPDATE=1: FAULT INJECTION for the parity tests
+                               // -- the sparse-elimination update is planned with zero pairs, so
+                               // the factor is wrong; never set outside tests
+  int32_t gatherMaxPairs = 128;  // BSP_GATHER_MAX_PAIRS
+  double bulkAhead = 0.6;     // BSP_BULK_AHEAD
+  static HipPlanOptions fromEnv();
+};
+
 struct HipPlanHost {
+  HipPlanOptions opts;
   int64_t startLump = 0, upToLump = 0;
   std::vector<ElimRangePlan> elimRanges;
   std::vector<int32_t> elimChainLump;  // lump of every chain inside elimination ranges
@@ -307,7 +330,7 @@ struct HipPlanHost {
 // inside the interval are included); `sparseElimRanges` as stored by the Solver.
 HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& skel,
                          const std::vector<int64_t>& sparseElimRanges, int64_t startLump,
-                         int64_t upToLump);
+                         int64_t upToLump, const HipPlanOptions& opts = HipPlanOptions());
 
 // Plan of ONE dense operation of the per-op boundary (NumericCtx::potrf / trsm, MatOps.h:124-127)
 // on a row-major n x n block at offA followed (contiguously, as in Solver::factorLump,

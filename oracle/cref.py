@@ -191,3 +191,16 @@ def probe_residual(sk, A, L, x):
     if rc != 0:
         raise RuntimeError("probe failed")
     return out[0] / out[1]
+
+
+def abs_row_sums(sk, A):
+    """sum_{j != i} |A_ij| for every row of the symmetric matrix laid out by the skeleton (test-input
+    helper: matrices that are diagonally dominant by a few percent only)"""
+    h = sk if isinstance(sk, SkelHandle) else SkelHandle(sk)
+    n = int(h.arrays["spanStart"][-1])
+    out = np.zeros(n, dtype=np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib().orc_abs_row_sums_f64(ctypes.byref(h.c), A.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    if rc != 0:
+        raise RuntimeError("abs_row_sums failed")
+    return out

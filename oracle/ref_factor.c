@@ -87,3 +87,33 @@ int orc_probe_residual_f64(const orc_skel* sk, const double* A, const double* L,
   free(z);
   return 0;
 }
+
+/* Test-input helper (no reference counterpart): out[i] = sum_{j != i} |A_ij| of the symmetric
+   matrix stored by the skeleton (lower triangle; strictly-upper entries of the square diagonal
+   blocks ignored).  tests/test_full_size_gpu.py uses it to build matrices that are diagonally
+   dominant by a few percent only -- SPD, but with off-diagonal mass as large as the diagonal, so
+   that a wrong update cannot hide behind the damping. */
+int orc_abs_row_sums_f64(const orc_skel* sk, const double* A, double* out) {
+  int64_t n = sk->spanStart[sk->numSpans];
+  for (int64_t i = 0; i < n; i++) out[i] = 0;
+  for (int64_t l = 0; l < sk->numLumps; l++) {
+    int64_t w = sk->lumpStart[l + 1] - sk->lumpStart[l], gc0 = sk->lumpStart[l];
+    for (int64_t c = sk->chainColPtr[l]; c < sk->chainColPtr[l + 1]; c++) {
+      int64_t span = sk->chainRowSpan[c];
+      int64_t gr0 = sk->spanStart[span], rows = sk->spanStart[span + 1] - gr0;
+      const double* a = A + sk->chainData[c];
+      for (int64_t r = 0; r < rows; r++) {
+        int64_t gr = gr0 + r;
+        int64_t qEnd = gr - gc0 < w ? gr - gc0 : w; /* columns with gc < gr */
+        double acc = 0;
+        for (int64_t q = 0; q < qEnd; q++) {
+          double v = fabs(a[r * w + q]);
+          acc += v;
+          out[gc0 + q] += v;
+        }
+        out[gr] += acc;
+      }
+    }
+  }
+  return 0;
+}

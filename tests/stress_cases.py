@@ -1,0 +1,59 @@
+"""Randomised parity cases shared by tests/test_stress_gpu.py (a seeded slice, run by the driver)
+and tools/stress.py (long sweeps): random structures / parameter sizes / elimination sets / dtypes /
+batch sizes, factor + solve + addMvFrom on the device against dense numpy, the protocol of the
+reference's random families (tests/FactorTest.cpp:75-107,185-219; tests/SolveTest.cpp)."""
+import numpy as np
+
+import baspacho_amd as B
+from baspacho_amd import testing as T
+from helpers import dense_lower_chol, lower_of, spd_data, to_dev
+
+
+def run_case(seed, big=False):
+    """raises AssertionError (with the failing stage and error) when the device result is off"""
+    rng = np.random.default_rng(seed)
+    size = int(rng.integers(300, 900)) if big else int(rng.integers(20, 260))
+    fill = float(rng.choice([0.05, 0.15, 0.5])) if big else float(rng.choice([0.01, 0.03, 0.08, 0.3]))
+    pmax = int(rng.choice([3, 6, 9])) if big else int(rng.choice([1, 3, 5, 9, 23]))
+    sizes = rng.integers(1, pmax + 1, size=size).astype(np.int64)
+    cols = T.random_cols(size, fill, 100 + seed)
+    ranges = []
+    if rng.random() < 0.5:
+        k = int(rng.integers(5, max(6, size // 2)))
+        cols = T.make_independent_elim_set(cols, 0, k)
+        if rng.random() < 0.5:
+            ranges = [0, k]
+    ss = T.columns_to_structure(cols)
+    st = B.Settings(findSparseEliminationRanges=bool(rng.random() < 0.7))
+    dtype = np.float64 if rng.random() < 0.6 else np.float32
+    tol = 1e-8 if dtype == np.float64 else 3e-4
+    desc = dict(seed=seed, size=size, fill=fill, pmax=pmax, ranges=ranges, dtype=dtype.__name__)
+    sol = B.create_solver(st, sizes, ss, ranges)
+    n = sol.order()
+    nb = int(rng.choice([1, 1, 2, 5]))
+    datas = [spd_data(sol, 7 * seed + q, dtype=dtype) for q in range(nb)]
+    devs = [to_dev(d) for d in datas]
+    sol.factor(devs if nb > 1 else devs[0])
+    for q in range(nb):
+        L, A = dense_lower_chol(sol, datas[q])
+        got = lower_of(sol, devs[q].cpu().numpy())
+        err = np.linalg.norm(got - L) / np.linalg.norm(L)
+        assert err < tol, ("factor", q, err, desc)
+    nrhs = int(rng.choice([1, 3]))
+    rhs = rng.standard_normal(n * nrhs).astype(dtype)
+    v = to_dev(rhs)
+    sol.solve(devs[0], v, n, nrhs)
+    L, A = dense_lower_chol(sol, datas[0])
+    X = np.linalg.solve(A, rhs.astype(np.float64).reshape(nrhs, n).T)
+    got = v.cpu().numpy().astype(np.float64).reshape(nrhs, n).T
+    err = np.linalg.norm(got - X) / np.linalg.norm(X)
+    assert err < tol * 50, ("solve", err, desc)
+    # addMvFrom on the un-factored matrix
+    a_dev = to_dev(datas[0])
+    xin = rng.standard_normal(n).astype(dtype)
+    yout = to_dev(np.zeros(n, dtype=dtype))
+    sol.addMvFrom(a_dev, 0, to_dev(xin), n, yout, n, 1, 1.0)
+    ref = A @ xin.astype(np.float64)
+    err = np.linalg.norm(yout.cpu().numpy().astype(np.float64) - ref) / np.linalg.norm(ref)
+    assert err < tol * 10, ("addMv", err, desc)
+    return desc
