@@ -20,6 +20,21 @@ def build(force=False):
     return LIB_PATH
 
 
+def kernel_source_sha16():
+    """sha256 (16 hex digits) over the native sources of the library, in a fixed order: what
+    bench.py compares with the hash recorded next to committed rocprofv3 PMC numbers, so that
+    counters of an older build are never reported beside a newer build's timings"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def load():
     """Load the library.  There is no fallback: without the HIP library the product is unusable."""
     global _lib

@@ -1,10 +1,16 @@
 // Block accessors: how callers locate a block of the factor inside the flat numeric buffer.
 // Plain structs of raw pointers (POD, no constructor) so they can be passed by value to a HIP
-// kernel.  Same names/semantics as baspacho/baspacho/Accessor.h:18-200; the Eigen `block()`
-// helpers are replaced by raw (pointer, stride) views since Eigen is not a dependency here.
+// kernel.  Same names/semantics as baspacho/baspacho/Accessor.h:18-200.  Eigen is not a dependency
+// here: `block()` / `diagBlock()` (Accessor.h:69-107,165-200) return a BlockView -- a strided
+// (rows, cols, rowStride, colStride) view with operator()(i, j), setZero(), +=, -= and transpose(),
+// the subset of Eigen::Map the reference's callers use (BaAtLargeOptimizer.cpp:119-129) -- with the
+// same template arguments (compile-time sizes are checked against the parameter sizes) and the
+// same flip handling for permuted accessors (a flipped block is a view with swapped strides).
 #pragma once
 
 #include <cstdint>
+#include <stdexcept>
+#include <string>
 #include <tuple>
 #include <utility>
 
@@ -16,6 +22,53 @@
 #endif
 
 namespace BaSpaCho {
+
+constexpr int Dynamic = -1;  // Eigen::Dynamic's role in block<rowSize, colSize>()
+
+// compile-time block sizes must match the parameter sizes (BASPACHO_CHECK_EQ in Accessor.h:76-81):
+// an exception on the host, a trap inside a kernel
+BASPACHO_HOST_DEVICE inline void checkBlockSize(int64_t wanted, int64_t actual) {
+  if (wanted != Dynamic && wanted != actual) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_trap();
+#else
+    throw std::runtime_error("accessor: compile-time block size " + std::to_string(wanted) +
+                             " != parameter size " + std::to_string(actual));
+#endif
+  }
+}
+
+// Strided view of a block of the numeric data (what the reference returns as
+// Eigen::Map<Matrix<T, r, c, RowMajor>, 0, Stride<Dynamic, Dynamic>>, Accessor.h:69-107,165-200)
+template <typename T>
+struct BlockView {
+  T* ptr;
+  int64_t nRows, nCols, rowStride, colStride;
+  BASPACHO_HOST_DEVICE int64_t rows() const { return nRows; }
+  BASPACHO_HOST_DEVICE int64_t cols() const { return nCols; }
+  BASPACHO_HOST_DEVICE T& operator()(int64_t i, int64_t j) const { return ptr[i * rowStride + j * colStride]; }
+  BASPACHO_HOST_DEVICE BlockView transpose() const { return {ptr, nCols, nRows, colStride, rowStride}; }
+  BASPACHO_HOST_DEVICE void setZero() const {
+    for (int64_t i = 0; i < nRows; i++) {
+      for (int64_t j = 0; j < nCols; j++) (*this)(i, j) = T(0);
+    }
+  }
+  // element-wise accumulate from anything indexable as src(i, j) (another view, a lambda, ...)
+  template <typename Src>
+  BASPACHO_HOST_DEVICE const BlockView& operator+=(const Src& src) const {
+    for (int64_t i = 0; i < nRows; i++) {
+      for (int64_t j = 0; j < nCols; j++) (*this)(i, j) += src(i, j);
+    }
+    return *this;
+  }
+  template <typename Src>
+  BASPACHO_HOST_DEVICE const BlockView& operator-=(const Src& src) const {
+    for (int64_t i = 0; i < nRows; i++) {
+      for (int64_t j = 0; j < nCols; j++) (*this)(i, j) -= src(i, j);
+    }
+    return *this;
+  }
+};
 
 struct CoalescedAccessor {
   void init(const int64_t* spanStart_, const int64_t* spanToLump_, const int64_t* lumpStart_,
@@ -80,6 +133,25 @@ struct CoalescedAccessor {
             lumpSize};
   }
 
+  // block reference, from the numeric data pointer (Accessor.h:69-87); row >= col
+  template <int rowSize = Dynamic, int colSize = Dynamic, typename T>
+  BASPACHO_HOST_DEVICE BlockView<T> block(T* data, int64_t rowBlockIndex, int64_t colBlockIndex) const {
+    checkBlockSize(rowSize, paramSize(rowBlockIndex));
+    checkBlockSize(colSize, paramSize(colBlockIndex));
+    auto os = blockOffset(rowBlockIndex, colBlockIndex);
+    return {data + os.first, rowSize != Dynamic ? rowSize : paramSize(rowBlockIndex),
+            colSize != Dynamic ? colSize : paramSize(colBlockIndex), os.second, 1};
+  }
+
+  // diagonal block reference (Accessor.h:89-101)
+  template <int size = Dynamic, typename T>
+  BASPACHO_HOST_DEVICE BlockView<T> diagBlock(T* data, int64_t blockIndex) const {
+    checkBlockSize(size, paramSize(blockIndex));
+    auto os = diagBlockOffset(blockIndex);
+    const int64_t n = size != Dynamic ? size : paramSize(blockIndex);
+    return {data + os.first, n, n, os.second, 1};
+  }
+
   const int64_t* spanStart;
   const int64_t* spanToLump;
   const int64_t* lumpStart;
@@ -122,6 +194,28 @@ struct PermutedCoalescedAccessor {
 
   BASPACHO_HOST_DEVICE std::pair<int64_t, int64_t> diagBlockOffset(int64_t blockIndex) const {
     return plainAcc.diagBlockOffset(permutation[blockIndex]);
+  }
+
+  // block reference through the permutation (Accessor.h:165-185): a flipped block (stored as the
+  // transpose) comes back as a view with swapped strides, so view(i, j) is always entry (i, j) of
+  // block (rowBlockIndex, colBlockIndex)
+  template <int rowSize = Dynamic, int colSize = Dynamic, typename T>
+  BASPACHO_HOST_DEVICE BlockView<T> block(T* data, int64_t rowBlockIndex, int64_t colBlockIndex) const {
+    checkBlockSize(rowSize, paramSize(rowBlockIndex));
+    checkBlockSize(colSize, paramSize(colBlockIndex));
+    auto osf = blockOffset(rowBlockIndex, colBlockIndex);
+    const bool flip = std::get<2>(osf);
+    return {data + std::get<0>(osf), rowSize != Dynamic ? rowSize : paramSize(rowBlockIndex),
+            colSize != Dynamic ? colSize : paramSize(colBlockIndex), flip ? 1 : std::get<1>(osf),
+            flip ? std::get<1>(osf) : 1};
+  }
+
+  template <int size = Dynamic, typename T>
+  BASPACHO_HOST_DEVICE BlockView<T> diagBlock(T* data, int64_t blockIndex) const {
+    checkBlockSize(size, paramSize(blockIndex));
+    auto os = diagBlockOffset(blockIndex);
+    const int64_t n = size != Dynamic ? size : paramSize(blockIndex);
+    return {data + os.first, n, n, os.second, 1};
   }
 
   CoalescedAccessor plainAcc;

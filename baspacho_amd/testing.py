@@ -160,6 +160,91 @@ def gen_grid(width, height, fill=1.0, conn=2, seed=37):
     return structure_from_pairs(n, np.concatenate(rows), np.concatenate(cols))
 
 
+def connect_ranges_pairs(size, begin1, end1, begin2, end2, fill, max_offset, seed):
+    """SparseMatGenerator::connectRanges (TestingMatGen.cpp:23-50) as a list of (row j, col i) pairs,
+    i < j: for i in [begin1, end1), j = i + d with min(maxOffset, max(begin2 - i, 1)) <= d <
+    min(maxOffset, end2 - i), each kept with probability `fill`; begin1 > begin2 swaps the ranges,
+    end1 > end2 adds connectRanges(begin2, end2, end2, end1).  NOTE the reference's semantics: the
+    offset limit applies to j - i whatever the ranges are, so two ranges further apart than
+    maxOffset get NO connection.  Decisions come from the stateless hash of (i, j)."""
+    if begin1 > begin2:
+        return connect_ranges_pairs(size, begin2, end2, begin1, end1, fill, max_offset, seed)
+    rows, cols = [], []
+    if end1 > end2:
+        r, c = connect_ranges_pairs(size, begin2, end2, end2, end1, fill, max_offset, seed)
+        rows.append(r)
+        cols.append(c)
+    i = np.arange(begin1, end1, dtype=np.int64)
+    d_begin = np.minimum(max_offset, np.maximum(begin2 - i, 1))
+    d_end = np.minimum(max_offset, end2 - i)
+    for d in range(1, int(max_offset)):
+        ii = i[(d >= d_begin) & (d < d_end)]
+        if len(ii) == 0:
+            continue
+        jj = ii + d
+        if fill < 1.0:
+            keep = hash_unit(seed, ii.astype(np.uint64) * np.uint64(size) + jj.astype(np.uint64)) < fill
+            ii, jj = ii[keep], jj[keep]
+        rows.append(jj)
+        cols.append(ii)
+    if not rows:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    return np.concatenate(rows), np.concatenate(cols)
+
+
+def gen_meridians(num, line_len, fill, band, hair_len, n_pole_hairs, s_pole_hairs, seed=37):
+    """SparseMatGenerator::genMeridians (TestingMatGen.cpp:87-168), call for call: `num` tracks of
+    `line_len` parameters and n + s "hair" tracks of `hair_len`, each a band of width `band`
+    (neighbours connected with probability `fill`), then the pole connections (meridian-meridian,
+    meridian-hair, hair-hair), every one through connectRanges with maxOffset = band.  Because that
+    limit is on the INDEX distance (see connect_ranges_pairs), pole connections between tracks whose
+    index ranges are further apart than `band` are empty in the reference, and so they are here; the
+    south-pole hair-hair loop's `kBegin` is computed from h, not k, in the reference (a track with
+    itself): restated as written."""
+    tot_hairs = n_pole_hairs + s_pole_hairs
+    size = line_len * num + hair_len * tot_hairs
+    end_meridians = line_len * num
+    assert band <= line_len and band <= hair_len
+    acc = []
+
+    def conn(b1, e1, b2, e2):
+        acc.append(connect_ranges_pairs(size, b1, e1, b2, e2, fill, band, seed))
+
+    for i in range(num):
+        b = line_len * i
+        conn(b, b + line_len, b, b + line_len)
+    for h in range(tot_hairs):
+        b = end_meridians + hair_len * h
+        conn(b, b + hair_len, b, b + hair_len)
+    for i in range(num):
+        ib = line_len * i
+        for j in range(i):
+            jb = line_len * j
+            conn(ib, ib + band, jb, jb + band)
+            conn(ib + line_len - band, ib + line_len, jb + line_len - band, jb + line_len)
+    for i in range(num):
+        ib = line_len * i
+        for h in range(n_pole_hairs):
+            hb = end_meridians + hair_len * h
+            conn(ib, ib + band, hb, hb + band)
+        for h in range(s_pole_hairs):
+            hb = end_meridians + hair_len * (h + n_pole_hairs)
+            conn(ib + line_len - band, ib + line_len, hb, hb + band)
+    for h in range(n_pole_hairs):
+        hb = end_meridians + hair_len * h
+        for k in range(h):
+            kb = end_meridians + hair_len * k
+            conn(kb, kb + band, hb, hb + band)
+    for h in range(s_pole_hairs):
+        hb = end_meridians + hair_len * (h + n_pole_hairs)
+        for k in range(h):
+            kb = end_meridians + hair_len * (h + n_pole_hairs)   # (sic: h, TestingMatGen.cpp:160)
+            conn(kb, kb + band, hb, hb + band)
+    rows = np.concatenate([a[0] for a in acc])
+    cols = np.concatenate([a[1] for a in acc])
+    return structure_from_pairs(size, rows, cols)
+
+
 def block_tridiagonal(n):
     """column i holds blocks {i, i+1}"""
     i = np.arange(n - 1, dtype=np.int64)

@@ -37,6 +37,9 @@ try:
 except (OSError, ValueError):
     doc = {}
 doc["_source"] = label
+sys.path.insert(0, os.path.dirname(here))
+from baspacho_amd import _lib  # noqa: E402
+doc["_kernel_source_sha16"] = _lib.kernel_source_sha16()   # bench.py ignores the file when this is stale
 doc["_note"] = ("KB per factor() call as rocprofv3 reports them; bench.py doubles FETCH_SIZE (gfx950 "
                 "tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM); WRITE_SIZE is "
                 "uncalibrated; Infinity-Cache hits are included")

@@ -103,6 +103,9 @@ try:
 except (OSError, ValueError):
     doc = {}
 doc[bench["config"]["workload"]] = out
+sys.path.insert(0, os.path.dirname(here))
+from baspacho_amd import _lib  # noqa: E402
+doc["_kernel_source_sha16"] = _lib.kernel_source_sha16()   # bench.py ignores the file when this is stale
 doc["_how"] = ("frac = algorithmic work of the class (bench.py kernel_rates) / (calls x avg_ns of its kernels in the "
                "headline-only table of the stats file) / peak (78.6 TFLOP/s fp64 MFMA, 8000 GB/s HBM); frac_busy = the same "
                "over the time during which at least one launch of the class is running (its launches overlap when "

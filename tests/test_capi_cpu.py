@@ -184,3 +184,71 @@ def test_chain_contraction_gives_ranges_and_a_valid_factor(closures):
     assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) < 1e-12
     p = ss.fillReducingPermutation()
     assert sorted(np.asarray(p).tolist()) == list(range(n))
+
+
+def _connect_ranges_literal(columns, b1, e1, b2, e2, fill, max_offset, seed):
+    """the reference's connectRanges loop, statement for statement (TestingMatGen.cpp:23-50), on a
+    list of sets; the keep/drop decision is the generator's stateless hash of (i, j)"""
+    size = len(columns)
+    if b1 > b2:
+        return _connect_ranges_literal(columns, b2, e2, b1, e1, fill, max_offset, seed)
+    if e1 > e2:
+        _connect_ranges_literal(columns, b2, e2, e2, e1, fill, max_offset, seed)
+    for i in range(b1, e1):
+        d_begin = min(max_offset, max(b2 - i, 1))
+        d_end = min(max_offset, e2 - i)
+        for j in range(i + d_begin, i + d_end):
+            u = T.hash_unit(seed, np.uint64(i) * np.uint64(size) + np.array([j], dtype=np.uint64))[0]
+            if fill >= 1.0 or fill > u:
+                columns[i].add(j)
+
+
+def test_gen_meridians_is_the_reference_construction():
+    """genMeridians (TestingMatGen.cpp:87-168) restated with numpy == the literal loops on a small
+    instance; bands never exceed `band`; the size formula holds"""
+    num, line_len, fill, band, hair_len, nh, sh, seed = 3, 40, 0.5, 7, 15, 2, 1, 5
+    ss = T.gen_meridians(num, line_len, fill, band, hair_len, nh, sh, seed)
+    size = line_len * num + hair_len * (nh + sh)
+    assert ss.order() == size
+    cols = [{i} for i in range(size)]
+    end_m = line_len * num
+
+    def conn(b1, e1, b2, e2):
+        _connect_ranges_literal(cols, b1, e1, b2, e2, fill, band, seed)
+
+    for i in range(num):
+        conn(line_len * i, line_len * (i + 1), line_len * i, line_len * (i + 1))
+    for h in range(nh + sh):
+        b = end_m + hair_len * h
+        conn(b, b + hair_len, b, b + hair_len)
+    for i in range(num):
+        ib = line_len * i
+        for j in range(i):
+            jb = line_len * j
+            conn(ib, ib + band, jb, jb + band)
+            conn(ib + line_len - band, ib + line_len, jb + line_len - band, jb + line_len)
+    for i in range(num):
+        ib = line_len * i
+        for h in range(nh):
+            hb = end_m + hair_len * h
+            conn(ib, ib + band, hb, hb + band)
+        for h in range(sh):
+            hb = end_m + hair_len * (h + nh)
+            conn(ib + line_len - band, ib + line_len, hb, hb + band)
+    for h in range(nh):
+        hb = end_m + hair_len * h
+        for k in range(h):
+            kb = end_m + hair_len * k
+            conn(kb, kb + band, hb, hb + band)
+    for h in range(sh):
+        hb = end_m + hair_len * (h + nh)
+        for k in range(h):
+            conn(hb, hb + band, hb, hb + band)
+    want = T.columns_to_structure(cols)
+    assert np.array_equal(ss.ptrs, want.ptrs) and np.array_equal(ss.inds, want.inds)
+    rows = np.repeat(np.arange(size), np.diff(ss.ptrs))
+    assert (rows - ss.inds).max() < band
+    # a genuinely connected case: adjacent tracks closer than the band DO get pole connections
+    ss2 = T.gen_meridians(2, 8, 1.0, 8, 8, 1, 0, 1)
+    rows2 = np.repeat(np.arange(ss2.order()), np.diff(ss2.ptrs))
+    assert ((rows2 >= 8) & (ss2.inds < 8)).any()
