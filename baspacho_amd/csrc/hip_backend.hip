@@ -351,6 +351,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     // the plan builder's switches: read here, once per Solver, handed to every buildHipPlan call
     // and recorded in the plan; launchLevels takes dueStream / dueSplit from the plan it runs
     planOpts = HipPlanOptions::fromEnv();
+    nowSplit = planOpts.nowSplit;
     if (const char* e = std::getenv("BSP_LOOKAHEAD_MIN_GF")) lookaheadMinFlops = 1e9 * std::atof(e);
     if (const char* e = std::getenv("BSP_GRAPH")) graphMode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
   }
@@ -486,6 +487,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
   int graphMode = 0;           // factor() as a captured hipGraph (BSP_GRAPH): 0 never (default: measured no faster, see factorViaGraph), 1 always, 2 launch-bound plans only
   bool earlyDiag = true;       // intra-block chain steps pre-apply their panel to the next block's tile (0,0) (BSP_EARLY_DIAG=0 disables)
+  bool nowSplit = false;       // opt-in BSP_NOW_SPLIT=1: block-last steps leave column tiles 2-3 of their now-update to the next two steps
   bool bulkYield = true;       // bulk tiles pause on the CU of the chain's potrf workgroup (BSP_BULK_YIELD=0 disables)
   bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
   bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
@@ -577,6 +579,26 @@ struct HipNumericCtx : NumericCtx<T> {
     vector<hipEvent_t> defDone(levels.size(), nullptr);  // due units of a level complete
     vector<hipEvent_t> optDone(levels.size(), nullptr);  // ... its optional units (due-stream mode)
     vector<hipEvent_t> due0Done(levels.size(), nullptr); // ... the first column tile of its due units
+    // NOW SPLIT (LevelRange::nowHeadTiles): a block-last step left the finished block's rank-256
+    // update of the next block's column tiles 2 and 3 to that block's first two steps
+    struct Carry {
+      int64_t level = -1;    // the block-last level that split (its soon task lists are the fallback)
+      int64_t srcOff = 0;    // SrcDesc::off of the finished block (row 0 = first row of the next block)
+      int32_t lda = 0, K = 0, lump = -1;
+      int step = 0;          // steps of the next block that took their column tile so far (0..2)
+    } carry;
+    // fallback: a carried column tile that no merged chain step can take goes as plain bulk tiles
+    auto flushCarry = [&]() {
+      if (carry.level < 0) return;
+      const LevelRange& bl = levels[carry.level];
+      const int64_t b = carry.step == 0 ? bl.soonBegin : bl.soonMid;
+      if (carry.step < 2 && bl.soonEnd > b) {
+        timer.begin(kProfUpdate);
+        launchUpdate(plan, b, bl.soonEnd, ref, sym.stream);
+        timer.end();
+      }
+      carry.level = -1;
+    };
     // (fp32: its atomics cost more than the second stream returns -- BAL-871 5.86 against 5.22 ms,
     //  BAL-1723 20.5 against 18.8 -- so single-precision calls keep the one-side-stream order, and
     //  the tasks' "two streams may meet" bit is masked off)
@@ -698,6 +720,30 @@ struct HipNumericCtx : NumericCtx<T> {
       // DUE SPLIT: a merged block-last step waits for the first column tile of the due units only
       const bool nowAtomic = merged && kMem > 0 && lookahead && dueStream && lr.waitDefLevel >= 0 &&
                              due0Done[lr.waitDefLevel] != nullptr;
+      // NOW SPLIT: does this step take the carried column tile?  (merged intra-block step of the
+      // same lump whose segment holds at least the column tile in question and one before it)
+      int memColBegin = 0, memColEnd = INT32_MAX;
+      if (carry.level >= 0) {
+        bool take = false;
+        if (merged && kMem == 0 && lr.directSeg >= 0) {
+          const SegDesc& sd = plan.host.segs[lr.directSeg];
+          const PanelDesc& pdc = plan.host.panels[lr.directPanel];
+          take = pdc.lump == carry.lump && pdc.lda == carry.lda && !sd.outer && sd.kind == kSegIntra &&
+                 sd.q0 == 0 && sd.m >= 2 * kTile && pdc.nb == kPanelWidth;
+        }
+        if (take) {
+          // rows of the finished block's source are indexed from the next block's first row; this
+          // panel's rows below start 64 (step 0) or 128 (step 1) rows further down
+          memOff = carry.srcOff + (int64_t)kTile * (carry.step + 1) * carry.lda;
+          kMem = carry.K;
+          memColBegin = kTile;
+          memColEnd = 2 * kTile;
+          if (++carry.step == 2) carry.level = -1;
+        } else {
+          flushCarry();
+        }
+      }
+      const bool carried = memColEnd != INT32_MAX;
       if (!waitedDef && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
         waitDeferred(lr.waitDefLevel, nowAtomic);
       }
@@ -789,10 +835,26 @@ struct HipNumericCtx : NumericCtx<T> {
       const int64_t updBegin = lr.updBegin;
       if (lr.updEnd > updBegin) {
         timer.begin(direct && lr.directSeg >= 0 ? kProfChainUpdate : kProfUpdate);
-        const unsigned nUpd = (unsigned)(lr.updEnd - updBegin);
+        unsigned nUpd = (unsigned)(lr.updEnd - updBegin);
+        // NOW SPLIT: only the first two column tiles of the block-wide update stay in this launch
+        const bool split = merged && kMem > 0 && !carried && fuse && sym.nowSplit &&
+                           lr.soonEnd > lr.soonBegin && lr.nowHeadTiles > 0 &&
+                           (unsigned)lr.nowHeadTiles < nUpd && li + 2 < levels.size();
+        if (split) {
+          const SegDesc& sd = plan.host.segs[lr.directSeg];
+          const SrcDesc& sr = plan.host.srcs[sd.src];
+          nUpd = (unsigned)lr.nowHeadTiles;
+          carry.level = (int64_t)li;
+          carry.srcOff = sr.off;
+          carry.lda = sr.lda;
+          carry.K = sr.K;
+          carry.lump = plan.host.panels[lr.directPanel].lump;
+          carry.step = 0;
+        }
         if (merged) {
           int kMem0 = kMem, extra = 0;
-          if (kMem == 0) {  // intra-block step
+          if (kMem == 0 || carried) {  // intra-block step
+            kMem0 = 0;
             if (earlyDiag && lr.extraDiag && !extraBroken && fuse) {
               extra = 1;
               extraApplied++;
@@ -808,7 +870,7 @@ struct HipNumericCtx : NumericCtx<T> {
               plan.host.panels[lr.directPanel], plan.host.segs[lr.directSeg], (int)nUpd, nextPanel,
               fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
               memOff, kMem, (lookahead && batchSize == 1 && sym.bulkYield) ? sym.yieldWord() : nullptr,
-              sym.traceLaunchId++, kMem0, extra, nowAtomic ? 1 : 0);
+              sym.traceLaunchId++, kMem0, extra, nowAtomic ? 1 : 0, memColBegin, memColEnd);
           potrfFused = fuse;
         } else if (fuse) {
           if (extraApplied > 0) {
@@ -851,6 +913,7 @@ struct HipNumericCtx : NumericCtx<T> {
         }
       }
     }
+    flushCarry();  // (a split is only planned with two more steps to come: nothing left here)
     if (sideUsed) {  // join: everything on the side stream(s) happens-before what follows
       hipEvent_t join = sym.eventFromPool();
       hipCHECK(hipEventRecord(join, sym.sideStream()));

@@ -2096,7 +2096,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     PanelDesc pd, SegDesc sd, int nTasks, PanelDesc next, int fuse, DataRef<T> dref,
     const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase,
     int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag,
-    int nowAtomic) {
+    int nowAtomic, int memColBegin, int memColEnd) {
+  // memColBegin / memColEnd (NOW SPLIT, LevelRange::nowHeadTiles): only the tiles of column tiles
+  // [memColBegin, memColEnd) (below-row indices) take the kMem source columns at memOff -- the
+  // block-last step passes [0, INT_MAX); the first two steps of the next block pass the ONE column
+  // tile that still owes the previous block's rank-256 update, with memOff pointing at that block's
+  // solved rows (shifted to this panel's row origin)
   // nowAtomic (block-last step, DUE SPLIT): the tiles right of the segment's first column tile are
   // subtracted with atomics -- the due units of those columns may still be running on the side
   // kMem0 <= kMem: source columns workgroup 0 still has to apply from memory to tile (0,0), the
@@ -2172,7 +2177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int colEnd = extra ? segEnd + kTile : segEnd;  // columns this tile may write
   const int ri = rowTile + 16 * w + n, rj = colTile + 16 * w + n;
   Acc D[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-  if (kMem > 0) {
+  if (kMem > 0 && !extra && colTile >= memColBegin && colTile < memColEnd) {
     ChainTile<T>::multiplyMem(data + memOff, lda, kMem, rowTile, colTile, rowsBelow, segEnd,
                               rowTile == colTile, XB, D);
   }

@@ -530,6 +530,7 @@ HipPlanOptions HipPlanOptions::fromEnv() {
   o.elimOverlap = optIn("BSP_ELIM_OVERLAP");
   o.planTiming = std::getenv("BSP_TIMING") != nullptr;
   o.dropElimUpdate = optIn("BSP_FAULT_DROP_ELIM_UPDATE");
+  o.nowSplit = optIn("BSP_NOW_SPLIT");
   if (const char* e = std::getenv("BSP_GATHER_MAX_PAIRS")) o.gatherMaxPairs = std::max(8, atoi(e));
   if (const char* e = std::getenv("BSP_BULK_AHEAD")) o.bulkAhead = std::atof(e);
   return o;
@@ -1037,6 +1038,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       lr.defMid = (int64_t)plan.updTasks.size();
       plan.updTasks.insert(plan.updTasks.end(), deferredLate.begin(), deferredLate.end());
       lr.defEnd = (int64_t)plan.updTasks.size();
+      lr.soonBegin = lr.soonMid = lr.soonEnd = lr.defEnd;
       // XCD-aware order: workgroup b lands on XCD b % 8 (observed dispatch; each XCD has its own
       // L2), so hand every XCD a CONTIGUOUS run of the tile list (neighbouring tiles share
       // operand rows) instead of every 8th tile.  Pure permutation: speed only.
@@ -1118,6 +1120,30 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             const int32_t nbLast = plan.panels[bucket[0].panel].nb;
             if (sd.outer && sr.K > nbLast) lr.splitK = sr.K - nbLast;
           }
+        }
+      }
+      // NOW SPLIT (LevelRange::nowHeadTiles): block-last step of a chain with a full next block
+      // (four column tiles) and at least that block's first two steps in this chain
+      if (opts.nowSplit && chain && lr.directSeg >= 0 && lr.fuseNext &&
+          bi + 2 < buckets.size() && buckets[bi + 2].size() == 1 &&
+          plan.panels[buckets[bi + 2][0].panel].lump == plan.panels[bucket[0].panel].lump) {
+        const SegDesc& sd = plan.segs[lr.directSeg];
+        const SrcDesc& sr = plan.srcs[sd.src];
+        const PanelDesc& pd = plan.panels[bucket[0].panel];
+        if (sd.outer == 1 && sd.kind == kSegIntra && sd.m == kOuterWidth && sr.K == kOuterWidth &&
+            sd.rowMin == 0 && pd.nb == kPanelWidth && sr.rowsBelow - sd.q0 >= 2 * kOuterWidth) {
+          int32_t head = 0;
+          for (int32_t cT = sd.q0; cT < sd.q0 + 2 * kTile; cT += kTile) {
+            head += (sr.rowsBelow - cT + kTile - 1) / kTile;
+          }
+          lr.nowHeadTiles = head;
+          for (int32_t cT = sd.q0 + 2 * kTile; cT < sd.q0 + sd.m; cT += kTile) {
+            if (cT == sd.q0 + 3 * kTile) lr.soonMid = (int64_t)plan.updTasks.size();
+            for (int32_t rT = cT; rT < sr.rowsBelow; rT += kTile) {
+              plan.updTasks.push_back(UpdTask{lr.directSeg, rT, cT, 1});
+            }
+          }
+          lr.soonEnd = (int64_t)plan.updTasks.size();
         }
       }
       xcdOrder(lr.updBegin, lr.updEnd);

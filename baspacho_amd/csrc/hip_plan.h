@@ -139,6 +139,27 @@ struct LevelRange {
   // due-stream mode: level whose OPTIONAL lookahead units (forked two outer blocks earlier: plain
   // read-modify-write on far columns) must be complete before this level's due units start; -1
   int64_t optWaitLevel = -1;
+  // NOW SPLIT (HipPlanOptions::nowSplit).  The block-last step of a chain applies the finished
+  // outer block (rank 256) to the NEXT block's 256 columns: ~390 tiles, two rounds of the one
+  // workgroup slot per CU the bulk tiles leave free, 46-84 us where an ordinary step takes 26 -- and
+  // the chain's next launch waits for all of them although it needs the first two column tiles only
+  // (it solves panel 0 and factors panel 1 of that block).  With the split the block-last step
+  // launches its first nowHeadTiles tasks (column tiles 0-1, column-tile-major as the direct kernels
+  // decode them) and the finished block's contribution to column tile 2 / 3 rides in the tiles of
+  // the next block's first / second step, which visit those columns anyway (chainStep: source
+  // columns from memory for one column tile, memCol): every launch of the chain is then about one
+  // round of its slot.  MEASURED (BAL-871, profiles/r3_ab_nowsplit.sh, tools/trace_extents.py): the
+  // block-last launch drops from 64-80 us to 28-41, but the two steps that inherit a column tile
+  // go from 34 / 45 us to 55 / 60 -- a tile with 256 source columns from memory takes ~50 us beside
+  // a saturated bulk stream whatever launch it is in -- and factor() stays at 6.87-6.91 ms against
+  // 6.85-6.88: opt-in, tested (test_schedule_variants).  A first variant that ran column tiles 2-3
+  // as bulk tiles on the due stream (event wait two steps later) was SLOWER, 7.56 ms: those tiles
+  // queue for slots behind the optional units like every due launch does.
+  // [soonBegin, soonMid) / [soonMid, soonEnd): the same tiles as self-contained
+  // bulk tasks (column tile 2 / 3), launched on the execution stream only if a following step turns
+  // out not to be a merged chain step (fallback, never the fast path).
+  int64_t soonBegin = 0, soonMid = 0, soonEnd = 0;
+  int32_t nowHeadTiles = 0;
 };
 
 // One work item of the gather-form sparse-elimination update: a target block (sj,si) of the
@@ -262,6 +283,9 @@ struct HipPlanOptions {
   bool dropElimUpdate = false; // BSP_FAULT_DROP_ELIM_UPDATE=1: FAULT INJECTION for the parity tests
                                // -- the sparse-elimination update is planned with zero pairs, so
                                // the factor is wrong; never set outside tests
+  bool nowSplit = false;      // BSP_NOW_SPLIT=1 (opt-in; measured: no gain, below): a chain's block-wide "now" update keeps only the next
+                              // block's first two column tiles, the other two are applied by the
+                              // next block's first two steps (LevelRange::nowHeadTiles)
   int32_t gatherMaxPairs = 128;  // BSP_GATHER_MAX_PAIRS
   double bulkAhead = 0.6;     // BSP_BULK_AHEAD
   static HipPlanOptions fromEnv();

@@ -297,7 +297,8 @@ def test_lump_widths_around_panel_and_block_boundaries(dtype):
                                   "BSP_SPLIT_DIAG=0", "BSP_ELIM_FACTOR_DESC=0",
                                   "BSP_MERGED_CHAIN=0", "BSP_BULK_KERNEL=0", "BSP_EARLY_FORK=0",
                                   "BSP_MERGED_BLOCK_LAST=0", "BSP_EARLY_DIAG=0", "BSP_BULK_YIELD=0",
-                                  "BSP_BULK_ROW_MAJOR=0", "BSP_DUE_STREAM=0", "BSP_EARLY_DUE=1", "BSP_DUE_SPLIT=1"])
+                                  "BSP_BULK_ROW_MAJOR=0", "BSP_DUE_STREAM=0", "BSP_EARLY_DUE=1", "BSP_DUE_SPLIT=1",
+                                  "BSP_NOW_SPLIT=1"])
 def test_schedule_variants(monkeypatch, knob):
     """every optimisation of the launch schedule can be switched off (the environment is read
     when the solver is created); each fallback must still factor correctly"""
@@ -349,6 +350,26 @@ def test_overlapped_elimination(monkeypatch, overlap, dtype):
     for q in range(3):
         got = devs[q].cpu().numpy().astype(np.float64)
         assert np.linalg.norm((got - refs[q])[mask]) / np.linalg.norm(refs[q][mask]) < tol, q
+
+
+@pytest.mark.parametrize("lookahead", ["on", "off"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_now_split_carries_column_tiles(monkeypatch, lookahead, dtype):
+    """opt-in BSP_NOW_SPLIT=1 (LevelRange::nowHeadTiles): the block-last step of a chain applies the
+    finished outer block to the next block's first two column tiles only; column tiles 2 and 3
+    receive it inside the next block's first two steps (chainStep: source columns from memory for
+    ONE column tile).  A dense lump of seven outer blocks, with the side streams and in line."""
+    monkeypatch.setenv("BSP_NOW_SPLIT", "1")
+    if lookahead == "off":
+        monkeypatch.setenv("BSP_NO_LOOKAHEAD", "1")
+    n = 1700
+    ss = T.columns_to_structure([set(range(i, n)) for i in range(n)])
+    sol = B.create_solver(B.Settings(), np.ones(n, dtype=np.int64), ss)
+    data = spd_data(sol, 23, beta_factor=1.2, dtype=dtype)
+    _, A = dense_lower_chol(sol, data)
+    Lg = lower_of(sol, _gpu_factor(sol, data)).astype(np.float64)
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < tol
 
 
 @pytest.mark.parametrize("ahead", ["0", "0.6", "100"])
