@@ -340,6 +340,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_BLOCK_SOLVE")) blockSolve = e[0] != '0';
     if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
+    if (const char* e = std::getenv("BSP_ELIM_FACTOR_STAGED")) elimFactorStaged = e[0] != '0';
     if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
     if (const char* e = std::getenv("BSP_MERGED_CHAIN")) mergedChain = e[0] != '0';
     if (const char* e = std::getenv("BSP_EARLY_FORK")) earlyFork = e[0] != '0';
@@ -489,6 +490,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool earlyDiag = true;       // intra-block chain steps pre-apply their panel to the next block's tile (0,0) (BSP_EARLY_DIAG=0 disables)
   bool nowSplit = false;       // opt-in BSP_NOW_SPLIT=1: block-last steps leave column tiles 2-3 of their now-update to the next two steps
   bool bulkYield = true;       // bulk tiles pause on the CU of the chain's potrf workgroup (BSP_BULK_YIELD=0 disables)
+  bool elimFactorStaged = true; // ... staged through LDS with coalesced wave loads (BSP_ELIM_FACTOR_STAGED=0: direct loads, K1t)
   bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
   bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
@@ -949,7 +951,12 @@ struct HipNumericCtx : NumericCtx<T> {
       sym.elimPackBuf.resize((size_t)(packStride * batchSize) * sizeof(BT));
       packBuf = reinterpret_cast<BT*>(sym.elimPackBuf.ptr);
     }
-    if (er.maxWidth <= 4 && sym.elimFactorDesc) {
+    if (er.maxWidth <= 4 && sym.elimFactorDesc && sym.elimFactorStaged && !packed) {
+      const int64_t perWg = 4 * hipk::kTinyPerWave;
+      hipk::elimFactorTinyStaged<BT><<<dim3((unsigned)((nLumps + perWg - 1) / perWg), gy), 256, 0,
+                                      sym.stream>>>(
+          plan.elimLumpDesc.as<ElimLumpDesc>() + er.descBegin, ref, (int)nLumps);
+    } else if (er.maxWidth <= 4 && sym.elimFactorDesc) {
       const int64_t perWg = 4 * hipk::kTinyPerWave;
       hipk::elimFactorTiny<BT><<<dim3((unsigned)((nLumps + perWg - 1) / perWg), gy), 256, 0,
                                 sym.stream>>>(

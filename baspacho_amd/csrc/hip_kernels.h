@@ -305,6 +305,122 @@ __global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs,
   }
 }
 
+// K1s  K1t with the eliminated columns STAGED through LDS.  A wave's four lumps are neighbours in
+// memory (an elimination range is laid out lump after lump, each column one dense (n + rows) x n
+// block), so the wave reads its whole stretch -- typically ~600 values -- with fully coalesced
+// 512-byte wave loads, all issued back to back, factors and solves out of LDS (16 lanes per lump as
+// in K1t, the n x n Cholesky redundantly in registers) and writes the stretch back the same way.
+// K1t reads every 24-byte row with three 8-byte loads per lane and the diagonal block with six more
+// per lane: ~18 wave instructions of ~270 useful bytes each per four lumps, and it ran at 2.9 TB/s
+// (0.36 of the HBM roofline) on the 527 480 point columns of BAL-871.  A stretch that does not fit
+// the scratch (heavy-tail points seen by dozens of cameras) takes the direct path lump by lump.
+template <typename T>
+using LP = __attribute__((address_space(3))) T*;
+constexpr int kStagedCap = 1024;  // scratch values per wave (8 KB fp64; 32 KB per workgroup)
+
+// one lump of width n <= 4 by 16 lanes (sub = 0..15): Cholesky of the diagonal block at D, rows
+// below it (at D + n * n) solved against it; P: global or LDS pointer
+template <typename T, typename P>
+__device__ __forceinline__ void tinyLumpBody(P D, int n, int rowsBelow, int sub) {
+  constexpr int G = 16;
+  P B = D + n * n;
+  T a[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      const T v = D[min(i, n - 1) * n + min(j, n - 1)];
+      a[i][j] = (i < n && j < n) ? v : (i == j ? T(1) : T(0));
+    }
+  }
+  T inv[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    T d = a[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= a[j][k] * a[j][k];
+    inv[j] = fastRsqrt(d);
+    a[j][j] = d * inv[j];
+#pragma unroll
+    for (int i = j + 1; i < 4; i++) {
+      T s = a[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= a[i][k] * a[j][k];
+      a[i][j] = s * inv[j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      if (i < n && sub == i * n + j) D[i * n + j] = a[i][j];
+    }
+  }
+  for (int r = sub; r < rowsBelow; r += G) {
+    P row = B + r * n;
+    T y[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) y[j] = row[min(j, n - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      T s = y[j];
+#pragma unroll
+      for (int i = 0; i < j; i++) s -= y[i] * a[j][i];
+      y[j] = s * inv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (j < n) row[j] = y[j];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void elimFactorTinyStaged(const ElimLumpDesc* descs,
+                                                            DataRef<T> dref, int numLumps) {
+  __shared__ T scratch[4][kStagedCap];
+  constexpr int IT = kStagedCap / 64;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, sub = lane & 15, q = lane >> 4;
+  const int first = (blockIdx.x * 4 + wave) * kTinyPerWave;
+  if (first >= numLumps) return;
+  const int last = min(first + kTinyPerWave - 1, numLumps - 1);
+  const bool live = first + q <= last;
+  const ElimLumpDesc ld = descs[live ? first + q : last];
+  const ElimLumpDesc ld0 = descs[first], ldL = descs[last];  // (wave-uniform)
+  const int64_t start = ld0.diagOff;
+  const int64_t len = ldL.diagOff + (int64_t)ldL.n * (ldL.n + ldL.rowsBelow) - start;
+  GP<T> data = pickData(dref);
+  if (ld.n > 4) return;  // (the caller checks the range's maximum width)
+  // the lumps of a range follow one another in memory; anything else takes the direct path
+  if (len <= 0 || len > kStagedCap) {
+    if (live) tinyLumpBody<T>(data + ld.diagOff, ld.n, ld.rowsBelow, sub);
+    return;
+  }
+  const int E = (int)len;
+  GP<T> D0 = data + start;
+  LP<T> sc = (LP<T>)scratch[wave];
+  T v[IT];
+#pragma unroll
+  for (int it = 0; it < IT; it++) {
+    const int e = it * 64 + lane;
+    v[it] = e < E ? D0[e] : T(0);
+  }
+#pragma unroll
+  for (int it = 0; it < IT; it++) {
+    const int e = it * 64 + lane;
+    if (e < E) sc[e] = v[it];
+  }
+  waveSync();
+  if (live) tinyLumpBody<T>(sc + (int)(ld.diagOff - start), ld.n, ld.rowsBelow, sub);
+  waveSync();
+#pragma unroll
+  for (int it = 0; it < IT; it++) {
+    const int e = it * 64 + lane;
+    if (e < E) D0[e] = sc[e];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K2  sparse-elimination update: for column l and every pair of below-diagonal chains i<=j:
 //     target(sj,si) -= L(sj,l) * L(si,l)^T.
