@@ -83,11 +83,13 @@ def save_bal(path, prob):
             f.write("%.16e\n" % v)
 
 
-def bal_structure(prob):
+def bal_structure(prob, cam_size=9):
     """(paramSizes, SparseStructure, sparseElimRanges) as testSolvers builds them
-    (BaAtLargeBench.cpp:44-73): points first, then cameras; block (numPts + cam, pt) per observation"""
+    (BaAtLargeBench.cpp:44-73): points first, then cameras; block (numPts + cam, pt) per observation.
+    cam_size = 9: the camera blocks of BAL_bench (all parameters of a BAL file); cam_size = 6: the
+    blocks of the LM optimizer BAL_opt (SE3 tangent, BaAtLargeOptimizer.cpp:33-52)"""
     npt, nc = prob.num_pts, prob.num_cams
-    sizes = np.concatenate([np.full(npt, 3, dtype=np.int64), np.full(nc, 9, dtype=np.int64)])
+    sizes = np.concatenate([np.full(npt, 3, dtype=np.int64), np.full(nc, cam_size, dtype=np.int64)])
     key = np.unique(prob.obs_pt * nc + prob.obs_cam)   # duplicate observations share a block
     ss = structure_from_pairs(npt + nc, npt + key % nc, key // nc)
     return sizes, ss, [0, npt]
@@ -161,11 +163,134 @@ def synth_scene_for(num_cams, num_pts, obs_cam, obs_pt, seed=3, noise=0.5, pertu
     return BalProblem(cams, pts, oc, op, xy)
 
 
-class DevicePipeline:
-    """problem data resident on the GPU + the two device stages of a Gauss-Newton / LM iteration"""
+def _skew(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=np.float64)
 
-    def __init__(self, prob, solver, device="cuda"):
+
+def so3_exp(w):
+    th = float(np.linalg.norm(w))
+    K = _skew(w)
+    if th < 1e-10:
+        return np.eye(3) + K + 0.5 * K @ K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def so3_log(R):
+    c = min(1.0, max(-1.0, 0.5 * (np.trace(R) - 1.0)))
+    th = np.arccos(c)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    if th < 1e-10:
+        return 0.5 * v
+    if np.pi - th < 1e-6:   # near pi: axis from the symmetric part
+        A = 0.5 * (R + np.eye(3))
+        ax = np.sqrt(np.maximum(np.diag(A), 0.0))
+        k = int(np.argmax(ax))
+        ax = A[:, k] / ax[k]
+        return th * ax / np.linalg.norm(ax)
+    return th / (2.0 * np.sin(th)) * v
+
+
+def se3_exp(delta):
+    """Sophus::SE3d::exp for delta = (translation part, rotation part): (R, t)"""
+    u, w = np.asarray(delta[:3], dtype=np.float64), np.asarray(delta[3:], dtype=np.float64)
+    th = float(np.linalg.norm(w))
+    K = _skew(w)
+    if th < 1e-10:
+        V = np.eye(3) + 0.5 * K + K @ K / 6.0
+    else:
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+    return so3_exp(w), V @ u
+
+
+def apply_step_se3(prob, step, solver):
+    """applyStep of the reference's optimizer (BaAtLargeOptimizer.cpp:170-184): points -= step,
+    T_W_C <- exp(-step) T_W_C; `step` is in the solver's internal order (paramToSpan /
+    spanVectorOffset); cameras keep the BAL storage (Rodrigues rotation, translation).  Returns a
+    new BalProblem."""
+    out = BalProblem(prob.cams.copy(), prob.pts.copy(), prob.obs_cam, prob.obs_pt, prob.obs_xy)
+    perm = solver.paramToSpan()
+    ss = solver.skel()["spanStart"]
+    npt = prob.num_pts
+    pt_off = ss[perm[:npt]]
+    out.pts -= step[pt_off[:, None] + np.arange(3)[None, :]]
+    for i in range(prob.num_cams):
+        o = int(ss[perm[npt + i]])
+        Rd, td = se3_exp(-step[o:o + 6])
+        R = so3_exp(prob.cams[i, 0:3])
+        out.cams[i, 0:3] = so3_log(Rd @ R)
+        out.cams[i, 3:6] = Rd @ prob.cams[i, 3:6] + td
+    return out
+
+
+def total_cost(prob):
+    """computeCost (BaAtLargeOptimizer.cpp:54-63) with the reference's behind-the-camera rule"""
+    w, t = prob.cams[prob.obs_cam, 0:3], prob.cams[prob.obs_cam, 3:6]
+    X = prob.pts[prob.obs_pt]
+    th = np.linalg.norm(w, axis=1, keepdims=True)
+    k = w / np.maximum(th, 1e-300)
+    P = X * np.cos(th) + np.cross(k, X) * np.sin(th) + k * np.sum(k * X, axis=1, keepdims=True) * (1 - np.cos(th)) + t
+    bad = P[:, 2] > 0.01
+    err = project(prob.cams[prob.obs_cam], X) - prob.obs_xy
+    err[bad] = (25.0, 0.0)
+    return 0.5 * float(np.sum(err * err))
+
+
+def lm_optimize(prob, solver, max_iters=50, lam=1e-5, log=None):
+    """the Levenberg-Marquardt loop of BAL_opt (BaAtLargeOptimizer.cpp:186-234), every numeric stage
+    on the device: linearise (SE3 tangent) -> Hessian through deviceAccessor() -> factor -> solve ->
+    exp-map update; same lambda schedule, same acceptance and convergence rules.  `solver` must have
+    6-wide camera blocks (bal_structure(prob, cam_size=6)).  Returns (problem, cost history)."""
+    import torch
+    hist = []
+    last_failed = last_ok = last_good = 0
+    for i in range(max_iters):
+        pipe = DevicePipeline(prob, solver, param="se3")
+        pipe.linearize()
+        cost = 0.5 * float((pipe.res * pipe.res).sum())
+        H = torch.zeros(solver.dataSize(), dtype=torch.float64, device=pipe.res.device)
+        g = torch.zeros(solver.order(), dtype=torch.float64, device=pipe.res.device)
+        pipe.fill_hessian(H, g, lam)
+        step = g.clone()
+        solver.factor(H)
+        solver.solve(H, step, solver.order(), 1)
+        cand = apply_step_se3(prob, step.cpu().numpy(), solver)
+        model_red = 0.5 * float(torch.dot(g, step))
+        new_cost = total_cost(cand)
+        bad, good = new_cost > cost, new_cost < cost * 0.999
+        hist.append((cost, new_cost, lam))
+        if log:
+            log("[%d] cost %.3e -> %.3e lambda %.1e" % (i, cost, new_cost, lam))
+        if bad:
+            last_failed = i
+            if lam > 1e8 or i > last_ok + 15:
+                break
+            lam *= 3
+            continue
+        prob = cand
+        last_ok = i
+        if good:
+            last_good = i
+        rel_red = (cost - new_cost) / model_red if model_red != 0 else 0.0
+        if rel_red > 0.6:
+            lam *= 0.6
+        elif rel_red < 0.4:
+            lam *= 1.3
+        if i >= last_good + 3 and i >= last_failed + 3:
+            break
+    return prob, hist
+
+
+class DevicePipeline:
+    """problem data resident on the GPU + the two device stages of a Gauss-Newton / LM iteration.
+    param = "bal9": cameras are the 9 parameters of a BAL file (BAL_bench's block size, derivatives
+    by dual numbers); param = "se3": the reference optimizer's parameterisation (6-wide SE3-tangent
+    camera blocks, calibration fixed, closed-form Jacobians of BaAtLarge.h:56-150)"""
+
+    def __init__(self, prob, solver, device="cuda", param="bal9"):
         import torch
+        assert param in ("bal9", "se3")
+        self.param = param
+        self.cam_size = 9 if param == "bal9" else 6
         self.prob, self.solver = prob, solver
         self.lib = _lib.load()
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device)
@@ -174,7 +299,7 @@ class DevicePipeline:
         self.cams, self.pts = t(prob.cams, np.float64), t(prob.pts, np.float64)
         n = len(prob.obs_cam)
         self.res = torch.empty(2 * n, dtype=torch.float64, device=device)
-        self.Jc = torch.empty(18 * n, dtype=torch.float64, device=device)
+        self.Jc = torch.empty(2 * self.cam_size * n, dtype=torch.float64, device=device)
         self.Jp = torch.empty(6 * n, dtype=torch.float64, device=device)
         self.n_obs = n
 
@@ -185,7 +310,8 @@ class DevicePipeline:
     def linearize(self):
         """residuals and Jacobians of every observation (bsp_bal_linearize_f64)"""
         from . import _check
-        _check(self.lib.bsp_bal_linearize_f64(
+        fn = self.lib.bsp_bal_linearize_f64 if self.param == "bal9" else self.lib.bsp_bal_linearize_se3_f64
+        _check(fn(
             ctypes.c_int64(self.n_obs), self._p(self.obs_cam), self._p(self.obs_pt), self._p(self.obs_xy),
             self._p(self.cams), self._p(self.pts), self._p(self.res), self._p(self.Jc), self._p(self.Jp),
             ctypes.c_void_p(0)))
@@ -197,10 +323,14 @@ class DevicePipeline:
         import torch
         from . import _check
         f32 = data.dtype == torch.float32
-        fn = self.lib.bsp_bal_fill_hessian_f32 if f32 else self.lib.bsp_bal_fill_hessian_f64
         lam_c = ctypes.c_float(lam) if f32 else ctypes.c_double(lam)
-        _check(fn(self.solver._h, ctypes.c_int64(self.prob.num_pts), ctypes.c_int64(self.prob.num_cams),
-                  ctypes.c_int64(self.n_obs), self._p(self.obs_cam), self._p(self.obs_pt), self._p(self.Jc),
-                  self._p(self.Jp), self._p(self.res), lam_c, self._p(data), self._p(grad), self._p(dbg),
-                  ctypes.c_void_p(0)))
+        head = (self.solver._h, ctypes.c_int64(self.prob.num_pts), ctypes.c_int64(self.prob.num_cams),
+                ctypes.c_int64(self.n_obs), self._p(self.obs_cam), self._p(self.obs_pt), self._p(self.Jc),
+                self._p(self.Jp), self._p(self.res), lam_c, self._p(data), self._p(grad))
+        if self.param == "se3":
+            fn = self.lib.bsp_bal_fill_hessian_se3_f32 if f32 else self.lib.bsp_bal_fill_hessian_se3_f64
+            _check(fn(*head, ctypes.c_void_p(0)))
+        else:
+            fn = self.lib.bsp_bal_fill_hessian_f32 if f32 else self.lib.bsp_bal_fill_hessian_f64
+            _check(fn(*head, self._p(dbg), ctypes.c_void_p(0)))
         return data

@@ -142,11 +142,107 @@ __global__ __launch_bounds__(64) void balLinearizeKernel(int64_t numObs, const i
   }
 }
 
+// The REFERENCE's parameterisation (benchmarking/BaAtLarge.h:56-150, Cost::compute_residual as the
+// LM optimizer calls it, BaAtLargeOptimizer.cpp:108-124): the camera is T_W_C in SE(3) (camPt = R X +
+// t) with FIXED calibration (f, k1, k2); its 6 parameters are the tangent of a LEFT perturbation,
+// translation first, T <- exp(delta) T, and the optimizer applies T <- exp(-step) T
+// (BaAtLargeOptimizer.cpp:176-183).  Jacobians in closed form, exactly the expressions of the
+// reference: with p = -camPt.xy / camPt.z, s = |p|^2, r = 1 + (k1 + k2 s) s,
+//   D = d p / d(.) ,   J = f r D + p (2 p^T D) f (k1 + 2 k2 s),
+// D_point = [(z R_0 - x R_2); (z R_1 - y R_2)] * (-1 / z^2),  D_cam = the 2 x 6 matrix below.
+// A point in front of the image plane (camPt.z > 0.01; BAL cameras look down -z) gives the fixed
+// residual (25, 0) and zero Jacobians, as in the reference.
+__device__ __forceinline__ void rodriguesMatrix(const double* w, double (&R)[3][3]) {
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double a, b;  // R = I + a [w]x + b [w]x^2
+  if (th2 > 1e-20) {
+    const double th = sqrt(th2);
+    a = sin(th) / th;
+    b = (1.0 - cos(th)) / th2;
+  } else {
+    a = 1.0;
+    b = 0.5;
+  }
+  const double K[3][3] = {{0, -w[2], w[1]}, {w[2], 0, -w[0]}, {-w[1], w[0], 0}};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double k2 = 0;
+#pragma unroll
+      for (int l = 0; l < 3; l++) k2 += K[i][l] * K[l][j];
+      R[i][j] = (i == j ? 1.0 : 0.0) + a * K[i][j] + b * k2;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void balLinearizeSe3Kernel(int64_t numObs, const int64_t* obsCam,
+                                                            const int64_t* obsPt, const double* obsXy,
+                                                            const double* cams, const double* pts,
+                                                            double* res, double* Jc, double* Jp) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= numObs) return;
+  const double* cam = cams + 9 * obsCam[o];
+  const double* X = pts + 3 * obsPt[o];
+  double R[3][3];
+  rodriguesMatrix(cam, R);
+  double P[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) P[i] = R[i][0] * X[0] + R[i][1] * X[1] + R[i][2] * X[2] + cam[3 + i];
+  double* jc = Jc + 12 * o;
+  double* jp = Jp + 6 * o;
+  if (P[2] > 0.01) {
+    res[2 * o] = 25.0;
+    res[2 * o + 1] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) jc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) jp[i] = 0.0;
+    return;
+  }
+  const double f = cam[6], k1 = cam[7], k2 = cam[8];
+  const double p0 = -P[0] / P[2], p1 = -P[1] / P[2];
+  const double sq = p0 * p0 + p1 * p1;
+  const double r = 1.0 + (k1 + k2 * sq) * sq;
+  res[2 * o] = f * r * p0 - obsXy[2 * o];
+  res[2 * o + 1] = f * r * p1 - obsXy[2 * o + 1];
+  const double g = f * (k1 + k2 * 2.0 * sq);
+  // point Jacobian
+  {
+    const double denum = -1.0 / (P[2] * P[2]);
+    double D[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      D[0][c] = (P[2] * R[0][c] - P[0] * R[2][c]) * denum;
+      D[1][c] = (P[2] * R[1][c] - P[1] * R[2][c]) * denum;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const double dsq = 2.0 * (p0 * D[0][c] + p1 * D[1][c]);
+      jp[c] = f * r * D[0][c] + p0 * dsq * g;
+      jp[3 + c] = f * r * D[1][c] + p1 * dsq * g;
+    }
+  }
+  // camera Jacobian (translation, rotation)
+  {
+    const double dz = 1.0 / P[2], xdz = P[0] * dz, ydz = P[1] * dz, xydz2 = xdz * ydz;
+    const double D[2][6] = {{-dz, 0.0, xdz * dz, xydz2, -1.0 - xdz * xdz, ydz},
+                            {0.0, -dz, ydz * dz, 1.0 + ydz * ydz, -xydz2, -xdz}};
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const double dsq = 2.0 * (p0 * D[0][c] + p1 * D[1][c]);
+      jc[c] = f * r * D[0][c] + p0 * dsq * g;
+      jc[6 + c] = f * r * D[1][c] + p1 * dsq * g;
+    }
+  }
+}
+
 // One observation per 64 threads (a wave): H(cam,cam) += Jc^T Jc, H(pt,pt) += Jp^T Jp,
 // H(cam,pt) += Jc^T Jp, g += J^T r -- every block located with the device accessor.
 // Parameter numbering of the caller: points 0..numPts-1, cameras numPts.. (BaAtLargeBench.cpp:50-57).
 template <typename T>
-__global__ __launch_bounds__(256) void balFillKernel(PermutedCoalescedAccessor acc, int64_t numPts,
+__global__ __launch_bounds__(256) void balFillKernel(PermutedCoalescedAccessor acc, int camSize,
+                                                     int64_t numPts, int64_t numCams,
                                                      int64_t numObs, const int64_t* obsCam,
                                                      const int64_t* obsPt, const double* Jc,
                                                      const double* Jp, const double* res, T* data,
@@ -154,25 +250,29 @@ __global__ __launch_bounds__(256) void balFillKernel(PermutedCoalescedAccessor a
   const int lane = threadIdx.x & 63;
   const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (o >= numObs) return;
+  // (an observation whose indices fall outside [0, numPts) x [0, numCams) is skipped: its atomics
+  //  would land outside the numeric data; the host-side loader rejects such files, bal.py)
+  if (obsPt[o] < 0 || obsPt[o] >= numPts || obsCam[o] < 0 || obsCam[o] >= numCams) return;
   const int64_t ptId = obsPt[o], camId = numPts + obsCam[o];
-  const double* jc = Jc + 18 * o;
+  const int CS = camSize;  // camera block: 9 (BAL file parameters) or 6 (SE3 tangent)
+  const double* jc = Jc + 2 * CS * o;
   const double* jp = Jp + 6 * o;
   // off-diagonal block (cam, pt): 9 x 3, stored as it is or transposed (flipped)
   const auto off = acc.blockOffset(camId, ptId);
   const int64_t bo = std::get<0>(off), bs = std::get<1>(off);
   const bool flip = std::get<2>(off);
-  if (lane < 27) {
+  if (lane < 3 * CS) {
     const int i = lane / 3, j = lane % 3;  // (camera row, point column)
-    const double v = jc[i] * jp[j] + jc[9 + i] * jp[3 + j];
+    const double v = jc[i] * jp[j] + jc[CS + i] * jp[3 + j];
     T* p = data + bo + (flip ? (int64_t)j * bs + i : (int64_t)i * bs + j);
     unsafeAtomicAdd(p, (T)v);
   }
   // diagonal blocks (lower AND upper triangle written, as Eigen's += on the full block does)
   const auto dc = acc.diagBlockOffset(camId);
-  for (int e = lane; e < 81; e += 64) {
-    const int i = e / 9, j = e % 9;
+  for (int e = lane; e < CS * CS; e += 64) {
+    const int i = e / CS, j = e % CS;
     unsafeAtomicAdd(data + dc.first + (int64_t)i * dc.second + j,
-                    (T)(jc[i] * jc[j] + jc[9 + i] * jc[9 + j]));
+                    (T)(jc[i] * jc[j] + jc[CS + i] * jc[CS + j]));
   }
   const auto dp = acc.diagBlockOffset(ptId);
   if (lane < 9) {
@@ -182,7 +282,7 @@ __global__ __launch_bounds__(256) void balFillKernel(PermutedCoalescedAccessor a
   }
   if (grad) {
     const double r0 = res[2 * o], r1 = res[2 * o + 1];
-    if (lane < 9) unsafeAtomicAdd(grad + acc.paramStart(camId) + lane, (T)(jc[lane] * r0 + jc[9 + lane] * r1));
+    if (lane < CS) unsafeAtomicAdd(grad + acc.paramStart(camId) + lane, (T)(jc[lane] * r0 + jc[CS + lane] * r1));
     if (lane >= 16 && lane < 19) {
       const int i = lane - 16;
       unsafeAtomicAdd(grad + acc.paramStart(ptId) + i, (T)(jp[i] * r0 + jp[3 + i] * r1));
@@ -225,15 +325,24 @@ void balLinearize(int64_t numObs, const int64_t* obsCam, const int64_t* obsPt, c
   balCHECK(hipGetLastError());
 }
 
+void balLinearizeSe3(int64_t numObs, const int64_t* obsCam, const int64_t* obsPt, const double* obsXy,
+                     const double* cams, const double* pts, double* res, double* Jc, double* Jp,
+                     void* stream) {
+  if (numObs <= 0) return;
+  balLinearizeSe3Kernel<<<dim3((unsigned)((numObs + 63) / 64)), 64, 0, (hipStream_t)stream>>>(
+      numObs, obsCam, obsPt, obsXy, cams, pts, res, Jc, Jp);
+  balCHECK(hipGetLastError());
+}
+
 template <typename T>
-void balFillHessian(const PermutedCoalescedAccessor& acc, int64_t numPts, int64_t numCams,
+void balFillHessian(const PermutedCoalescedAccessor& acc, int camSize, int64_t numPts, int64_t numCams,
                     int64_t numObs, const int64_t* obsCam, const int64_t* obsPt, const double* Jc,
                     const double* Jp, const double* res, T lambda, T* data, T* grad, int64_t* dbg,
                     void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (numObs > 0) {
     balFillKernel<T><<<dim3((unsigned)((numObs + 3) / 4)), 256, 0, s>>>(
-        acc, numPts, numObs, obsCam, obsPt, Jc, Jp, res, data, grad, dbg);
+        acc, camSize, numPts, numCams, numObs, obsCam, obsPt, Jc, Jp, res, data, grad, dbg);
   }
   const int64_t numParams = numPts + numCams;
   if (lambda != T(0) && numParams > 0) {
@@ -243,10 +352,10 @@ void balFillHessian(const PermutedCoalescedAccessor& acc, int64_t numPts, int64_
   balCHECK(hipGetLastError());
 }
 
-template void balFillHessian<double>(const PermutedCoalescedAccessor&, int64_t, int64_t, int64_t,
+template void balFillHessian<double>(const PermutedCoalescedAccessor&, int, int64_t, int64_t, int64_t,
                                      const int64_t*, const int64_t*, const double*, const double*,
                                      const double*, double, double*, double*, int64_t*, void*);
-template void balFillHessian<float>(const PermutedCoalescedAccessor&, int64_t, int64_t, int64_t,
+template void balFillHessian<float>(const PermutedCoalescedAccessor&, int, int64_t, int64_t, int64_t,
                                     const int64_t*, const int64_t*, const double*, const double*,
                                     const double*, float, float*, float*, int64_t*, void*);
 

@@ -463,13 +463,34 @@ int bsp_bal_linearize_f64(int64_t numObs, const int64_t* obsCam, const int64_t* 
   balLinearize(numObs, obsCam, obsPt, obsXy, cams, pts, res, Jc, Jp, stream);
   BSP_CATCH
 }
+// bsp_bal_fill_hessian_*: the kernels hard-code 3 x 3 point blocks, 9 x 9 camera blocks and 9 x 3
+// camera-point blocks, points first -- a solver with any other parameter sizes would send their
+// atomics out of bounds, so the layout is checked on the host before the launch
+static void checkBalLayout(const BaSpaCho::Solver& solver, int64_t numPts, int64_t numCams,
+                           int64_t camSize = 9) {
+  if (camSize != 9 && camSize != 6) throw std::runtime_error("bsp_bal_fill_hessian: camera size must be 9 or 6");
+  BASPACHO_CHECK_GE(numPts, 0);
+  BASPACHO_CHECK_GE(numCams, 0);
+  BASPACHO_CHECK_EQ(numPts + numCams, solver.skel().numSpans());
+  const auto acc = solver.accessor();
+  for (int64_t p = 0; p < numPts + numCams; p++) {
+    const int64_t want = p < numPts ? 3 : camSize;
+    if (acc.paramSize(p) != want) {
+      throw std::runtime_error("bsp_bal_fill_hessian: parameter " + std::to_string(p) + " has size " +
+                               std::to_string(acc.paramSize(p)) + ", the BAL layout needs " +
+                               std::to_string(want) + " (points of size 3 first, then cameras of size " +
+                               std::to_string(camSize) + ")");
+    }
+  }
+}
+
 int bsp_bal_fill_hessian_f64(bsp_solver* s, int64_t numPts, int64_t numCams, int64_t numObs,
                              const int64_t* obsCam, const int64_t* obsPt, const double* Jc,
                              const double* Jp, const double* res, double lambda, double* data,
                              double* grad, int64_t* dbg, void* stream) {
   BSP_TRY
-  BASPACHO_CHECK_EQ(numPts + numCams, s->solver->skel().numSpans());
-  balFillHessian<double>(s->solver->deviceAccessor(), numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
+  checkBalLayout(*s->solver, numPts, numCams);
+  balFillHessian<double>(s->solver->deviceAccessor(), 9, numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
                          res, lambda, data, grad, dbg, stream);
   BSP_CATCH
 }
@@ -478,9 +499,37 @@ int bsp_bal_fill_hessian_f32(bsp_solver* s, int64_t numPts, int64_t numCams, int
                              const double* Jp, const double* res, float lambda, float* data,
                              float* grad, int64_t* dbg, void* stream) {
   BSP_TRY
-  BASPACHO_CHECK_EQ(numPts + numCams, s->solver->skel().numSpans());
-  balFillHessian<float>(s->solver->deviceAccessor(), numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
+  checkBalLayout(*s->solver, numPts, numCams);
+  balFillHessian<float>(s->solver->deviceAccessor(), 9, numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
                         res, lambda, data, grad, dbg, stream);
+  BSP_CATCH
+}
+
+int bsp_bal_linearize_se3_f64(int64_t numObs, const int64_t* obsCam, const int64_t* obsPt,
+                              const double* obsXy, const double* cams, const double* pts, double* res,
+                              double* Jc, double* Jp, void* stream) {
+  BSP_TRY
+  balLinearizeSe3(numObs, obsCam, obsPt, obsXy, cams, pts, res, Jc, Jp, stream);
+  BSP_CATCH
+}
+int bsp_bal_fill_hessian_se3_f64(bsp_solver* s, int64_t numPts, int64_t numCams, int64_t numObs,
+                                 const int64_t* obsCam, const int64_t* obsPt, const double* Jc,
+                                 const double* Jp, const double* res, double lambda, double* data,
+                                 double* grad, void* stream) {
+  BSP_TRY
+  checkBalLayout(*s->solver, numPts, numCams, 6);
+  balFillHessian<double>(s->solver->deviceAccessor(), 6, numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
+                         res, lambda, data, grad, nullptr, stream);
+  BSP_CATCH
+}
+int bsp_bal_fill_hessian_se3_f32(bsp_solver* s, int64_t numPts, int64_t numCams, int64_t numObs,
+                                 const int64_t* obsCam, const int64_t* obsPt, const double* Jc,
+                                 const double* Jp, const double* res, float lambda, float* data,
+                                 float* grad, void* stream) {
+  BSP_TRY
+  checkBalLayout(*s->solver, numPts, numCams, 6);
+  balFillHessian<float>(s->solver->deviceAccessor(), 6, numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
+                        res, lambda, data, grad, nullptr, stream);
   BSP_CATCH
 }
 

@@ -164,6 +164,7 @@ void EliminationTree::computeMerges() {
   }
 
   vector<NodeStats> mergedStats;
+  const bool denseMergeOn = std::getenv("BSP_DENSE_MERGE_OFF") == nullptr;  // (read once, not per candidate)
   while (!queue.empty()) {
     Cand top = queue.top();
     queue.pop();
@@ -190,7 +191,7 @@ void EliminationTree::computeMerges() {
     // trailing block, e.g. the cameras of a Schur complement -- merges whatever the model says: the
     // merged lump adds < 10 % of explicit zeros and is one chain of panels with lookahead, the
     // split one pays a lump boundary (BAL-871 with a model of lower fixed costs: 8.5 against 7.7 ms)
-    const bool denseMerge = std::getenv("BSP_DENSE_MERGE_OFF") == nullptr && score(k, p) >= 0.9;
+    const bool denseMerge = denseMergeOn && score(k, p) >= 0.9;
     if (!(tMerged < tSeparate) && !denseMerge) continue;
     childCount[p] += childCount[k] - 1;
 

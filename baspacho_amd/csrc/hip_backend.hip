@@ -330,6 +330,16 @@ struct OpTimer {
   }
 };
 
+// restores a flag on every exit (an exception from hipCHECK / launchLevels included)
+struct FlagOff {
+  bool& flag;
+  const bool saved;
+  explicit FlagOff(bool& f) : flag(f), saved(f) { flag = false; }
+  ~FlagOff() { flag = saved; }
+  FlagOff(const FlagOff&) = delete;
+  FlagOff& operator=(const FlagOff&) = delete;
+};
+
 struct HipSymbolicCtx : SymbolicCtx {
   HipSymbolicCtx(const CoalescedBlockMatrixSkel& skel_, const vector<int64_t>& permutation_)
       : skel(skel_), permutation(permutation_) {
@@ -451,7 +461,16 @@ struct HipSymbolicCtx : SymbolicCtx {
                                               int batchSize) override;
 
   // side streams (shared, see sharedStreams) + event pool of the lookahead schedule
-  hipStream_t sideStream() { return sharedStreams().side; }
+  // (resolved once per Solver, after checkDevice pinned its device: sharedStreams() takes a global
+  //  mutex and asks for the current device, several times per level on a launch-bound path)
+  SharedStreams& streams() {
+    if (!shared) {
+      checkDevice();
+      shared = &sharedStreams();
+    }
+    return *shared;
+  }
+  hipStream_t sideStream() { return streams().side; }
   // word of device memory through which the chain's potrf workgroup tells the bulk tiles which CU
   // it runs on (cooperative CU yield, hip_kernels.h)
   unsigned* yieldWord() {
@@ -461,8 +480,8 @@ struct HipSymbolicCtx : SymbolicCtx {
     }
     return reinterpret_cast<unsigned*>(yieldBuf.ptr);
   }
-  hipStream_t dueSideStream() { return sharedStreams().due; }
-  hipStream_t elimStream() { return sharedStreams().elim; }
+  hipStream_t dueSideStream() { return streams().due; }
+  hipStream_t elimStream() { return streams().elim; }
   hipEvent_t eventFromPool() {
     if (nextEvent == events.size()) {
       hipEvent_t e;
@@ -483,6 +502,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   unsigned bulkExtraLds = 6 * 1024;
   unsigned dueExtraLds = 6 * 1024;  // LDS padding of the due units' launches (BSP_DUE_EXTRA_LDS)
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
+  SharedStreams* shared = nullptr;  // this device's auxiliary streams (streams())
   HipPlanOptions planOpts;     // the plan builder's switches (BSP_DUE_STREAM, BSP_DUE_SPLIT, BSP_BULK_ROW_MAJOR, ...)
   bool mergeDeferred = false;  // BSP_MERGE_DEF=1: due + optional lookahead units of a block in one launch
   double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
@@ -1104,7 +1124,7 @@ struct HipNumericCtx : NumericCtx<T> {
     if (!g.exec) {
       g.slot.resize(std::max<size_t>((size_t)batchSize * sizeof(BT*), 256));
       hipk::DataRef<BT> ref{nullptr, (BT* const*)g.slot.ptr};
-      hipStream_t user = sym.stream, cap = sharedStreams().capture;
+      hipStream_t user = sym.stream, cap = sym.streams().capture;
       hipCHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
       sym.stream = cap;
       hipGraph_t graph = nullptr;
@@ -1163,10 +1183,10 @@ struct HipNumericCtx : NumericCtx<T> {
     DevPlan& plan = adoptPlan(buildDenseOpPlan(n, 0, offA, /*potrfOnly=*/true));
     OpTimer opTimer(sym.potrfStat, sym.stream, (double)n);
     LaunchTimer timer(sym.stream, nullptr);
-    const bool la = sym.lookaheadEnabled;
-    sym.lookaheadEnabled = false;
-    launchLevels(plan, plan.host.levels, makeRef(data), timer);
-    sym.lookaheadEnabled = la;
+    {
+      FlagOff noLookahead(sym.lookaheadEnabled);
+      launchLevels(plan, plan.host.levels, makeRef(data), timer);
+    }
     hipCHECK(hipGetLastError());
   }
 
@@ -1177,10 +1197,10 @@ struct HipNumericCtx : NumericCtx<T> {
     DevPlan& plan = adoptPlan(buildDenseOpPlan(n, k, offA, /*potrfOnly=*/false));
     OpTimer opTimer(sym.trsmStat, sym.stream, (double)n, (double)k);
     LaunchTimer timer(sym.stream, nullptr);
-    const bool la = sym.lookaheadEnabled;
-    sym.lookaheadEnabled = false;
-    launchLevels(plan, plan.host.levels, makeRef(data), timer);
-    sym.lookaheadEnabled = la;
+    {
+      FlagOff noLookahead(sym.lookaheadEnabled);
+      launchLevels(plan, plan.host.levels, makeRef(data), timer);
+    }
     hipCHECK(hipGetLastError());
   }
 
@@ -1248,8 +1268,7 @@ struct HipNumericCtx : NumericCtx<T> {
       hipk::pseudoFactorSpansKernel<BT><<<dim3((unsigned)((e - b + 3) / 4), (unsigned)batchSize), 256,
                                           0, sym.stream>>>(sym.skelDev(), ref, b, e);
     };
-    const bool la = sym.lookaheadEnabled;
-    sym.lookaheadEnabled = false;
+    FlagOff noLookahead(sym.lookaheadEnabled);
     int64_t runBegin = spanBegin;
     for (int64_t s = spanBegin; s < spanEnd; s++) {
       const int64_t n = sk.spanStart[s + 1] - sk.spanStart[s];
@@ -1273,7 +1292,6 @@ struct HipNumericCtx : NumericCtx<T> {
       }
     }
     narrowRun(runBegin, spanEnd);
-    sym.lookaheadEnabled = la;
     hipCHECK(hipGetLastError());
   }
 

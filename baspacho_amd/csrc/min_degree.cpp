@@ -82,9 +82,20 @@ static std::vector<int64_t> contractChains(std::vector<std::vector<int32_t>>& ad
   auto key = [](int32_t x, int32_t y) {
     return (uint64_t)(uint32_t)std::min(x, y) << 32 | (uint32_t)std::max(x, y);
   };
+  // candidates = live nodes with at most two live neighbours, kept as a worklist: a round costs its
+  // candidates, not a scan of all n nodes (50 parallel strips that release one pivot each per round
+  // would otherwise take n / 50 rounds of n steps)
+  std::vector<int32_t> cand, nextCand;
+  std::vector<uint8_t> inCand(n, 0);
+  for (int64_t v = 0; v < n; v++) {
+    if (alive[v] && deg[v] <= 2) {
+      cand.push_back((int32_t)v);
+      inCand[v] = 1;
+    }
+  }
   for (int64_t round = 0;; round++) {
     picked.clear();
-    for (int64_t v = 0; v < n; v++) {
+    for (int32_t v : cand) {
       if (!alive[v] || deg[v] > 2 || blockedAt[v] == round) continue;
       Pick p{(int32_t)v, -1, -1};
       for (int32_t u : adj[v]) {
@@ -117,6 +128,27 @@ static std::vector<int64_t> contractChains(std::vector<std::vector<int32_t>>& ad
       std::vector<int32_t>().swap(adj[p.v]);
       order.push_back(p.v);
     }
+    // next round's candidates: this round's survivors plus the neighbours whose degree just dropped
+    nextCand.clear();
+    for (int32_t v : cand) {
+      if (alive[v] && deg[v] <= 2) {
+        nextCand.push_back(v);
+      } else {
+        inCand[v] = 0;
+      }
+    }
+    for (const Pick& p : picked) {
+      for (int32_t u : {p.a, p.b}) {
+        if (u >= 0 && alive[u] && deg[u] <= 2 && !inCand[u]) {
+          inCand[u] = 1;
+          nextCand.push_back(u);
+        }
+      }
+    }
+    // (the scan order of a round decides which of two adjacent candidates is taken: keep it
+    //  ascending, as the full scan was, so that the ordering -- and every plan -- is unchanged)
+    std::sort(nextCand.begin(), nextCand.end());
+    cand.swap(nextCand);
   }
   return order;
 }

@@ -225,6 +225,24 @@ int bsp_bal_fill_hessian_f32(bsp_solver* s, int64_t num_pts, int64_t num_cams, i
                              const double* Jp, const double* res, float lambda, float* dev_data,
                              float* dev_grad, int64_t* dev_dbg, void* stream);
 
+/* The same pipeline in the REFERENCE's parameterisation (benchmarking/BaAtLarge.h:56-150
+   Cost::compute_residual, BaAtLargeOptimizer.cpp:24-52,100-131,176-183): cameras are 6-wide blocks,
+   the tangent of a left SE(3) perturbation T_W_C <- exp(delta) T_W_C (translation first), calibration
+   (f, k1, k2) fixed; Jc[nObs][2][6]; a point with camPt.z > 0.01 gives the residual (25, 0) and zero
+   Jacobians.  cams[nCams][9] keeps the BAL storage (Rodrigues rotation, translation, f, k1, k2).
+   The solver must have been created with camera blocks of size 6 (checked). */
+int bsp_bal_linearize_se3_f64(int64_t num_obs, const int64_t* obs_cam, const int64_t* obs_pt,
+                              const double* obs_xy, const double* cams, const double* pts,
+                              double* res, double* Jc, double* Jp, void* stream);
+int bsp_bal_fill_hessian_se3_f64(bsp_solver* s, int64_t num_pts, int64_t num_cams, int64_t num_obs,
+                                 const int64_t* obs_cam, const int64_t* obs_pt, const double* Jc,
+                                 const double* Jp, const double* res, double lambda, double* dev_data,
+                                 double* dev_grad, void* stream);
+int bsp_bal_fill_hessian_se3_f32(bsp_solver* s, int64_t num_pts, int64_t num_cams, int64_t num_obs,
+                                 const int64_t* obs_cam, const int64_t* obs_pt, const double* Jc,
+                                 const double* Jp, const double* res, float lambda, float* dev_data,
+                                 float* dev_grad, void* stream);
+
 /* ---- measurement helpers (no reference counterpart; Solver::printStats is the analogue) */
 /* algorithmic flops of a full factor: sum over lumps n^3/3 + r n^2 + r^2 n */
 double bsp_factor_flops(const bsp_solver* s);

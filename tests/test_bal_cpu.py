@@ -105,3 +105,43 @@ def test_host_fill_equals_dense_normal_equations():
     got = sol.densify(data, fill_upper_half=False)
     assert np.allclose(np.tril(got), np.tril(H), rtol=1e-12, atol=1e-9 * np.abs(H).max())
     assert np.allclose(grad, J.T @ res.reshape(-1), rtol=1e-12, atol=1e-9)
+
+
+def test_se3_jacobians_are_the_derivatives_of_the_left_perturbation():
+    """the oracle's restatement of Cost::compute_residual (BaAtLarge.h:74-147: SE3 tangent of a left
+    perturbation, translation first; fixed calibration) against central finite differences of the
+    residual under T <- exp(delta) T and X <- X + dX -- the pin of the oracle for the reference's
+    parameterisation -- and the reference's behind-the-camera rule (residual (25, 0), zero Jacobians)"""
+    from baspacho_amd import bal
+    from oracle import bal_model
+    prob = bal.synth_scene(num_cams=6, num_pts=40, seed=5)
+    cams, pts, xy = prob.cams[prob.obs_cam], prob.pts[prob.obs_pt], prob.obs_xy
+    res, Jc, Jp = bal_model.linearize_se3(cams, pts, xy)
+    # the residual itself is the BAL model's
+    assert np.allclose(res, bal.project(cams, pts) - xy, rtol=1e-12, atol=1e-10)
+    R = bal_model._rodrigues(cams[:, 0:3])
+    t, calib = cams[:, 3:6], cams[:, 6:9]
+    h = 1e-6
+    for c in range(6):
+        d = np.zeros(6)
+        d[c] = h
+        Rp, tp = bal.se3_exp(d)
+        Rm, tm = bal.se3_exp(-d)
+        rp = bal_model.residual_se3(Rp[None] @ R, (Rp @ t.T).T + tp, calib, pts, xy)
+        rm = bal_model.residual_se3(Rm[None] @ R, (Rm @ t.T).T + tm, calib, pts, xy)
+        fd = (rp - rm) / (2 * h)
+        assert np.allclose(fd, Jc[:, :, c], rtol=2e-6, atol=2e-5), c
+    for c in range(3):
+        d = np.zeros(3)
+        d[c] = h
+        fd = (bal_model.residual_se3(R, t, calib, pts + d, xy) -
+              bal_model.residual_se3(R, t, calib, pts - d, xy)) / (2 * h)
+        assert np.allclose(fd, Jp[:, :, c], rtol=2e-6, atol=2e-5), c
+    # a point on the wrong side of the image plane
+    cams2 = cams.copy()
+    cams2[0, 5] += 100.0
+    res2, Jc2, Jp2 = bal_model.linearize_se3(cams2, pts, xy)
+    assert tuple(res2[0]) == (25.0, 0.0) and not Jc2[0].any() and not Jp2[0].any()
+    # exp / log round trip of the update rule
+    w = np.array([0.3, -0.2, 0.5])
+    assert np.allclose(bal.so3_log(bal.so3_exp(w)), w, atol=1e-12)
