@@ -351,6 +351,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_STAGED")) elimFactorStaged = e[0] != '0';
+    if (const char* e = std::getenv("BSP_GATHER_FUSED_LOAD")) gatherFusedLoad = e[0] != '0';
     if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
     if (const char* e = std::getenv("BSP_MERGED_CHAIN")) mergedChain = e[0] != '0';
     if (const char* e = std::getenv("BSP_EARLY_FORK")) earlyFork = e[0] != '0';
@@ -510,6 +511,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool earlyDiag = true;       // intra-block chain steps pre-apply their panel to the next block's tile (0,0) (BSP_EARLY_DIAG=0 disables)
   bool nowSplit = false;       // opt-in BSP_NOW_SPLIT=1: block-last steps leave column tiles 2-3 of their now-update to the next two steps
   bool bulkYield = true;       // bulk tiles pause on the CU of the chain's potrf workgroup (BSP_BULK_YIELD=0 disables)
+  bool gatherFusedLoad = true;  // MFMA gather: both blocks of a pair with ONE wave load (BSP_GATHER_FUSED_LOAD=0: two)
   bool elimFactorStaged = true; // ... staged through LDS with coalesced wave loads (BSP_ELIM_FACTOR_STAGED=0: direct loads, K1t)
   bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
   bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
@@ -766,6 +768,29 @@ struct HipNumericCtx : NumericCtx<T> {
         }
       }
       const bool carried = memColEnd != INT32_MAX;
+      // CHAIN WINDOW segment (SegDesc::pad bit 2): its tiles in the NEXT outer block's columns may
+      // meet lookahead units of the side streams (none yet before this chain's first fork; all
+      // waited for at a block-last panel, bit 3).  The merged chain kernel subtracts there with
+      // atomics; any other kernel of the fallback modes joins the side streams first.
+      int atomicFromCol = INT32_MAX;
+      if (nowAtomic && lr.directSeg >= 0) atomicFromCol = plan.host.segs[lr.directSeg].q0 + kTile;
+      if (lookahead && lr.directSeg >= 0 && (sideUsed || dueUsed)) {
+        const SegDesc& sd = plan.host.segs[lr.directSeg];
+        if ((sd.pad & 4) && !(sd.pad & 8)) {
+          if (merged || direct) {   // (the direct chain kernels take the column from here on)
+            atomicFromCol = sd.q0 + sd.firstChainOrd;
+          } else {
+            hipEvent_t j1 = sym.eventFromPool();
+            hipCHECK(hipEventRecord(j1, sym.sideStream()));
+            hipCHECK(hipStreamWaitEvent(sym.stream, j1, 0));
+            if (dueUsed) {
+              hipEvent_t j2 = sym.eventFromPool();
+              hipCHECK(hipEventRecord(j2, sym.dueSideStream()));
+              hipCHECK(hipStreamWaitEvent(sym.stream, j2, 0));
+            }
+          }
+        }
+      }
       if (!waitedDef && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
         waitDeferred(lr.waitDefLevel, nowAtomic);
       }
@@ -892,7 +917,7 @@ struct HipNumericCtx : NumericCtx<T> {
               plan.host.panels[lr.directPanel], plan.host.segs[lr.directSeg], (int)nUpd, nextPanel,
               fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
               memOff, kMem, (lookahead && batchSize == 1 && sym.bulkYield) ? sym.yieldWord() : nullptr,
-              sym.traceLaunchId++, kMem0, extra, nowAtomic ? 1 : 0, memColBegin, memColEnd);
+              sym.traceLaunchId++, kMem0, extra, atomicFromCol, memColBegin, memColEnd);
           potrfFused = fuse;
         } else if (fuse) {
           if (extraApplied > 0) {
@@ -903,7 +928,7 @@ struct HipNumericCtx : NumericCtx<T> {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
           hipk::updateTileDirectPotrf<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
               plan.host.srcs[sd.src], sd, (int)nUpd, nextPanel, ref, splitK, dinvNext,
-              stage ? rawNext : nullptr, 2 * rawSlot);
+              stage ? rawNext : nullptr, 2 * rawSlot, atomicFromCol);
           potrfFused = true;
         } else if (direct && lr.directSeg >= 0) {
           if (extraApplied > 0) {
@@ -914,7 +939,7 @@ struct HipNumericCtx : NumericCtx<T> {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
           hipk::updateTileDirect<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
               plan.host.srcs[sd.src], sd, (int)nUpd, ref, stage ? rawNext : nullptr, nextPanel.nb,
-              2 * rawSlot);
+              2 * rawSlot, atomicFromCol);
         } else {
           launchUpdate(plan, updBegin, lr.updEnd, ref, sym.stream);
         }
@@ -1028,7 +1053,7 @@ struct HipNumericCtx : NumericCtx<T> {
           timer.begin(kProfElimUpdate, sym.elimStream());
           hipk::elimGatherMfma<BT><<<dim3((unsigned)((n + 3) / 4), gy), 256, 0, sym.elimStream()>>>(
               plan.elimItems.as<ElimGatherItem>() + er.groupItem[q], plan.elimPairOffJ.as<uint32_t>(),
-              plan.elimPairOffI.as<uint32_t>(), ref, (int)n, packBuf, packStride);
+              plan.elimPairOffI.as<uint32_t>(), ref, (int)n, packBuf, packStride, sym.gatherFusedLoad ? 1 : 0);
           timer.end();
         }
         hipEvent_t done = sym.eventFromPool();
@@ -1041,7 +1066,7 @@ struct HipNumericCtx : NumericCtx<T> {
         timer.begin(kProfElimUpdate);
         hipk::elimGatherMfma<BT><<<dim3((unsigned)((nItems + 3) / 4), gy), 256, 0, sym.stream>>>(
             plan.elimItems.as<ElimGatherItem>() + er.itemBegin, plan.elimPairOffJ.as<uint32_t>(),
-            plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems, packBuf, packStride);
+            plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems, packBuf, packStride, sym.gatherFusedLoad ? 1 : 0);
         timer.end();
       }
       const int64_t nWide = er.ldsEnd - er.ldsBegin;

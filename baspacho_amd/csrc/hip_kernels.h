@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
                                                       const uint32_t* offJ, const uint32_t* offI,
                                                       DataRef<T> dref, int numItems,
                                                       const T* packBuf = nullptr,
-                                                      int64_t packStride = 0) {
+                                                      int64_t packStride = 0, int fusedLoad = 1) {
   // packBuf: the pair offsets point into the packed copy of the solved blocks (elimFactorTiny)
   // pairs whose operand loads are in flight together.  With items of at most 128 pairs the kernel is
   // not bound by a wave's own round trips any more: 4 / 8 / 16 give 6.87-6.92 / 6.95-6.99 / 7.03 ms on
@@ -669,6 +669,52 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
   const int rows = it.rows, cols = it.cols, n = it.n;
   using Acc = typename Mfma<T>::Acc;
   Acc acc = {0, 0, 0, 0};
+  // ONE load instruction per pair (round 3).  PMC on BAL-871 (profiles/r03_pmc_ta.txt): the texture
+  // addresser is busy 91-100 % of this kernel, ~20 cycles per wave load whatever the 27 active lanes
+  // fetch, while the L1 -> L2 read latency averages 460 cycles: the kernel is bound by the NUMBER of
+  // vector-memory instructions, not by bytes or latency.  When both blocks of a pair fit half a wave
+  // (rows * n, cols * n <= 32 and n <= 4: the 9x3 blocks of bundle adjustment), lanes 0-31 fetch B_j
+  // and lanes 32-63 fetch B_i with the same instruction -- element e of a block in lane e -- and the
+  // MFMA operand layout (lane (i, k) wants element i * n + k) is restored through the LDS crossbar
+  // (ds_bpermute: no LDS memory, four 32-bit permutes per pair).
+  const int EA = rows * n, EB = cols * n;
+  if (fusedLoad && n <= 4 && EA <= 32 && EB <= 32) {
+    const int half = lane >> 5, e = lane & 31;
+    const bool ldOk = half ? e < EB : e < EA;
+    const uint32_t eOff = ldOk ? (uint32_t)e : 0u;
+    const bool okA = li < rows && lk < n, okB = li < cols && lk < n;
+    const int selA = 4 * (okA ? li * n + lk : 0), selB = 4 * (32 + (okB ? li * n + lk : 0));
+    for (int base = it.pairBegin; base < it.pairEnd; base += 64) {
+      const int cnt = min(64, it.pairEnd - base);
+      const uint32_t myJ = lane < cnt ? offJ[base + lane] : 0u;
+      const uint32_t myI = lane < cnt ? offI[base + lane] : 0u;
+      for (int t0 = 0; t0 < cnt; t0 += U) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int t = min(t0 + u, cnt - 1);
+          const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)myJ, t);
+          const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)myI, t);
+          v[u] = src[(half ? oi : oj) + eOff];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const bool live = t0 + u < cnt;
+          T a, b;
+          if constexpr (sizeof(T) == 8) {
+            const int lo = __double2loint(v[u]), hi = __double2hiint(v[u]);
+            a = __hiloint2double(__builtin_amdgcn_ds_bpermute(selA, hi), __builtin_amdgcn_ds_bpermute(selA, lo));
+            b = __hiloint2double(__builtin_amdgcn_ds_bpermute(selB, hi), __builtin_amdgcn_ds_bpermute(selB, lo));
+          } else {
+            const int w = __float_as_int(v[u]);
+            a = __int_as_float(__builtin_amdgcn_ds_bpermute(selA, w));
+            b = __int_as_float(__builtin_amdgcn_ds_bpermute(selB, w));
+          }
+          acc = Mfma<T>::run((okA && live) ? a : T(0), okB ? b : T(0), acc);
+        }
+      }
+    }
+  } else {
   for (int k0 = 0; k0 < n; k0 += 4) {  // one pass per 4 source columns (n <= 4: a single pass)
     const int k = k0 + lk;
     const bool okA = li < rows && k < n, okB = li < cols && k < n;
@@ -695,6 +741,7 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
         }
       }
     }
+  }
   }
   GP<T> target = data + it.tgtOff;
   GP<T> ptr[4];
@@ -1867,7 +1914,8 @@ __device__ __forceinline__ int xcdContiguous(int b, int n) {
 template <typename T>
 __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const SegDesc& sd, int idx,
                                                      GP<T> data, T* As, T* Bs,
-                                                     GP<T> rawOut = nullptr, int nbNext = 0) {
+                                                     GP<T> rawOut = nullptr, int nbNext = 0,
+                                                     int atomicFromCol = 0x7fffffff) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
   int colTile = sd.q0, rowTile;
   for (;;) {
@@ -1962,11 +2010,15 @@ __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const Se
       for (int reg = 0; reg < 4; reg++) {
         const int qr = rowTile + wr + (t >> 1) * 16 + Mfma<T>::row(lane, reg);
         if (qc < segEnd && qr < pd.rowsBelow && qr >= qc && qr >= sd.rowMin) {
-          const T val = old[t * 4 + reg] - (*accs[t])[reg];
-          tgt[(int64_t)qr * sd.tgtStride + qc] = val;
-          // rows below the next panel's diagonal block, also to the chain's staging buffer
-          if (rawOut && colTile == 0 && qc < nbNext && qr >= nbNext) {
-            rawOut[(int64_t)(qr - nbNext) * kTile + qc] = val;
+          if (colTile >= atomicFromCol) {  // (CHAIN WINDOW: columns shared with lookahead units)
+            atomicSub(tgt + (int64_t)qr * sd.tgtStride + qc, (*accs[t])[reg]);
+          } else {
+            const T val = old[t * 4 + reg] - (*accs[t])[reg];
+            tgt[(int64_t)qr * sd.tgtStride + qc] = val;
+            // rows below the next panel's diagonal block, also to the chain's staging buffer
+            if (rawOut && colTile == 0 && qc < nbNext && qr >= nbNext) {
+              rawOut[(int64_t)(qr - nbNext) * kTile + qc] = val;
+            }
           }
         }
       }
@@ -1977,13 +2029,14 @@ __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const Se
 template <typename T>
 __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, int nTasks,
                                                         DataRef<T> dref, T* rawOut, int nbNext,
-                                                        int64_t rawStride) {
+                                                        int64_t rawStride, int atomicFromCol) {
   constexpr int LD = kUpdChunk + 2;
   __shared__ T As[kTile * LD];
   __shared__ T Bs[kTile * LD];
   __builtin_amdgcn_s_setprio(BSP_TILE_PRIO);
   updateTileDirectBody<T>(pd, sd, xcdContiguous(blockIdx.x, nTasks), pickData(dref), As, Bs,
-                          rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr, nbNext);
+                          rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr, nbNext,
+                          atomicFromCol);
 }
 
 // K5f  the same launch with the NEXT panel's potrf fused in.  Tile 0 of the segment is the next
@@ -2016,7 +2069,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc sd, int nTasks,
                                                              PanelDesc next, DataRef<T> dref,
                                                              int kStart, T* dinvOut, T* rawOut,
-                                                             int64_t rawStride) {
+                                                             int64_t rawStride, int atomicFromCol) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
   __shared__ __attribute__((aligned(16))) T As[kTile * LD];
   __shared__ __attribute__((aligned(16))) T Bs[kTile * LD];
@@ -2027,7 +2080,7 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
     GP<T> raw = rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr;
     // (the bulk tile body -- operands straight to LDS, no register prefetch -- was measured
     //  slower for these tiles: they run on the chain's stream, where latency counts)
-    updateTileDirectBody<T>(pd, sd, idx, data, As, Bs, raw, next.nb);
+    updateTileDirectBody<T>(pd, sd, idx, data, As, Bs, raw, next.nb, atomicFromCol);
     return;
   }
   __builtin_amdgcn_s_setprio(3);
@@ -2212,14 +2265,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     PanelDesc pd, SegDesc sd, int nTasks, PanelDesc next, int fuse, DataRef<T> dref,
     const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase,
     int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag,
-    int nowAtomic, int memColBegin, int memColEnd) {
+    int atomicFromCol, int memColBegin, int memColEnd) {
+  // atomicFromCol: tiles whose column tile starts at or beyond this below-row index subtract with
+  // atomics -- DUE SPLIT block-last steps (everything right of the first column tile) and CHAIN
+  // WINDOW steps (the next outer block's columns, shared with lookahead units); INT_MAX: none
   // memColBegin / memColEnd (NOW SPLIT, LevelRange::nowHeadTiles): only the tiles of column tiles
   // [memColBegin, memColEnd) (below-row indices) take the kMem source columns at memOff -- the
   // block-last step passes [0, INT_MAX); the first two steps of the next block pass the ONE column
   // tile that still owes the previous block's rank-256 update, with memOff pointing at that block's
   // solved rows (shifted to this panel's row origin)
-  // nowAtomic (block-last step, DUE SPLIT): the tiles right of the segment's first column tile are
-  // subtracted with atomics -- the due units of those columns may still be running on the side
   // kMem0 <= kMem: source columns workgroup 0 still has to apply from memory to tile (0,0), the
   // LAST kMem0 of the kMem ones -- the earlier panels of the block applied theirs already, each in
   // its own step (extraDiag: one more workgroup, the diagonal tile just past the segment's columns
@@ -2326,7 +2380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int reg = 0; reg < 4; reg++) {
       const int qr = rowTile + 16 * w + Mfma<T>::row(lane, reg);
       if (qc < colEnd && qr < rowsBelow && qr >= qc && qr >= sd.rowMin) {
-        if (extra || (nowAtomic && colTile > sd.q0)) {
+        if (extra || colTile >= atomicFromCol) {
           atomicSub(tgt + (int64_t)qr * sd.tgtStride + qc, D[t][reg]);
         } else {
           const T val = old[t * 4 + reg] - D[t][reg];

@@ -478,6 +478,9 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
       }
       perXcd[row % 8].push_back(k);
     }
+    if (plan.opts.gatherReverse) {
+      for (auto& v : perXcd) std::reverse(v.begin(), v.end());
+    }
     size_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t remaining = nItems, out = er.itemBegin + g0;
     while (remaining > 0) {
@@ -531,6 +534,9 @@ HipPlanOptions HipPlanOptions::fromEnv() {
   o.planTiming = std::getenv("BSP_TIMING") != nullptr;
   o.dropElimUpdate = optIn("BSP_FAULT_DROP_ELIM_UPDATE");
   o.nowSplit = optIn("BSP_NOW_SPLIT");
+  o.chainWindow = optIn("BSP_CHAIN_WINDOW");
+  o.gatherReverse = optIn("BSP_GATHER_REVERSE");
+  if (o.chainWindow) o.nowSplit = false;
   if (const char* e = std::getenv("BSP_GATHER_MAX_PAIRS")) o.gatherMaxPairs = std::max(8, atoi(e));
   if (const char* e = std::getenv("BSP_BULK_AHEAD")) o.bulkAhead = std::atof(e);
   return o;
@@ -593,7 +599,16 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         plan.potrfFlops += double(nb) * nb * nb / 3.0;
         plan.trsmFlops += double(pd.rowsBelow) * nb * nb;
         panelSegBegin.push_back((int64_t)plan.segs.size());
-        const int64_t innerCols = blockEnd - c0 - nb;
+        // CHAIN WINDOW (opts.chainWindow): a panel of a lump with further outer blocks updates, with
+        // its own rank nb, not only the rest of its block but the whole NEXT block as well, and the
+        // block-wide rank-256 "now" update (390 tiles with 256 source columns from memory on the
+        // execution stream, ~50 us each beside a saturated bulk stream) does not exist: every launch
+        // of the chain is made of light tiles.  The next block's columns are shared with the
+        // lookahead units that are due at the end of this block: both sides use atomics there.
+        const bool window = opts.chainWindow && n > blockEnd && nb == kPanelWidth &&
+                            blockEnd - blockStart == kOuterWidth;
+        const int64_t ownCols = blockEnd - c0 - nb;
+        const int64_t innerCols = ownCols + (window ? std::min<int64_t>(kOuterWidth, n - blockEnd) : 0);
         if (innerCols > 0) {
           SrcDesc sr{};
           sr.off = pd.diagOff + (int64_t)nb * n;
@@ -610,6 +625,11 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           s.m = (int32_t)innerCols;
           s.tgtBase = g.diagOff + (c0 + nb) * n + (c0 + nb);
           s.tgtStride = (int32_t)n;
+          if (window) {
+            s.lump = (int32_t)l;
+            s.firstChainOrd = (int32_t)ownCols;
+            s.pad = 4 | (ownCols == 0 ? 8 : 0);
+          }
           plan.segs.push_back(s);
         }
         // EARLY DUE: the due unit of this block (to column block b + 2) is what the chain waits for
@@ -670,7 +690,10 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
               s.m = (int32_t)std::min<int64_t>(sr.nRest, kOuterWidth);
               s.tgtBase = g.diagOff + blockEnd * n + blockEnd;
               s.tgtStride = (int32_t)n;
-              plan.segs.push_back(s);
+              // (CHAIN WINDOW: the block's four panels have each applied their rank 64 to these
+              //  columns already; `s` only serves as the template of the lookahead units below)
+              const bool windowBlock = opts.chainWindow && blockEnd - blockStart == kOuterWidth;
+              if (!windowBlock) plan.segs.push_back(s);
               // Columns further right go to the lookahead (side) stream, in DEADLINE order rather
               // than source order: a column block c only has to be up to date when block c-1's
               // "now" update reaches it, so what this block (and earlier ones) still owe to c is
@@ -703,8 +726,12 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                 // bit 0: several units on this target in one launch; bit 1: the target may be met
                 // by a launch of the OTHER side stream (due-stream mode; the kernels take a mask, so
                 // a call that orders the launches on one stream ignores this bit)
+                // (CHAIN WINDOW: the chain's own tiles reach column block c from block c - 1's first
+                //  step on, i.e. they meet the due units and the optional units to c = b + 3
+                //  whatever the streams are: plain bit 0, honoured by every launch mode)
                 const int32_t multi = (pendingFrom[c] < b ? 1 : 0) |
-                                      ((dueStream && (outerKind == 2 || c == b + 3)) ? 2 : 0);
+                                      ((dueStream && (outerKind == 2 || c == b + 3)) ? 2 : 0) |
+                                      ((windowBlock && (outerKind == 2 || c == b + 3)) ? 1 : 0);
                 for (int64_t sb = pendingFrom[c]; sb <= b; sb++) {
                   SrcDesc fs = sr;
                   fs.off = g.diagOff + blockEnd * n + sb * kOuterWidth;
@@ -958,7 +985,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           // (bit 1: only when launches of two side streams can meet, see pushUnit)
           const int32_t atomic = ((sd.kind == kSegBoard && hits[sd.tgtBase] > 1) || (sd.pad & 1) ? 1 : 0) |
                                  (sd.pad & 2);
-          if (sd.outer == 1) {
+          if (sd.outer == 1 || (sd.pad & 8)) {
             // this block-wide update touches columns that the previous block's deferred tiles
             // of the same lump also touch: they must have completed
             auto it = lastDeferredLevel.find(sd.lump);
@@ -1000,9 +1027,14 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             const int32_t cb = s < (int64_t)plan.segColBlock.size() ? plan.segColBlock[s] : -1;
             (late ? maxCbLate : maxCbMid) = std::max(late ? maxCbLate : maxCbMid, cb);
           } else {
+            // (CHAIN WINDOW segment: the tiles in the next block's columns may meet lookahead units;
+            //  a block-last panel's level has waited for them.  The task-list kernels go by the flag,
+            //  the direct chain kernels by SegDesc::firstChainOrd)
+            const bool win = (sd.pad & 4) != 0 && !(sd.pad & 8);
             for (int32_t cT = sd.q0; cT < sd.q0 + sd.m; cT += step) {
+              const int32_t a = atomic | ((win && cT >= sd.q0 + sd.firstChainOrd) ? 1 : 0);
               for (int32_t rT = cT; rT < sr.rowsBelow; rT += step) {
-                plan.updTasks.push_back(UpdTask{(int32_t)s, rT, cT, atomic});
+                plan.updTasks.push_back(UpdTask{(int32_t)s, rT, cT, a});
                 if (nowSeg != (int32_t)s) nowSegs++;
                 nowSeg = (int32_t)s;
                 if (sd.kind != kSegIntra || atomic) nowPlain = false;
@@ -1102,8 +1134,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             // tile (0,0) of a following block inside the lump
             const PanelDesc& pd0 = plan.panels[bucket[0].panel];
             const SrcDesc& sr0 = plan.srcs[sd.src];
+            // (not with a CHAIN WINDOW segment: the next block's tile (0,0) is inside the window)
             if (!sd.outer && sd.kind == kSegIntra && sd.q0 == 0 && sr0.K == pd0.nb &&
-                pd0.nb == kPanelWidth && pd0.nRest - sd.m >= kTile) {
+                pd0.nb == kPanelWidth && pd0.nRest - sd.m >= kTile && !(sd.pad & 4)) {
               lr.extraDiag = 1;
             }
           }

@@ -58,12 +58,17 @@ struct SegDesc {
   int32_t m;             // number of columns
   int64_t tgtBase;       // intra: data offset of element (row q=0, col q=0) of the target region
   int32_t tgtStride;     // row stride of the target lump
-  int32_t firstChainOrd; // board: below-diagonal chain ordinal of the segment's first chain
+  int32_t firstChainOrd; // board: below-diagonal chain ordinal of the segment's first chain;
+                         // intra WINDOW segment (pad bit 2): number of leading columns that lie in
+                         // the panel's own outer block -- the rest belong to the next block, where
+                         // lookahead units may be at work (those tiles subtract with atomics)
   int64_t chainTabPtr;   // board: index into chainOffTab of that chain's entry
   int32_t outer;         // 1: source is a complete outer block (rank-kOuterWidth update)
   int32_t lump;          // lump owning the source columns
   int32_t rowMin;        // rows (below-row index) smaller than this are left untouched
-  int32_t pad;
+  int32_t pad;           // bit 0: several writers in one launch, bit 1: writers of two side streams may
+                         // meet, bit 2: WINDOW segment (chainWindow), bit 3: window segment of a
+                         // block-last panel (the level waits for the lookahead units of its target)
 };
 
 struct UpdTask {
@@ -286,6 +291,12 @@ struct HipPlanOptions {
   bool nowSplit = false;      // BSP_NOW_SPLIT=1 (opt-in; measured: no gain, below): a chain's block-wide "now" update keeps only the next
                               // block's first two column tiles, the other two are applied by the
                               // next block's first two steps (LevelRange::nowHeadTiles)
+  bool chainWindow = false;   // BSP_CHAIN_WINDOW: every panel of a multi-block lump updates through the
+                              // end of the NEXT outer block (rank 64) and the block-wide "now"
+                              // update disappears (SegDesc::pad bit 2, hip_plan.cpp addPanels)
+  bool gatherReverse = false; // BSP_GATHER_REVERSE: gather items from the LAST target row to the first
+                              // (the sources of the last rows are what the factor kernel wrote
+                              // last, i.e. what the memory-side cache still holds)
   int32_t gatherMaxPairs = 128;  // BSP_GATHER_MAX_PAIRS
   double bulkAhead = 0.6;     // BSP_BULK_AHEAD
   static HipPlanOptions fromEnv();

@@ -294,7 +294,7 @@ def test_lump_widths_around_panel_and_block_boundaries(dtype):
 
 
 @pytest.mark.parametrize("knob", ["BSP_NO_LOOKAHEAD=1", "BSP_DIRECT_CHAIN=0", "BSP_FUSE_POTRF=0",
-                                  "BSP_SPLIT_DIAG=0", "BSP_ELIM_FACTOR_DESC=0", "BSP_ELIM_FACTOR_STAGED=0",
+                                  "BSP_SPLIT_DIAG=0", "BSP_ELIM_FACTOR_DESC=0", "BSP_ELIM_FACTOR_STAGED=0", "BSP_GATHER_FUSED_LOAD=0",
                                   "BSP_MERGED_CHAIN=0", "BSP_BULK_KERNEL=0", "BSP_EARLY_FORK=0",
                                   "BSP_MERGED_BLOCK_LAST=0", "BSP_EARLY_DIAG=0", "BSP_BULK_YIELD=0",
                                   "BSP_BULK_ROW_MAJOR=0", "BSP_DUE_STREAM=0", "BSP_EARLY_DUE=1", "BSP_DUE_SPLIT=1",
@@ -370,6 +370,37 @@ def test_now_split_carries_column_tiles(monkeypatch, lookahead, dtype):
     Lg = lower_of(sol, _gpu_factor(sol, data)).astype(np.float64)
     tol = 1e-10 if dtype == np.float64 else 2e-5
     assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < tol
+
+
+@pytest.mark.parametrize("extra", ["", "BSP_NO_LOOKAHEAD=1", "BSP_MERGED_CHAIN=0", "BSP_DIRECT_CHAIN=0",
+                                   "BSP_DUE_STREAM=0", "BSP_BULK_AHEAD=0", "BSP_BULK_AHEAD=100"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_chain_window(monkeypatch, extra, dtype):
+    """opt-in BSP_CHAIN_WINDOW=1 (SegDesc::pad bit 2): every panel of a multi-block lump applies its
+    rank-64 update through the end of the NEXT outer block and the block-wide now-update disappears;
+    the next block's columns are shared with the lookahead units (atomics on both sides; the
+    fallback kernels join the side streams first).  Dense lumps of seven and of two-and-a-bit outer
+    blocks, and a bundle-adjustment shape, under the schedule fallbacks that interact with it."""
+    monkeypatch.setenv("BSP_CHAIN_WINDOW", "1")
+    if extra:
+        k, v = extra.split("=")
+        monkeypatch.setenv(k, v)
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    for n in (1700, 600):
+        ss = T.columns_to_structure([set(range(i, n)) for i in range(n)])
+        sol = B.create_solver(B.Settings(), np.ones(n, dtype=np.int64), ss)
+        data = spd_data(sol, 23 + n, beta_factor=1.2, dtype=dtype)
+        _, A = dense_lower_chol(sol, data)
+        Lg = lower_of(sol, _gpu_factor(sol, data)).astype(np.float64)
+        assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < tol, n
+    sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=130, num_pts=9000, band=30, seed=5)
+    sol = B.create_solver(B.Settings(), sizes, ss, [0, 9000])
+    data = spd_data(sol, 11, beta_factor=1.2, dtype=dtype)
+    ref = data.astype(np.float64)
+    cref.factor(sol.skel(), ref, sol.sparseEliminationRanges())
+    got = _gpu_factor(sol, data).astype(np.float64)
+    mask = sol.lowerMask()
+    assert np.linalg.norm((got - ref)[mask]) / np.linalg.norm(ref[mask]) < (1e-12 if dtype == np.float64 else 2e-5)
 
 
 @pytest.mark.parametrize("ahead", ["0", "0.6", "100"])
