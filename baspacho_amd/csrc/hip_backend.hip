@@ -351,7 +351,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_STAGED")) elimFactorStaged = e[0] != '0';
-    if (const char* e = std::getenv("BSP_GATHER_FUSED_LOAD")) gatherFusedLoad = e[0] != '0';
+    if (const char* e = std::getenv("BSP_GATHER_FUSED_LOAD")) gatherFusedLoad = atoi(e);
     if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
     if (const char* e = std::getenv("BSP_MERGED_CHAIN")) mergedChain = e[0] != '0';
     if (const char* e = std::getenv("BSP_EARLY_FORK")) earlyFork = e[0] != '0';
@@ -511,7 +511,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool earlyDiag = true;       // intra-block chain steps pre-apply their panel to the next block's tile (0,0) (BSP_EARLY_DIAG=0 disables)
   bool nowSplit = false;       // opt-in BSP_NOW_SPLIT=1: block-last steps leave column tiles 2-3 of their now-update to the next two steps
   bool bulkYield = true;       // bulk tiles pause on the CU of the chain's potrf workgroup (BSP_BULK_YIELD=0 disables)
-  bool gatherFusedLoad = true;  // MFMA gather: both blocks of a pair with ONE wave load (BSP_GATHER_FUSED_LOAD=0: two)
+  int gatherFusedLoad = 1;  // MFMA gather, wave loads per pair (BSP_GATHER_FUSED_LOAD): 1 -> one (both blocks of a pair; default), 0 -> two, 2 -> half (fp64: two pairs per 16-byte-per-lane load through an LDS slot; measured 1.15 against 1.17 ms for the kernel and nothing for factor(): at 5.2 TB/s of fetch the kernel is on the memory system, not the texture addresser, any more)
   bool elimFactorStaged = true; // ... staged through LDS with coalesced wave loads (BSP_ELIM_FACTOR_STAGED=0: direct loads, K1t)
   bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
   bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
@@ -1053,7 +1053,7 @@ struct HipNumericCtx : NumericCtx<T> {
           timer.begin(kProfElimUpdate, sym.elimStream());
           hipk::elimGatherMfma<BT><<<dim3((unsigned)((n + 3) / 4), gy), 256, 0, sym.elimStream()>>>(
               plan.elimItems.as<ElimGatherItem>() + er.groupItem[q], plan.elimPairOffJ.as<uint32_t>(),
-              plan.elimPairOffI.as<uint32_t>(), ref, (int)n, packBuf, packStride, sym.gatherFusedLoad ? 1 : 0);
+              plan.elimPairOffI.as<uint32_t>(), ref, (int)n, packBuf, packStride, sym.gatherFusedLoad);
           timer.end();
         }
         hipEvent_t done = sym.eventFromPool();
@@ -1066,7 +1066,7 @@ struct HipNumericCtx : NumericCtx<T> {
         timer.begin(kProfElimUpdate);
         hipk::elimGatherMfma<BT><<<dim3((unsigned)((nItems + 3) / 4), gy), 256, 0, sym.stream>>>(
             plan.elimItems.as<ElimGatherItem>() + er.itemBegin, plan.elimPairOffJ.as<uint32_t>(),
-            plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems, packBuf, packStride, sym.gatherFusedLoad ? 1 : 0);
+            plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems, packBuf, packStride, sym.gatherFusedLoad);
         timer.end();
       }
       const int64_t nWide = er.ldsEnd - er.ldsBegin;

@@ -678,6 +678,58 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
   // MFMA operand layout (lane (i, k) wants element i * n + k) is restored through the LDS crossbar
   // (ds_bpermute: no LDS memory, four 32-bit permutes per pair).
   const int EA = rows * n, EB = cols * n;
+  // TWO pairs per load instruction (fp64): 16 bytes per lane, lane group g = lane / 16 fetches block
+  // (pair g / 2, B_j or B_i) two elements per lane, the wave's 1 KB lands lane-linear in a private LDS
+  // slot (one ds_write_b128) where element e of group g is simply slot[32 g + e], and the MFMA
+  // operands are read back from there.  The texture addresser spends ~22 cycles per wave load
+  // whatever it fetches (PMC, profiles/r03_pmc_ta_*.txt): 4 blocks per instruction instead of 2.
+  // (the last lane of an odd-sized block reads 8 bytes past it: inside the numeric data, a source
+  //  block is always followed by the column its pairs update, or by the rest of its 32-element slot)
+  if constexpr (sizeof(T) == 8) {
+    if (fusedLoad >= 2 && n <= 4 && EA <= 32 && EB <= 32) {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // (blocks are 8-byte aligned)
+      typedef __attribute__((address_space(1))) const d2u* GP2;
+      constexpr int S = U / 2;  // wave loads in flight
+      __shared__ __attribute__((aligned(16))) double stage[4][S][128];
+      const int g = lane >> 4, q = lane & 15, hp = g >> 1, isI = g & 1;
+      const bool ldOk = 2 * q < (isI ? EB : EA);
+      const bool okA = li < rows && lk < n, okB = li < cols && lk < n;
+      const int idxA = okA ? li * n + lk : 0, idxB = 32 + (okB ? li * n + lk : 0);
+      for (int base = it.pairBegin; base < it.pairEnd; base += 64) {
+        const int cnt = min(64, it.pairEnd - base);
+        const uint32_t myJ = lane < cnt ? offJ[base + lane] : 0u;
+        const uint32_t myI = lane < cnt ? offI[base + lane] : 0u;
+        for (int t0 = 0; t0 < cnt; t0 += U) {
+          d2 v[S];
+#pragma unroll
+          for (int s2 = 0; s2 < S; s2++) {
+            const int ta = min(t0 + 2 * s2, cnt - 1), tb = min(t0 + 2 * s2 + 1, cnt - 1);
+            const uint32_t oja = (uint32_t)__builtin_amdgcn_readlane((int)myJ, ta);
+            const uint32_t oia = (uint32_t)__builtin_amdgcn_readlane((int)myI, ta);
+            const uint32_t ojb = (uint32_t)__builtin_amdgcn_readlane((int)myJ, tb);
+            const uint32_t oib = (uint32_t)__builtin_amdgcn_readlane((int)myI, tb);
+            const uint32_t o = hp ? (isI ? oib : ojb) : (isI ? oia : oja);
+            v[s2] = *(GP2)((GP<const double>)src + o + (ldOk ? 2 * q : 0));
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < S; s2++) *(d2*)&stage[wave][s2][2 * lane] = v[s2];
+          waveSync();
+#pragma unroll
+          for (int s2 = 0; s2 < S; s2++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const bool live = t0 + 2 * s2 + h < cnt;
+              const double a = stage[wave][s2][64 * h + idxA], b = stage[wave][s2][64 * h + idxB];
+              acc = Mfma<T>::run((okA && live) ? a : 0.0, okB ? b : 0.0, acc);
+            }
+          }
+          waveSync();  // (the slots are rewritten by the next group of pairs)
+        }
+      }
+      goto gathered;
+    }
+  }
   if (fusedLoad && n <= 4 && EA <= 32 && EB <= 32) {
     const int half = lane >> 5, e = lane & 31;
     const bool ldOk = half ? e < EB : e < EA;
@@ -743,6 +795,7 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
     }
   }
   }
+gathered:
   GP<T> target = data + it.tgtOff;
   GP<T> ptr[4];
   bool ok[4];

@@ -294,7 +294,7 @@ def test_lump_widths_around_panel_and_block_boundaries(dtype):
 
 
 @pytest.mark.parametrize("knob", ["BSP_NO_LOOKAHEAD=1", "BSP_DIRECT_CHAIN=0", "BSP_FUSE_POTRF=0",
-                                  "BSP_SPLIT_DIAG=0", "BSP_ELIM_FACTOR_DESC=0", "BSP_ELIM_FACTOR_STAGED=0", "BSP_GATHER_FUSED_LOAD=0",
+                                  "BSP_SPLIT_DIAG=0", "BSP_ELIM_FACTOR_DESC=0", "BSP_ELIM_FACTOR_STAGED=0", "BSP_GATHER_FUSED_LOAD=0", "BSP_GATHER_FUSED_LOAD=2",
                                   "BSP_MERGED_CHAIN=0", "BSP_BULK_KERNEL=0", "BSP_EARLY_FORK=0",
                                   "BSP_MERGED_BLOCK_LAST=0", "BSP_EARLY_DIAG=0", "BSP_BULK_YIELD=0",
                                   "BSP_BULK_ROW_MAJOR=0", "BSP_DUE_STREAM=0", "BSP_EARLY_DUE=1", "BSP_DUE_SPLIT=1",
