@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests -q -m gpu 2>&1 | tail -4 > gpurun_out/r03_gpu_tests.txt; cat gpurun_out/r03_gpu_tests.txt
+timeout 1500 bash profiles/collect_round.sh r03
+python bench.py --suite ref --suite-out gpurun_out/r03_ref_suite.json > gpurun_out/r03_ref_suite.log 2>/dev/null; tail -1 gpurun_out/r03_ref_suite.log
+timeout 300 bash profiles/prof_grid.sh
+python tools/vendor_compare.py > gpurun_out/r03_vendor_compare.txt 2>&1; cat gpurun_out/r03_vendor_compare.txt
+ls gpurun_out | head -80
