@@ -348,6 +348,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_DUE_EXTRA_LDS")) dueExtraLds = (unsigned)atoi(e);
     if (const char* e = std::getenv("BSP_FUSE_POTRF")) fusePotrf = e[0] != '0';
     if (const char* e = std::getenv("BSP_BLOCK_SOLVE")) blockSolve = e[0] != '0';
+    if (const char* e = std::getenv("BSP_SOLVE_INV")) solveInv = e[0] != '0';
     if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_STAGED")) elimFactorStaged = e[0] != '0';
@@ -530,6 +531,17 @@ struct HipSymbolicCtx : SymbolicCtx {
   // destroyed around every factor() / solve(), Solver.cpp:176,223, while their kernels may still be
   // queued): sized on first use, only ever grown
   DevBuf dinvScratch, rawScratch, yieldBuf;
+  // block solves through inverted diagonal blocks (denseLevels): the inverses of one solve call, and
+  // per level list the panels whose diagonal blocks are inverted (uploaded once)
+  DevBuf solveInvScratch;
+  struct SolveInvList {
+    bool built = false;
+    int64_t count = 0;
+    DevBuf list;
+    vector<int32_t> slotOfGroup;
+  };
+  std::map<const void*, SolveInvList> solveInvLists;
+  bool solveInv = true;  // BSP_SOLVE_INV=0: the substitution kernels of rounds 1-2
   DevBuf elimPackBuf;  // packed copy of the solved blocks of a sparse-elimination range (BSP_ELIM_PACK=1)
   PtrRing ptrRing;
   bool rowFormAttrSet[2] = {false, false};  // elimRowMfma dynamic-LDS attribute (fp64, fp32)
@@ -1453,13 +1465,64 @@ struct HipSolveCtx : SolveCtx<T> {
       l = e;
     }
     const int64_t nG = (int64_t)groups.size();
+    // round 3 (BSP_SOLVE_INV=0 disables): the block triangles through inverted 64 x 64 diagonal
+    // blocks -- one launch inverts the diagonal block of every panel of every block group (the list
+    // of those panels is built and uploaded once per level list), the block kernel then needs one
+    // round trip (hip_solve_kernels.h, K-B0 / K-B1i)
+    const BT* invBase = nullptr;
+    int64_t invBatchStride = 0;
+    const vector<int32_t>* invSlot = nullptr;
+    if (sym.solveInv && sym.blockSolve) {  // (blockSolve off: one-off level lists of the per-op path)
+      auto& ent = sym.solveInvLists[&levels];
+      if (!ent.built) {
+        vector<PanelDesc> list;
+        ent.slotOfGroup.assign(groups.size(), -1);
+        for (size_t g = 0; g < groups.size(); g++) {
+          if (groups[g].second - groups[g].first < 2) continue;
+          ent.slotOfGroup[g] = (int32_t)list.size();
+          for (int64_t l = groups[g].first; l < groups[g].second; l++) {
+            list.push_back(plan.host.panels[levels[l].directPanel]);
+          }
+        }
+        ent.count = (int64_t)list.size();
+        if (ent.count) ent.list.upload(list);
+        ent.built = true;
+      }
+      if (ent.count > 0) {
+        invBatchStride = ent.count * kPanelWidth * kPanelWidth;
+        sym.solveInvScratch.resize((size_t)(invBatchStride * batch) * sizeof(BT));
+        BT* scratch = const_cast<BT*>(sym.solveInvScratch.as<BT>());
+        hipk::solveInvertPanels<BT><<<dim3((unsigned)ent.count, 1, (unsigned)batch), 64, 0, sym.stream>>>(
+            ent.list.as<PanelDesc>(), scratch, invBatchStride, ref);
+        invBase = scratch;
+        invSlot = &ent.slotOfGroup;
+      }
+    }
     for (int64_t gi = 0; gi < nG; gi++) {
-      const auto& grp = groups[BACKWARD ? nG - 1 - gi : gi];
+      const int64_t gIdx = BACKWARD ? nG - 1 - gi : gi;
+      const auto& grp = groups[gIdx];
       if (grp.second - grp.first >= 2) {
         const PanelDesc& first = plan.host.panels[levels[grp.first].directPanel];
         const PanelDesc& last = plan.host.panels[levels[grp.second - 1].directPanel];
         const int w = (int)(grp.second - 1 - grp.first) * kPanelWidth + last.nb;
         const unsigned nT = (unsigned)((last.rowsBelow + kTile - 1) / kTile);
+        if (invBase && (*invSlot)[gIdx] >= 0) {
+          const BT* inv = invBase + (int64_t)(*invSlot)[gIdx] * kPanelWidth * kPanelWidth;
+          if (!BACKWARD) {
+            hipk::solveTriBlockInv<BT, false><<<grid(1), 256, 0, sym.stream>>>(first, w, inv, invBatchStride, ref);
+            if (nT) {
+              hipk::solveGemvBlockL<BT><<<grid(nT), 256, 0, sym.stream>>>(
+                  first, last, w, plan.rowGlobal.as<int32_t>(), ref);
+            }
+          } else {
+            if (nT) {
+              hipk::solveGemvBlockLt<BT><<<grid(nT), 256, 0, sym.stream>>>(
+                  first, last, w, plan.rowGlobal.as<int32_t>(), ref);
+            }
+            hipk::solveTriBlockInv<BT, true><<<grid(1), 256, 0, sym.stream>>>(first, w, inv, invBatchStride, ref);
+          }
+          continue;
+        }
         if (!BACKWARD) {
           hipk::solveTriBlock<BT, false><<<grid(1), 256, 0, sym.stream>>>(first, w, ref);
           if (nT) {

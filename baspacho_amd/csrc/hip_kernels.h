@@ -18,6 +18,9 @@ namespace hipk {
 
 // One matrix (single) or a batch of identical-structure matrices (many, indexed by blockIdx.y);
 // replaces the Plain/Batched policy structs of MatOpsCuda.cu:345-368.
+#ifndef BSP_BULK_AUX
+#define BSP_BULK_AUX 0  // cache policy of the bulk tile's operand loads (global_load_lds aux: 1 sc0, 2 nt, 16 sc1)
+#endif
 #ifndef BSP_TILE_PRIO
 #define BSP_TILE_PRIO 2  // s_setprio of the chain launches' tile workgroups (the potrf / trsm ones: 3)
 #endif
@@ -1867,13 +1870,13 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
 #pragma unroll
     for (int it = 0; it < NI; it++) {
       __builtin_amdgcn_global_load_lds((GV)(srcA[it] + kBase), (LV)(As + RPI * (4 * it + wave) * KC),
-                                       16, 0, 0);
+                                       16, 0, BSP_BULK_AUX);
     }
     if (!diagTile) {
 #pragma unroll
       for (int it = 0; it < NI; it++) {
         __builtin_amdgcn_global_load_lds((GV)(srcB[it] + kBase),
-                                         (LV)(Bs + RPI * (4 * it + wave) * KC), 16, 0, 0);
+                                         (LV)(Bs + RPI * (4 * it + wave) * KC), 16, 0, BSP_BULK_AUX);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -253,23 +253,67 @@ __global__ __launch_bounds__(256) void solveElimLumpsLt(const SolveLumpDesc* des
   GP<T> vec = solveVec(ref);
   const bool kOk = k < n;
   T acc = T(0);
-  for (int e = ld.blockBegin; e < ld.blockEnd; e++) {
-    const SolveLumpBlock b = blocks[e];
-    for (int i0 = 0; i0 < b.rows; i0 += 8) {
-      const int ia = i0 + ip, ib = i0 + 4 + ip;
-      const bool oa = kOk && ia < b.rows, ob = kOk && ib < b.rows;
-      const T va = oa ? data[b.dataOff + ia * n + k] : T(0);
-      const T vb = ob ? data[b.dataOff + ib * n + k] : T(0);
-      const T ya = oa ? vec[b.yOff + ia] : T(0);
-      const T yb = ob ? vec[b.yOff + ib] : T(0);
-      acc += va * ya + vb * yb;
+  const int grp = lane & 48;
+  // Round 3: PMC says this kernel is bound by the texture addresser (12.1 M wave loads per call on
+  // BAL-871, TA busy 76 %, ~22 cycles per wave load whatever it fetches), so it issues fewer of
+  // them.  The group's block descriptors come with ONE load (lane e takes block e, 16 per pass) and
+  // travel by shuffle; a block of at most 32 values and 16 rows (the 9 x 3 blocks of bundle
+  // adjustment) is two loads -- lane s takes elements s and s + 16 -- plus one for its y values
+  // (lane s = row s), instead of four + four behind a dependent descriptor load.  Element e = (row e
+  // / n, column e % n): its y comes from lane e / n of the group, its product goes to column e % n.
+  const int nBlocks = ld.blockEnd - ld.blockBegin;
+  T c0 = T(0), c1 = T(0);  // products of the lane's elements s and s + 16
+  bool allFast = true;
+  for (int b0 = 0; b0 < nBlocks; b0 += 16) {
+    const bool hasB = b0 + sub < nBlocks;
+    const SolveLumpBlock myB = blocks[ld.blockBegin + (hasB ? b0 + sub : 0)];
+    const bool fastB = !hasB || (myB.rows <= 16 && myB.rows * n <= 32);
+    // (a vote among the 16 lanes of the group: the groups of a wave run different trip counts, and
+    //  the lanes of a group past the last lump have left the kernel)
+    const unsigned long long slow = __ballot(!fastB);
+    allFast = allFast && ((slow >> grp) & 0xffffull) == 0;
+    if (!allFast) break;
+    const int passB = min(16, nBlocks - b0);
+    for (int e = 0; e < passB; e++) {
+      const int64_t off = (int64_t)__shfl((int)(myB.dataOff >> 32), grp + e, 64) << 32 |
+                          (uint32_t)__shfl((int)(uint32_t)myB.dataOff, grp + e, 64);
+      const int yOff = __shfl(myB.yOff, grp + e, 64), rows = __shfl(myB.rows, grp + e, 64);
+      const int ne = rows * n;
+      const T v0 = sub < ne ? data[off + sub] : T(0);
+      const T v1 = sub + 16 < ne ? data[off + sub + 16] : T(0);
+      const T yv = sub < rows ? vec[yOff + sub] : T(0);
+      c0 += v0 * __shfl(yv, grp + sub / n, 64);
+      c1 += v1 * __shfl(yv, grp + min(15, (sub + 16) / n), 64);
+    }
+  }
+  if (allFast) {
+    // column k of the sum: the lanes whose element index is k modulo n
+    T colSum = T(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; s2++) {
+      const T p0 = __shfl(c0, grp + s2, 64), p1 = __shfl(c1, grp + s2, 64);
+      colSum += (s2 % n == k ? p0 : T(0)) + ((s2 + 16) % n == k ? p1 : T(0));
+    }
+    acc = T(0.25) * colSum;  // (the reduction below adds the four lanes ip = 0..3 of a column)
+  } else {
+    acc = T(0);
+    for (int e = ld.blockBegin; e < ld.blockEnd; e++) {
+      const SolveLumpBlock b = blocks[e];
+      for (int i0 = 0; i0 < b.rows; i0 += 8) {
+        const int ia = i0 + ip, ib = i0 + 4 + ip;
+        const bool oa = kOk && ia < b.rows, ob = kOk && ib < b.rows;
+        const T va = oa ? data[b.dataOff + ia * n + k] : T(0);
+        const T vb = ob ? data[b.dataOff + ib * n + k] : T(0);
+        const T ya = oa ? vec[b.yOff + ia] : T(0);
+        const T yb = ob ? vec[b.yOff + ib] : T(0);
+        acc += va * ya + vb * yb;
+      }
     }
   }
   acc += __shfl_xor(acc, 4, 64);
   acc += __shfl_xor(acc, 8, 64);  // every lane: the sum for its column k
   // back substitution with the upper triangle L^T, redundantly in every lane of the group
   T x[4], d[4][4];
-  const int grp = lane & 48;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const T xj = j < n ? vec[ld.xOff + j] : T(0);
@@ -287,6 +331,13 @@ __global__ __launch_bounds__(256) void solveElimLumpsLt(const SolveLumpDesc* des
   if (ip == 0 && kOk) vec[ld.xOff + k] = k == 0 ? x[0] : k == 1 ? x[1] : k == 2 ? x[2] : x[3];
 }
 
+// (round 3, tried and removed: K-S3 with the wave's four columns staged through LDS like the factor's
+//  K1s.  PMC says K-S3 is texture-addresser bound -- 12.1 M wave loads per call, TA 76 % busy, 561 us
+//  on BAL-871 -- but three staged variants were all SLOWER: blocks walked by the (k, ip) lanes with y
+//  from global memory 859 us; a lane per block with its y values prefetched 691 us (64 scattered
+//  8-byte gathers per instruction: L1 stalled on pending misses 65 % of the time); lane = row of the
+//  block, y read as one contiguous piece per block, 775 us -- 32 KB of LDS per workgroup leaves 20
+//  waves per CU for a loop whose every iteration is a dependent shuffle + load + LDS read.)
 // ---- dense panels ----------------------------------------------------------------------------
 // triangular solve with the nb x nb diagonal block of a panel, one workgroup per panel: 256
 // threads stage L (batched, coalesced loads), then wave 0 solves with x_i in lane i and the
@@ -534,6 +585,145 @@ __global__ __launch_bounds__(256) void solveTriBlock(PanelDesc first, int w, Sol
       __syncthreads();
       triSolve64<T, true>(Ls, xs + c, nb);
       __syncthreads();
+    }
+  }
+  if (tid < w) x[tid] = xs[tid];
+}
+
+// ---- round 3: the block's triangle through INVERTED 64 x 64 diagonal blocks ------------------------
+// K-B1 spends ~20 us per 256 columns: per panel a global round trip for the triangle, a 64-step
+// dependent chain on ONE wave (triSolve64, ~1.8 us), and another round trip for the rows of the block
+// below the panel -- eight dependent round trips and four serial chains per block, 62 blocks per
+// solve of BAL-871 (1.25 of the 2.95 ms).  Prefetching around the unrolled chain was tried in round
+// 2 and lost to register pressure.  Here the chains leave the block kernel altogether:
+//   K-B0 (one launch per solve call, one wave per panel of every block group): the inverse of the
+//        panel's nb x nb diagonal block of L, lane t = column t by forward substitution in
+//        registers, stored row-major (64 x 64 slot, identity-padded);
+//   K-B1i: left-looking over the block's panels with everything -- the block's strictly lower 64 x 64
+//        tiles and the four inverses, 320 KB -- requested up front (one round trip):
+//        x_q = Inv_q (y_q - sum_{p<q} L_qp x_p); both products are row sums over 64 lanes
+//        (waveSum16), two barriers per panel.  Backward: x_q = Inv_q^T (y_q - sum_{p>q} L_pq^T x_p),
+//        column sums per lane + a cross-wave reduction.
+// The solve through explicitly inverted diagonal blocks is the standard GPU formulation (as the
+// factor's trsm already does with 16 x 16 blocks): its error grows with the condition number of a
+// 64 x 64 diagonal block of L, not with that of the matrix.
+template <typename T>
+__global__ __launch_bounds__(64) void solveInvertPanels(const PanelDesc* list, T* invOut,
+                                                        int64_t batchStride, SolveRef<T> ref) {
+  constexpr int NB = kPanelWidth, LD = NB + 1;
+  __shared__ T Ls[NB * LD];
+  const PanelDesc pd = list[blockIdx.x];
+  const int t = threadIdx.x, nb = pd.nb, lda = pd.lda;
+  GP<const T> A = solveMat(ref) + pd.diagOff;
+  T y[NB];
+  {  // row i: lanes = columns; all 64 loads in flight before the first LDS store
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      y[i] = A[(int64_t)min(i, nb - 1) * lda + min(t, min(i, nb - 1))];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      Ls[i * LD + t] = (i < nb && t <= i) ? y[i] : (i == t ? T(1) : T(0));
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  // (1 / L_jj once per lane, handed round with readlane: no division inside the chain)
+  const T myInvD = T(1) / Ls[t * LD + t];
+#pragma unroll
+  for (int i = 0; i < NB; i++) y[i] = i == t ? T(1) : T(0);
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    y[j] *= readLaneT(myInvD, j);
+#pragma unroll
+    for (int i = j + 1; i < NB; i++) y[i] -= Ls[i * LD + j] * y[j];
+  }
+  GP<T> out = (GP<T>)invOut + (int64_t)blockIdx.z * batchStride + (int64_t)blockIdx.x * NB * NB;
+#pragma unroll
+  for (int i = 0; i < NB; i++) out[i * NB + t] = y[i];  // Inv[i][t]
+}
+
+template <typename T, bool BACKWARD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void solveTriBlockInv(
+    PanelDesc first, int w, const T* invBase, int64_t batchStride, SolveRef<T> ref) {
+  constexpr int NB = kPanelWidth, NQ = kSolveBlock / NB;
+  __shared__ T xs[kSolveBlock];
+  __shared__ T ts[NB];
+  __shared__ T part[4][NB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lda = first.lda;
+  GP<const T> A = solveMat(ref) + first.diagOff;  // (c0, c0) of the block
+  GP<const T> inv = (GP<const T>)invBase + (int64_t)blockIdx.z * batchStride;
+  GP<T> x = solveVec(ref) + first.vecOff;
+  const int nq = (w + NB - 1) / NB;
+  // everything the block needs, requested before the first use: tile (q, p) of the block's strict
+  // lower part, rows 16 wv .. 16 wv + 15 of it (lane = column), and the same rows of Inv_q
+  T Lt[NQ * (NQ - 1) / 2][16], Iv[NQ][16];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      Iv[q][u] = q < nq ? inv[(int64_t)q * NB * NB + (16 * wv + u) * NB + lane] : T(0);
+    }
+#pragma unroll
+    for (int p = 0; p < q; p++) {
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int r = NB * q + 16 * wv + u;
+        Lt[q * (q - 1) / 2 + p][u] = r < w ? A[(int64_t)r * lda + NB * p + lane] : T(0);
+      }
+    }
+  }
+  if (tid < kSolveBlock) xs[tid] = tid < w ? x[tid] : T(0);
+  __syncthreads();
+  const int ur = (lane >> 2) & 15;
+  if (!BACKWARD) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      if (q < nq) {
+        T v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = T(0);
+#pragma unroll
+        for (int p = 0; p < q; p++) {
+          const T xp = xs[NB * p + lane];
+#pragma unroll
+          for (int u = 0; u < 16; u++) v[u] += Lt[q * (q - 1) / 2 + p][u] * xp;
+        }
+        const T s = waveSum16(v, lane);
+        if ((lane & 3) == 0) ts[16 * wv + ur] = xs[NB * q + 16 * wv + ur] - s;
+        __syncthreads();
+        const T tq = ts[lane];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = Iv[q][u] * tq;
+        const T xq = waveSum16(v, lane);
+        if ((lane & 3) == 0) xs[NB * q + 16 * wv + ur] = xq;
+        __syncthreads();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = NQ - 1; q >= 0; q--) {
+      if (q < nq) {
+        // t_q[c] = y_q[c] - sum over the tiles (p, q), p > q, of L[row][c] x[row]; lane = c
+        T acc = T(0);
+#pragma unroll
+        for (int p = q + 1; p < NQ; p++) {
+#pragma unroll
+          for (int u = 0; u < 16; u++) acc += Lt[p * (p - 1) / 2 + q][u] * xs[NB * p + 16 * wv + u];
+        }
+        part[wv][lane] = acc;
+        __syncthreads();
+        if (wv == 0) ts[lane] = xs[NB * q + lane] - (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+        __syncthreads();
+        // x_q[c] = sum_r Inv_q[r][c] t_q[r]
+        acc = T(0);
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc += Iv[q][u] * ts[16 * wv + u];
+        part[wv][lane] = acc;
+        __syncthreads();
+        if (wv == 0) xs[NB * q + lane] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        __syncthreads();
+      }
     }
   }
   if (tid < w) x[tid] = xs[tid];

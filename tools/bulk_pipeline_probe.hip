@@ -174,6 +174,102 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 struct Result { double tf; float ms; };
+// W2: one workgroup = 64 rows x 128 columns (two column tiles of one row tile): the row operand is
+// loaded once for both, 48 KB of LDS (2 workgroups per CU beside a chain workgroup, or 3 without)
+template <int KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void bulkWide(
+    const Task* tasks, int nTasks, double* data, int lda) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int OPA = 64 * KC, OPB = 128 * KC;
+  constexpr int RPL = 32 / KC;
+  constexpr int IPWA = (OPA / 32) / 16, IPWB = (OPB / 32) / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+  GPm D = (GPm)data;
+  const int cur = blockIdx.x;
+  if (2 * cur >= nTasks) return;
+  const Task t = tasks[2 * cur];  // (column tiles 2 cur and 2 cur + 1 of the row-major list: neighbours)
+  const long long itStride = (long long)16 * RPL * lda;
+  const int line = 4 * wave + (lane >> 4);
+  const int slot = (lane & 15) ^ (line & 15);
+  const int e = 2 * slot, r = line * RPL + e / KC, k = e % KC;
+  GPc srcA = (GPc)D + t.srcOff + (long long)(t.rowTile + r) * lda + k;
+  GPc srcB = (GPc)D + t.srcOff + (long long)(t.colTile + r) * lda + k;
+  double* As = lds;
+  double* Bs = lds + OPA;
+  d4 c[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) c[i][j] = d4{0, 0, 0, 0};
+  const int nChunks = t.K / KC;
+  for (int ch = 0; ch < nChunks; ch++) {
+    if (ch > 0) __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IPWA; it++)
+      __builtin_amdgcn_global_load_lds((GV)(srcA + it * itStride + ch * KC), (LV)(As + 128 * (4 * it + wave)), 16, 0, 0);
+#pragma unroll
+    for (int it = 0; it < IPWB; it++)
+      __builtin_amdgcn_global_load_lds((GV)(srcB + it * itStride + ch * KC), (LV)(Bs + 128 * (4 * it + wave)), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < KC; k0 += 4) {
+      int ra = wr + li, rb = wc + li;
+      asm volatile("" : "+v"(ra), "+v"(rb));
+      const double a0 = As[Lay<KC>::at(ra, k0 + lk)], a1 = As[Lay<KC>::at(ra + 16, k0 + lk)];
+      double b[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = Bs[Lay<KC>::at(rb + 16 * j, k0 + lk)];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        c[0][j] = MFMA(a0, b[j], c[0][j]);
+        c[1][j] = MFMA(a1, b[j], c[1][j]);
+      }
+    }
+  }
+  GPm tgt = D + t.tgtOff;
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    double old[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int qr = t.rowTile + wr + half * 16 + lk + 4 * reg, qc = t.colTile + wc + q * 16 + li;
+        old[4 * q + reg] = tgt[(long long)qr * lda + qc];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int qr = t.rowTile + wr + half * 16 + lk + 4 * reg, qc = t.colTile + wc + q * 16 + li;
+        tgt[(long long)qr * lda + qc] = old[4 * q + reg] - c[half][q][reg] * 1e-9;
+      }
+    }
+  }
+}
+
+template <int KC>
+Result runWide(const Task* dTasks, int nTasks, double* data, int lda, int wgPerCu, int K) {
+  const size_t need = (size_t)(64 + 128) * KC * 8;
+  size_t smem = (160 * 1024) / wgPerCu - 1024;
+  if (smem < need) smem = need;
+  hipFuncSetAttribute((const void*)bulkWide<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 150000);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; rep++) {
+    hipEventRecord(e0);
+    bulkWide<KC><<<nTasks / 2, 256, smem>>>(dTasks, nTasks, data, lda);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  return {double(nTasks / 2 * 2) * 64 * 64 * K * 2 / (best * 1e-3) / 1e12, best};
+}
+
+
 template <int KC, int NBUF, bool PERSIST>
 Result run(const Task* dTasks, int nTasks, double* data, int lda, int* ticket, int wgPerCu, int K) {
   const size_t need = (size_t)NBUF * 2 * 64 * KC * 8;
@@ -233,6 +329,49 @@ int main(int argc, char** argv) {
     }
     return p;
   };
+  // pairs of neighbouring column tiles for the 64 x 128 variant: full rows only, XCD-contiguous by pair
+  auto makeTasksWide = [&](int nTiles) {
+    std::vector<Task> v;
+    const int b = 2;
+    for (int c = b + 2; (int)v.size() < nTiles && c < 30; c++) {
+      const int col0 = 256 * c;
+      for (int rt = col0 + 192; rt + 64 <= n - 31 && (int)v.size() + 4 <= nTiles; rt += 64) {
+        for (int ct = 0; ct < 4; ct++) {
+          Task t;
+          const int base = 256 * (b + 1);
+          t.srcOff = (long long)base * lda + 256 * b;
+          t.tgtOff = (long long)base * lda + base;
+          t.rowTile = rt - base; t.colTile = col0 + 64 * ct - base; t.K = K; t.pad = 0;
+          v.push_back(t);
+        }
+      }
+    }
+    const int np = (int)v.size() / 2, bs = np >> 3, ex = np & 7;
+    std::vector<Task> p(v.size());
+    for (int i = 0; i < np; i++) {
+      const int x = i & 7;
+      int idx = x * bs + (x < ex ? x : ex) + (i >> 3);
+      if (idx >= np) idx = i;
+      p[2 * i] = v[2 * idx];
+      p[2 * i + 1] = v[2 * idx + 1];
+    }
+    return p;
+  };
+  printf("%-10s%9s%9s%9s%9s\n", "tiles", "S1@3", "W2@3", "W2@2", "W2k16@3");
+  for (int nt : {768, 1536, 2304, 3072, 6144}) {
+    auto host = makeTasksWide(nt);
+    const int nTasks = (int)host.size();
+    Task* dT; hipMalloc(&dT, nTasks * sizeof(Task));
+    hipMemcpy(dT, host.data(), nTasks * sizeof(Task), hipMemcpyHostToDevice);
+    Result a = run<32, 1, false>(dT, nTasks, data, lda, ticket, 3, K);
+    Result w3 = runWide<32>(dT, nTasks, data, lda, 3, K);
+    Result w2 = runWide<32>(dT, nTasks, data, lda, 2, K);
+    Result w16 = runWide<16>(dT, nTasks, data, lda, 3, K);
+    printf("%-10d%9.1f%9.1f%9.1f%9.1f   TF/s\n%-10s%9.1f%9.1f%9.1f%9.1f   us\n", nTasks, a.tf, w3.tf, w2.tf, w16.tf, "",
+           a.ms * 1e3, w3.ms * 1e3, w2.ms * 1e3, w16.ms * 1e3);
+    hipFree(dT);
+  }
+  if (argc > 1) return 0;   // (any argument: the wide-tile table only)
   const int sizes[] = {768, 1536, 1900, 2304, 3072, 6144};
   printf("%-10s", "tiles");
   const char* names[] = {"S1@3", "S1@4", "D32@2", "D16@3", "D16@4", "T16@3", "PS1@3", "PD32@2", "PD16@3", "PD16@4", "PT16@3"};
