@@ -191,6 +191,9 @@ __global__ __launch_bounds__(256) void solveElimGatherL(const SolveGatherItem* i
                             (uint32_t)__builtin_amdgcn_readlane(offLo, t);
         const int xo = __builtin_amdgcn_readlane(en.xOff, t);
         const int n = __builtin_amdgcn_readlane(en.n, t);
+        // (round 3, tried: x_lump fetched by lanes (15, k) of the SAME wave load as B and shuffled to
+        //  lanes (0, k) -- one load per block instead of two in a kernel whose texture addresser is 90 %
+        //  busy -- measured 297 against 247 us: the two-region load costs more than it saves)
         const bool okA = li < it.rows && lk < n, okB = li == 0 && lk < n;
         a[u] = okA ? data[off + li * n + lk] : T(0);
         b[u] = okB ? vec[xo + lk] : T(0);
