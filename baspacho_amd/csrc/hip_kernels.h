@@ -1407,21 +1407,60 @@ __device__ __forceinline__ void trsmTileMfma(GP<const T> A, GP<T> P, int lda, in
   GP<T> row = P + (int64_t)(active ? 16 * w + n : 0) * lda;
   using Acc = typename Mfma<T>::Acc;
   Acc x[4];
-  T v[16];
+  // (round 3: two values per lane and load where the panel is at least two columns wide -- on the
+  //  batched GRID workload the texture addresser is busy 72 % of this kernel, ~22 cycles per wave
+  //  load whatever it fetches; rows are only sizeof(T)-aligned, the pair type says so)
+  typedef T TV2 __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+  typedef __attribute__((address_space(1))) const TV2* GP2;
+  if (nb >= 4) {
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < 4; j++) {
+      const int c = 16 * j + 4 * q;
+      if (c + 3 < nb) {
+        const TV2 lo = *(GP2)(row + c), hi = *(GP2)(row + c + 2);
+        x[j][0] = lo.x;
+        x[j][1] = lo.y;
+        x[j][2] = hi.x;
+        x[j][3] = hi.y;
+      } else {
 #pragma unroll
-    for (int r = 0; r < 4; r++) x[j][r] = row[min(16 * j + 4 * q + r, nb - 1)];
-  }
+        for (int r = 0; r < 4; r++) x[j][r] = row[min(c + r, nb - 1)];
+      }
+    }
+    // L: lane -> (row tid / 32 + 8 it, columns 2 (tid % 32) and + 1); the strictly upper entries of
+    // the square diagonal block are stored too (unspecified values, masked below)
+    TV2 v2[8];
+    const int jj = 2 * (tid & 31), jc = min(jj, nb - 2);
 #pragma unroll
-  for (int it = 0; it < 16; it++) {
-    const int e = tid + 256 * it, i = min(e / N, nb - 1), jj = e % N;
-    v[it] = A[(int64_t)i * lda + min(jj, i)];
-  }
+    for (int it = 0; it < 8; it++) {
+      const int i = min((tid >> 5) + 8 * it, nb - 1);
+      v2[it] = *(GP2)(A + (int64_t)i * lda + jc);
+    }
+    const bool sh = jj > nb - 2;  // (pair clamped back by one: column jj is its second value)
 #pragma unroll
-  for (int it = 0; it < 16; it++) {
-    const int e = tid + 256 * it, i = e / N, jj = e % N;
-    Ls[i * LDT + jj] = (i < nb && jj <= i) ? v[it] : ((i >= nb && i == jj) ? T(1) : T(0));
+    for (int it = 0; it < 8; it++) {
+      const int i = (tid >> 5) + 8 * it;
+      const T e0 = sh ? v2[it].y : v2[it].x, e1 = v2[it].y;
+      Ls[i * LDT + jj] = (i < nb && jj <= i) ? e0 : ((i >= nb && i == jj) ? T(1) : T(0));
+      Ls[i * LDT + jj + 1] = (i < nb && jj + 1 <= i && jj + 1 < nb) ? e1 : ((i >= nb && i == jj + 1) ? T(1) : T(0));
+    }
+  } else {
+    T v[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) x[j][r] = row[min(16 * j + 4 * q + r, nb - 1)];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int e = tid + 256 * it, i = min(e / N, nb - 1), jj = e % N;
+      v[it] = A[(int64_t)i * lda + min(jj, i)];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int e = tid + 256 * it, i = e / N, jj = e % N;
+      Ls[i * LDT + jj] = (i < nb && jj <= i) ? v[it] : ((i >= nb && i == jj) ? T(1) : T(0));
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -1457,12 +1496,18 @@ __device__ __forceinline__ void trsmTileMfma(GP<const T> A, GP<T> P, int lda, in
       x[j] = y;
     }
   }
+  typedef __attribute__((address_space(1))) TV2* GP2w;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
+    const int c = 16 * j + 4 * q;
+    if (active && c + 3 < nb) {
+      *(GP2w)(row + c) = TV2{x[j][0], x[j][1]};
+      *(GP2w)(row + c + 2) = TV2{x[j][2], x[j][3]};
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int col = 16 * j + 4 * q + r;
-      if (active && col < nb) row[col] = x[j][r];
+      for (int r = 0; r < 4; r++) {
+        if (active && c + r < nb) row[c + r] = x[j][r];
+      }
     }
   }
 }
@@ -1686,23 +1731,40 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
   // K loop in chunks of KC source columns.  Staging map: k = tid % KC, rows (tid / KC) + (256/KC)*it;
   // all loads of a chunk are issued before the first LDS write (memory-level parallelism), then
   // every wave runs its 2x2 MFMA tiles over the chunk.
-  constexpr int RSTEP = 256 / KC, NIT = kTile / RSTEP;
-  const int sk = tid % KC, sr = tid / KC;
-  // the next chunk is fetched (into registers) while the current one is multiplied: a chunk's
-  // loads miss L2 four times out of ten beside the other tiles and take microseconds
-  T va[NIT], vb[NIT];
+  // Round 3: TWO source columns per lane and load (PMC on the batched GRID workload: the texture
+  // addresser is busy 54 % of this kernel and ~22 cycles per wave load whatever it fetches, so the
+  // operands come with half as many loads).  Staging map: k = 2 (tid % 16) and k + 1, rows
+  // (tid / 16) + 16 it.  Rows are only 8-byte aligned: the pair type says so.  The pair (k, k + 1) is
+  // clamped into [0, K - 2] and sorted out when it is stored (a source of one column keeps the
+  // one-column map).
+  typedef T TV2 __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+  typedef __attribute__((address_space(1))) const TV2* GP2;
+  constexpr int RSTEP = 16, NIT = kTile / RSTEP;
+  const int sk = 2 * (tid % 16), sr = tid / 16;
+  const bool wide = K >= 2;
+  TV2 va[NIT], vb[NIT];
   auto fetch = [&](int kBase) {
-    const int kcl = min(kBase + sk, K - 1);
+    const int kcl = wide ? min(kBase + sk, K - 2) : 0;
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int qa = min(task.rowTile + sr + RSTEP * it, pd.rowsBelow - 1);
-      va[it] = P[(int64_t)qa * lda + kcl];
+      GP<const T> pa = P + (int64_t)qa * lda + kcl;
+      if (wide) {
+        va[it] = *(GP2)pa;
+      } else {
+        va[it] = TV2{*pa, T(0)};
+      }
     }
     if (!diagTile) {
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
         const int qb = min(task.colTile + sr + RSTEP * it, segEnd - 1);
-        vb[it] = P[(int64_t)qb * lda + kcl];
+        GP<const T> pb = P + (int64_t)qb * lda + kcl;
+        if (wide) {
+          vb[it] = *(GP2)pb;
+        } else {
+          vb[it] = TV2{*pb, T(0)};
+        }
       }
     }
   };
@@ -1716,16 +1778,24 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
     fetch(kBase);
 #endif
     if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
+    // element k of the chunk sits in .x of the loaded pair unless the pair was clamped back by one
+    // (k = K - 1 with K odd)
+    const bool shifted = wide && kBase + sk > K - 2;
+    const bool ok0 = sk < kc, ok1 = sk + 1 < kc;
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int r = sr + RSTEP * it;
-      As[r * LD + sk] = (sk < kc && task.rowTile + r < pd.rowsBelow) ? va[it] : T(0);
+      const bool rowOk = task.rowTile + r < pd.rowsBelow;
+      As[r * LD + sk] = (ok0 && rowOk) ? (shifted ? va[it].y : va[it].x) : T(0);
+      As[r * LD + sk + 1] = (ok1 && rowOk) ? va[it].y : T(0);
     }
     if (!diagTile) {
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
         const int r = sr + RSTEP * it;
-        Bs[r * LD + sk] = (sk < kc && task.colTile + r < segEnd) ? vb[it] : T(0);
+        const bool rowOk = task.colTile + r < segEnd;
+        Bs[r * LD + sk] = (ok0 && rowOk) ? (shifted ? vb[it].y : vb[it].x) : T(0);
+        Bs[r * LD + sk + 1] = (ok1 && rowOk) ? vb[it].y : T(0);
       }
     }
     __syncthreads();
