@@ -1675,7 +1675,7 @@ __global__ __launch_bounds__(256) void trsmPanelDirect(PanelDesc pd, DataRef<T> 
 // ------------------------------------------------------------------------------------------
 constexpr int kUpdChunk = 32;  // K chunk of updateTile: 2 x 64 x 34 doubles = 35 KB LDS -> 4 WG/CU
 template <typename T>
-__global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const SegDesc* segs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void updateTile(const SrcDesc* srcs, const SegDesc* segs,
                                                   const UpdTask* tasks, const int64_t* chainOffTab,
                                                   const int32_t* rowChain, const int32_t* rowLocal,
                                                   const int32_t* rowColOff, DataRef<T> dref,
@@ -1727,6 +1727,24 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
   Acc acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
   // a diagonal tile only needs sub-tiles on or below the diagonal
   const bool skipUpper = diagTile && wr < wc;
+  // Round 3: which of the wave's four 16 x 16 sub-tiles hold a wanted entry at all (wave-uniform).
+  // On block-sparse structures a quarter of the MFMA steps of whole 64 x 64 tiles only ever reach
+  // masked-off entries (ragged segment ends, rows under rowMin, the upper halves of diagonal tiles):
+  // GRID 82 x 82 runs 1.69 M steps per factor of which 1.28 M are wanted (BSP_PLAN_TILE_STATS=1).
+  // (Measured neutral on the batched GRID workload, 11.20 against 11.19 ms: its tiles live ~11 us
+  //  of which the matrix pipe accounts for 1-3 -- the rest is dependent memory round trips.)
+  bool live[4];
+  {
+    const int wrU = __builtin_amdgcn_readfirstlane(wr), wcU = __builtin_amdgcn_readfirstlane(wc);
+    const int rowLo = max(sd.rowMin, task.rowTile), rowHi = min(task.rowTile + kTile, pd.rowsBelow);
+    const int colHi = min(task.colTile + kTile, segEnd);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int r0 = task.rowTile + wrU + (t >> 1) * 16, c0 = task.colTile + wcU + (t & 1) * 16;
+      live[t] = max(r0, rowLo) < min(r0 + 16, rowHi) && c0 < colHi && min(r0 + 16, rowHi) - 1 >= c0;
+    }
+  }
+  const bool allLive = live[0] && live[1] && live[2] && live[3];
 
   // K loop in chunks of KC source columns.  Staging map: k = tid % KC, rows (tid / KC) + (256/KC)*it;
   // all loads of a chunk are issued before the first LDS write (memory-level parallelism), then
@@ -1768,15 +1786,10 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
       }
     }
   };
-#ifdef BSP_BULK_PREFETCH
-  fetch(0);
-#endif
   for (int kBase = 0; kBase < K; kBase += KC) {
     const int kc = min(KC, K - kBase);
     const int kPad = (kc + 3) & ~3;
-#ifndef BSP_BULK_PREFETCH
     fetch(kBase);
-#endif
     if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
     // element k of the chunk sits in .x of the loaded pair unless the pair was clamped back by one
     // (k = K - 1 with K odd)
@@ -1799,28 +1812,29 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
       }
     }
     __syncthreads();
-#ifdef BSP_BULK_PREFETCH
-    if (kBase + KC < K) fetch(kBase + KC);
-#endif
     if (!skipUpper) {
-      auto kstep = [&](int k0) __attribute__((always_inline)) {
-        const T a0 = As[(wr + li) * LD + k0 + lk];
-        const T a1 = As[(wr + 16 + li) * LD + k0 + lk];
-        const T b0 = Bt[(wc + li) * LD + k0 + lk];
-        const T b1 = Bt[(wc + 16 + li) * LD + k0 + lk];
-        acc00 = Mfma<T>::run(a0, b0, acc00);
-        acc01 = Mfma<T>::run(a0, b1, acc01);
-        acc10 = Mfma<T>::run(a1, b0, acc10);
-        acc11 = Mfma<T>::run(a1, b1, acc11);
-      };
-#ifdef BSP_BULK_UNROLL
-      if (kPad == KC) {
-#pragma unroll
-        for (int k0 = 0; k0 < KC; k0 += 4) kstep(k0);
-      } else
-#endif
-      {
-        for (int k0 = 0; k0 < kPad; k0 += 4) kstep(k0);
+      if (allLive) {
+        for (int k0 = 0; k0 < kPad; k0 += 4) {
+          const T a0 = As[(wr + li) * LD + k0 + lk];
+          const T a1 = As[(wr + 16 + li) * LD + k0 + lk];
+          const T b0 = Bt[(wc + li) * LD + k0 + lk];
+          const T b1 = Bt[(wc + 16 + li) * LD + k0 + lk];
+          acc00 = Mfma<T>::run(a0, b0, acc00);
+          acc01 = Mfma<T>::run(a0, b1, acc01);
+          acc10 = Mfma<T>::run(a1, b0, acc10);
+          acc11 = Mfma<T>::run(a1, b1, acc11);
+        }
+      } else {
+        for (int k0 = 0; k0 < kPad; k0 += 4) {
+          const T a0 = As[(wr + li) * LD + k0 + lk];
+          const T a1 = As[(wr + 16 + li) * LD + k0 + lk];
+          const T b0 = Bt[(wc + li) * LD + k0 + lk];
+          const T b1 = Bt[(wc + 16 + li) * LD + k0 + lk];
+          if (live[0]) acc00 = Mfma<T>::run(a0, b0, acc00);
+          if (live[1]) acc01 = Mfma<T>::run(a0, b1, acc01);
+          if (live[2]) acc10 = Mfma<T>::run(a1, b0, acc10);
+          if (live[3]) acc11 = Mfma<T>::run(a1, b1, acc11);
+        }
       }
     }
   }
@@ -1828,6 +1842,16 @@ __global__ __launch_bounds__(256) void updateTile(const SrcDesc* srcs, const Seg
     // Scatter.  Non-atomic targets: gather all 16 old values first (independent loads in
     // flight together), then subtract and store -- a read-modify-write per element would
     // serialise 16 memory round trips.
+    // Round 3, built and measured on the batched GRID workload, not kept:
+    //  * pair form (the lanes of a column pair swap one accumulator per two rows through DPP, each
+    //    then owns both columns of a row: one 16-byte read and write instead of two 8-byte ones,
+    //    wave-uniformly per sub-tile when every pair is adjacent in the target): 11.19 against
+    //    11.15 ms -- the instruction count of the read-modify-write is not the bound;
+    //  * old values requested BEFORE the K loop, or right after chunk 0 went to LDS (overlapping
+    //    one of the tile's dependent memory round trips with the operand fetch): 16 values held
+    //    across the loop do not fit the 128 registers of 4 waves per SIMD in fp64 (127-166
+    //    registers spilled; at 3 waves per SIMD and 168 registers it still spills);
+    //  * next chunk fetched during the multiplies (BSP_BULK_PREFETCH): 11.67 against 11.20 ms.
     const Acc* accs[4] = {&acc00, &acc01, &acc10, &acc11};
     GP<T> tbase = altTarget ? (GP<T>)altTarget + (int64_t)blockIdx.y * altStride : data;
     GP<T> ptr[16];

@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT
+for lib in "" $VARIANTS; do
+  export BSP_LIB_PATH=$GRAFT_REPO_ROOT/baspacho_amd/libbaspacho_amd$lib.so
+  echo "== lib '$lib'"
+  for w in "grid82 --batch 64" "grid82" "flat50k"; do
+    python bench.py --workload $w --no-extras --no-cpu-baseline --no-profile --steps 5 --warmup 2 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('%-20s %.3f ms  probe %.1e' % ('$w', d['ms_per_step'], d['residual_probe']))"
+  done
+  python bench.py --no-extras --no-cpu-baseline --steps 8 --warmup 2 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('bal871 %.3f ms' % d['ms_per_step'], d['solve1_ms'])"
+done

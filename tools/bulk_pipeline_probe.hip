@@ -47,7 +47,9 @@ struct Lay {
   }
 };
 
-template <int KC, int NBUF, bool PERSIST>
+// EPI: 0 read-modify-write after the K loop (the library), 1 store only (no old values: bound),
+//      2 no-return atomic adds, 3 old values requested BEFORE the last chunk's multiplies
+template <int KC, int NBUF, bool PERSIST, int EPI = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void bulk(const Task* tasks, int nTasks, double* data, int lda,
                                             int* ticket) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -98,13 +100,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int nxt = -1;
     if (PERSIST && tid == 0) nextTask = atomicAdd(ticket, 1);
     bool first = true;
+    double old[16];
     for (int c = 0; c < nChunks; c++) {
       const int buf = NBUF > 1 ? c % NBUF : 0;
       if (NBUF == 1) {
         if (c > 0) __syncthreads();
-        request(c * KC, 0);
+        if (EPI != 4 || c == 0) request(c * KC, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (EPI == 3 && c == nChunks - 1) {
+          GPm tg = D + t.tgtOff;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+              const int qr = t.rowTile + wr + (q >> 1) * 16 + lk + 4 * reg, qc = t.colTile + wc + (q & 1) * 16 + li;
+              old[4 * q + reg] = tg[(long long)qr * lda + qc];
+            }
+          }
+        }
       } else {
         // chunk c has landed when at most (NBUF - 2) chunks' worth of loads are still in flight;
         // the first wait of a tile (stores of the previous epilogue may be in flight) and the
@@ -128,7 +142,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         asm volatile("" : "+v"(ra), "+v"(rb));
         const double a0 = As[Lay<KC>::at(ra, k0 + lk)], a1 = As[Lay<KC>::at(ra + 16, k0 + lk)];
         const double b0 = Bs[Lay<KC>::at(rb, k0 + lk)], b1 = Bs[Lay<KC>::at(rb + 16, k0 + lk)];
-        c00 = MFMA(a0, b0, c00); c01 = MFMA(a0, b1, c01); c10 = MFMA(a1, b0, c10); c11 = MFMA(a1, b1, c11);
+        if (EPI == 5) {
+          c00[0] += a0 + b0; c01[0] += a1 + b1;
+        } else {
+          c00 = MFMA(a0, b0, c00); c01 = MFMA(a0, b1, c01); c10 = MFMA(a1, b0, c10); c11 = MFMA(a1, b1, c11);
+        }
       }
     }
     // epilogue: read-modify-write of the 64x64 target from accumulator layout
@@ -149,21 +167,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
     const d4* accs[4] = {&c00, &c01, &c10, &c11};
-    double old[16];
+    if (EPI == 2) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+      for (int q = 0; q < 4; q++) {
 #pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        const int qr = t.rowTile + wr + (q >> 1) * 16 + lk + 4 * reg, qc = t.colTile + wc + (q & 1) * 16 + li;
-        old[4 * q + reg] = tgt[(long long)qr * lda + qc];
+        for (int reg = 0; reg < 4; reg++) {
+          const int qr = t.rowTile + wr + (q >> 1) * 16 + lk + 4 * reg, qc = t.colTile + wc + (q & 1) * 16 + li;
+          unsafeAtomicAdd(data + t.tgtOff + (long long)qr * lda + qc, -(*accs[q])[reg] * 1e-9);
+        }
       }
-    }
+    } else {
+      if (EPI == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < 4; q++) {
 #pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        const int qr = t.rowTile + wr + (q >> 1) * 16 + lk + 4 * reg, qc = t.colTile + wc + (q & 1) * 16 + li;
-        tgt[(long long)qr * lda + qc] = old[4 * q + reg] - (*accs[q])[reg] * 1e-9;
+          for (int reg = 0; reg < 4; reg++) {
+            const int qr = t.rowTile + wr + (q >> 1) * 16 + lk + 4 * reg, qc = t.colTile + wc + (q & 1) * 16 + li;
+            old[4 * q + reg] = tgt[(long long)qr * lda + qc];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          const int qr = t.rowTile + wr + (q >> 1) * 16 + lk + 4 * reg, qc = t.colTile + wc + (q & 1) * 16 + li;
+          tgt[(long long)qr * lda + qc] = ((EPI == 1 || EPI >= 4) ? 0.0 : old[4 * q + reg]) - (*accs[q])[reg] * 1e-9;
+        }
       }
     }
     if (!PERSIST || !more) break;
@@ -270,20 +300,124 @@ Result runWide(const Task* dTasks, int nTasks, double* data, int lda, int wgPerC
 }
 
 
-template <int KC, int NBUF, bool PERSIST>
+// Q: one workgroup of 512 threads = 128 rows x 128 columns (2 x 2 tiles): 16 flops per operand byte
+// instead of 8; wave (wy, wx) owns 32 rows x 64 columns
+template <int KC, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void bulkQuad(
+    const Task* tasks, int nQuads, double* data, int lda) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int OP = 128 * KC;
+  constexpr int RPL = 32 / KC;
+  constexpr int IPW = (OP / 32) / 32;  // wave instructions per operand, chunk and wave (8 waves x 4 lines)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+  GPm D = (GPm)data;
+  const Task t = tasks[blockIdx.x];
+  const long long itStride = (long long)32 * RPL * lda;
+  const int line = 4 * wave + (lane >> 4);
+  const int slot = (lane & 15) ^ (line & 15);
+  const int e = 2 * slot, r = line * RPL + e / KC, k = e % KC;
+  GPc srcA = (GPc)D + t.srcOff + (long long)(t.rowTile + r) * lda + k;
+  GPc srcB = (GPc)D + t.srcOff + (long long)(t.colTile + r) * lda + k;
+  double* As = lds;
+  double* Bs = lds + OP;
+  d4 c[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) c[i][j] = d4{0, 0, 0, 0};
+  const int nChunks = t.K / KC;
+  GPm tgt = D + t.tgtOff;
+  for (int ch = 0; ch < nChunks; ch++) {
+    if (ch > 0) __syncthreads();
+    if (EPI != 4 || ch == 0)
+#pragma unroll
+    for (int it = 0; it < IPW; it++) {
+      __builtin_amdgcn_global_load_lds((GV)(srcA + it * itStride + ch * KC), (LV)(As + 128 * (8 * it + wave)), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((GV)(srcB + it * itStride + ch * KC), (LV)(Bs + 128 * (8 * it + wave)), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < KC; k0 += 4) {
+      int ra = wr + li, rb = wc + li;
+      asm volatile("" : "+v"(ra), "+v"(rb));
+      const double a0 = As[Lay<KC>::at(ra, k0 + lk)], a1 = As[Lay<KC>::at(ra + 16, k0 + lk)];
+      double b[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = Bs[Lay<KC>::at(rb + 16 * j, k0 + lk)];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (EPI == 5) {
+          c[0][j][0] += a0 + b[j]; c[1][j][0] += a1;
+        } else {
+          c[0][j] = MFMA(a0, b[j], c[0][j]);
+          c[1][j] = MFMA(a1, b[j], c[1][j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    double old[16];
+    if (EPI == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          const int qr = t.rowTile + wr + half * 16 + lk + 4 * reg, qc = t.colTile + wc + q * 16 + li;
+          old[4 * q + reg] = tgt[(long long)qr * lda + qc];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int qr = t.rowTile + wr + half * 16 + lk + 4 * reg, qc = t.colTile + wc + q * 16 + li;
+        if (EPI == 2) {
+          unsafeAtomicAdd(data + t.tgtOff + (long long)qr * lda + qc, -c[half][q][reg] * 1e-9);
+        } else {
+          tgt[(long long)qr * lda + qc] = ((EPI == 1 || EPI >= 4) ? 0.0 : old[4 * q + reg]) - c[half][q][reg] * 1e-9;
+        }
+      }
+    }
+  }
+}
+
+template <int KC, int EPI>
+Result runQuad(const Task* dQuads, int nQuads, double* data, int lda, int wgPerCu, int K) {
+  const size_t need = (size_t)(128 + 128) * KC * 8;
+  size_t smem = (160 * 1024) / wgPerCu - 1024;
+  if (smem < need) smem = need;
+  hipFuncSetAttribute((const void*)bulkQuad<KC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 150000);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; rep++) {
+    hipEventRecord(e0);
+    bulkQuad<KC, EPI><<<nQuads, 512, smem>>>(dQuads, nQuads, data, lda);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  return {double(nQuads) * 128 * 128 * K * 2 / (best * 1e-3) / 1e12, best};
+}
+
+
+template <int KC, int NBUF, bool PERSIST, int EPI = 0>
 Result run(const Task* dTasks, int nTasks, double* data, int lda, int* ticket, int wgPerCu, int K) {
   const size_t need = (size_t)NBUF * 2 * 64 * KC * 8;
   // pad dynamic LDS so that exactly wgPerCu workgroups fit the 160 KB of a CU
   size_t smem = (160 * 1024) / wgPerCu - 1024;
   if (smem < need) smem = need;
-  hipFuncSetAttribute((const void*)bulk<KC, NBUF, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, 150000);
+  hipFuncSetAttribute((const void*)bulk<KC, NBUF, PERSIST, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 150000);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int grid = PERSIST ? (256 * wgPerCu < nTasks ? 256 * wgPerCu : nTasks) : nTasks;
   float best = 1e30f;
   for (int rep = 0; rep < 6; rep++) {
     hipMemsetAsync(ticket, 0, 4);
     hipEventRecord(e0);
-    bulk<KC, NBUF, PERSIST><<<grid, 256, smem>>>(dTasks, nTasks, data, lda, ticket);
+    bulk<KC, NBUF, PERSIST, EPI><<<grid, 256, smem>>>(dTasks, nTasks, data, lda, ticket);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (rep > 0 && ms < best) best = ms;
@@ -357,6 +491,62 @@ int main(int argc, char** argv) {
     }
     return p;
   };
+  if (argc > 1 && argv[1][0] == 'q') {
+    // quads (2 x 2 tiles) of full rows, XCD-contiguous; the same tiles as a plain list for S1
+    printf("%-10s%9s%9s%9s%9s%9s%9s%9s%9s\n", "tiles", "S1@3", "S1st@3", "S1nold@3", "S1nomm@3", "Q32@2", "Q32st@2", "Q32nold", "Q32nomm");
+    for (int nt : {768, 1536, 3072, 6144}) {
+      std::vector<Task> quads, tiles;
+      const int b = 2, base = 256 * (b + 1);
+      for (int c = b + 2; (int)tiles.size() < nt && c < 30; c++) {
+        const int col0 = 256 * c;
+        for (int rt = col0 + 256; rt + 128 <= n - 31 && (int)tiles.size() + 8 <= nt; rt += 128) {
+          for (int cq = 0; cq < 2; cq++) {
+            Task t;
+            t.srcOff = (long long)base * lda + 256 * b;
+            t.tgtOff = (long long)base * lda + base;
+            t.rowTile = rt - base; t.colTile = col0 + 128 * cq - base; t.K = K; t.pad = 0;
+            quads.push_back(t);
+            for (int dr = 0; dr < 2; dr++) for (int dc = 0; dc < 2; dc++) {
+              Task u = t; u.rowTile += 64 * dr; u.colTile += 64 * dc; tiles.push_back(u);
+            }
+          }
+        }
+      }
+      auto xcd = [](std::vector<Task>& v) {
+        std::vector<Task> p(v.size());
+        const int nn = (int)v.size(), bs = nn >> 3, ex = nn & 7;
+        for (int i = 0; i < nn; i++) {
+          const int x = i & 7;
+          int idx = x * bs + (x < ex ? x : ex) + (i >> 3);
+          if (idx >= nn) idx = i;
+          p[i] = v[idx];
+        }
+        v = p;
+      };
+      xcd(quads); xcd(tiles);
+      Task *dQ, *dT;
+      hipMalloc(&dQ, quads.size() * sizeof(Task)); hipMalloc(&dT, tiles.size() * sizeof(Task));
+      hipMemcpy(dQ, quads.data(), quads.size() * sizeof(Task), hipMemcpyHostToDevice);
+      hipMemcpy(dT, tiles.data(), tiles.size() * sizeof(Task), hipMemcpyHostToDevice);
+      const int nT = (int)tiles.size(), nQ = (int)quads.size();
+      Result r[8];
+      r[0] = run<32, 1, false, 0>(dT, nT, data, lda, ticket, 3, K);
+      r[1] = run<32, 1, false, 1>(dT, nT, data, lda, ticket, 3, K);
+      r[2] = run<32, 1, false, 4>(dT, nT, data, lda, ticket, 3, K);
+      r[3] = run<32, 1, false, 5>(dT, nT, data, lda, ticket, 3, K);
+      r[4] = runQuad<32, 0>(dQ, nQ, data, lda, 2, K);
+      r[5] = runQuad<32, 1>(dQ, nQ, data, lda, 2, K);
+      r[6] = runQuad<32, 4>(dQ, nQ, data, lda, 2, K);
+      r[7] = runQuad<32, 5>(dQ, nQ, data, lda, 2, K);
+      printf("%-10d", nT);
+      for (auto& x : r) printf("%9.1f", x.tf);
+      printf("   TF/s\n%-10s", "");
+      for (auto& x : r) printf("%9.1f", x.ms * 1e3);
+      printf("   us\n");
+      hipFree(dQ); hipFree(dT);
+    }
+    return 0;
+  }
   printf("%-10s%9s%9s%9s%9s\n", "tiles", "S1@3", "W2@3", "W2@2", "W2k16@3");
   for (int nt : {768, 1536, 2304, 3072, 6144}) {
     auto host = makeTasksWide(nt);
