@@ -349,6 +349,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_FUSE_POTRF")) fusePotrf = e[0] != '0';
     if (const char* e = std::getenv("BSP_BLOCK_SOLVE")) blockSolve = e[0] != '0';
     if (const char* e = std::getenv("BSP_SOLVE_INV")) solveInv = e[0] != '0';
+    if (const char* e = std::getenv("BSP_UPD_PREFETCH_WGS")) updPrefetchMaxWgs = std::atoll(e);
     if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_STAGED")) elimFactorStaged = e[0] != '0';
@@ -542,6 +543,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   };
   std::map<const void*, SolveInvList> solveInvLists;
   bool solveInv = true;  // BSP_SOLVE_INV=0: the substitution kernels of rounds 1-2
+  int64_t updPrefetchMaxWgs = 2048;  // updateTile<PREFETCH> for launches of up to this many workgroups (BSP_UPD_PREFETCH_WGS; -1: never)
   DevBuf elimPackBuf;  // packed copy of the solved blocks of a sparse-elimination range (BSP_ELIM_PACK=1)
   PtrRing ptrRing;
   bool rowFormAttrSet[2] = {false, false};  // elimRowMfma dynamic-LDS attribute (fp64, fp32)
@@ -583,7 +585,13 @@ struct HipNumericCtx : NumericCtx<T> {
                                 stream>>>(plan.updTasksFat.as<UpdTaskFat>() + begin, ref, yf, atomicMask);
       return;
     }
-    hipk::updateTile<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, extraLds, stream>>>(
+    // (launches of at most ~2 rounds of workgroups: the latency-bound variant, hip_kernels.h)
+    const int64_t wgs = (end - begin) * (int64_t)batchSize;
+    const bool few = sym.updPrefetchMaxWgs >= 0 && wgs <= sym.updPrefetchMaxWgs;
+    auto kern = few ? hipk::updateTile<BT, true> : hipk::updateTile<BT, false>;
+    // (Asking for enough dynamic LDS that only ceil(workgroups / CUs) of a small launch fit on a CU,
+    //  in case the dispatcher packs them four to a CU: no effect at batch 1 / 8 / 64 -- it does not.)
+    kern<<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, extraLds, stream>>>(
         plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(), plan.updTasks.as<UpdTask>() + begin,
         plan.chainOffTab.as<int64_t>(), plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(),
         plan.rowColOff.as<int32_t>(), ref, altTarget, altStride, atomicMask);
@@ -1833,7 +1841,7 @@ int hipBackendReadExtents(unsigned long long* out, int maxLaunches) {
 }
 
 int hipBackendReadTrace(long long* out, int maxRecords) {
-#ifdef BSP_KTRACE
+#if defined(BSP_KTRACE) || defined(BSP_TRACE_UPD)
   unsigned n = 0;
   hipCHECK(hipDeviceSynchronize());
   hipCHECK(hipMemcpyFromSymbol(&n, HIP_SYMBOL(hipk::bspTraceCount), sizeof n));

@@ -1057,13 +1057,16 @@ __global__ __launch_bounds__(256) void elimGatherTiny(const ElimGatherItem* item
 // workgroup per panel, whole block in LDS.  Replaces cusolverDn?potrf / potrfBatched
 // (MatOpsCuda.cu:508-548, 727-755) on the panel granularity.
 // ------------------------------------------------------------------------------------------
-#if defined(BSP_KTRACE)
-// in-situ trace build (build.sh with BSP_KTRACE=1): every launch of a stamped kernel appends one
-// record of 4 clock values; read back with hipBackendReadTrace()
+#if defined(BSP_KTRACE) || defined(BSP_TRACE_UPD)
+// in-situ trace builds (build.sh with BSP_KTRACE=1, or BSP_EXTRA_DEFS=-DBSP_TRACE_UPD for the
+// updateTile trace alone): every launch of a stamped kernel appends one record of clock values;
+// read back with hipBackendReadTrace()
 constexpr int kTraceW = 8;  // clock values per record (slots 0-3: kernel phases, 4-7: inside a potrf step)
 __device__ long long bspTrace[8192 * kTraceW];
 __device__ unsigned bspTraceCount;
 __shared__ unsigned bspTraceSlot;
+#endif
+#if defined(BSP_KTRACE)
 #ifdef BSP_TRACE_TILE
 #define BSP_STEP_STAMPS(slot) ((slot) < 4)
 #define BSP_CLOCK() wall_clock64()  // device-wide constant-rate counter (the shader clocks of
@@ -1673,9 +1676,26 @@ __global__ __launch_bounds__(256) void trsmPanelDirect(PanelDesc pd, DataRef<T> 
 //   * fp64: v_mfma_f64_16x16x4_f64, C layout col = lane&15, row = (lane>>4) + 4*reg
 //   * fp32: v_mfma_f32_16x16x4_f32, C layout col = lane&15, row = 4*(lane>>4) + reg
 // ------------------------------------------------------------------------------------------
+#if defined(BSP_TRACE_UPD)
+// in-situ trace of ONE workgroup (the middle one, first matrix) of every updateTile launch: wall
+// clock (100 MHz) at start / tables + first fetch issued / first chunk in LDS / K loop done / old
+// values arrived / end; slot 6 = K, slot 7 = -(workgroups of the launch) marks the record
+#define UPD_STAMP(slot, val)                                                            \
+  if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) {             \
+    if ((slot) == 0) bspTraceSlot = atomicAdd(&bspTraceCount, 1u) & 8191u;              \
+    bspTrace[bspTraceSlot * kTraceW + (slot)] = (val);                                  \
+  }
+#else
+#define UPD_STAMP(slot, val)
+#endif
 constexpr int kUpdChunk = 32;  // K chunk of updateTile: 2 x 64 x 34 doubles = 35 KB LDS -> 4 WG/CU
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void updateTile(const SrcDesc* srcs, const SegDesc* segs,
+// PREFETCH: the next K chunk is requested before the current one is multiplied.  For launches of
+// at most ~2 rounds of workgroups (small batches, the top of an elimination tree) a tile's time is
+// its chain of dependent memory round trips -- one per K chunk -- and this overlaps them with the
+// multiplies; in saturated launches the other workgroups of the CU already do, and the staging
+// registers held across the multiplies cost more than they bring (64 x GRID: 11.67 against 11.20 ms).
+template <typename T, bool PREFETCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 3 : 4, 4))) void updateTile(const SrcDesc* srcs, const SegDesc* segs,
                                                   const UpdTask* tasks, const int64_t* chainOffTab,
                                                   const int32_t* rowChain, const int32_t* rowLocal,
                                                   const int32_t* rowColOff, DataRef<T> dref,
@@ -1689,12 +1709,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   __shared__ int64_t rowBase[kTile];
   __shared__ int32_t colOff[kTile];
 
+  UPD_STAMP(0, (long long)wall_clock64());
   const UpdTask task = tasks[blockIdx.x];
   const SegDesc sd = segs[task.seg];
   const SrcDesc pd = srcs[sd.src];  // (named pd: rowsBelow / nRest / lumpRowBase as for a panel)
   GP<T> data = pickData(dref);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = pd.K, lda = pd.lda;
+  UPD_STAMP(6, (long long)K);
+  UPD_STAMP(7, -(long long)(gridDim.x * gridDim.y));
+  UPD_STAMP(1, (long long)wall_clock64());
   GP<const T> P = data + pd.off;  // first row below the source columns
   const bool diagTile = task.rowTile == task.colTile;
   const int segEnd = sd.q0 + sd.m;
@@ -1786,10 +1810,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
   };
+  if (PREFETCH) fetch(0);
   for (int kBase = 0; kBase < K; kBase += KC) {
     const int kc = min(KC, K - kBase);
     const int kPad = (kc + 3) & ~3;
-    fetch(kBase);
+    if (!PREFETCH) fetch(kBase);
     if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
     // element k of the chunk sits in .x of the loaded pair unless the pair was clamped back by one
     // (k = K - 1 with K odd)
@@ -1812,6 +1837,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
     __syncthreads();
+    if (kBase == 0) { UPD_STAMP(2, (long long)wall_clock64()); }
+    if (PREFETCH && kBase + KC < K) fetch(kBase + KC);
     if (!skipUpper) {
       if (allLive) {
         for (int k0 = 0; k0 < kPad; k0 += 4) {
@@ -1838,6 +1865,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
   }
+  UPD_STAMP(3, (long long)wall_clock64());
   if (!skipUpper) {
     // Scatter.  Non-atomic targets: gather all 16 old values first (independent loads in
     // flight together), then subtract and store -- a read-modify-write per element would
@@ -1851,7 +1879,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     //    one of the tile's dependent memory round trips with the operand fetch): 16 values held
     //    across the loop do not fit the 128 registers of 4 waves per SIMD in fp64 (127-166
     //    registers spilled; at 3 waves per SIMD and 168 registers it still spills);
-    //  * next chunk fetched during the multiplies (BSP_BULK_PREFETCH): 11.67 against 11.20 ms.
+    //  * next chunk fetched during the multiplies in EVERY launch: 11.67 against 11.20 ms (now the
+    //    PREFETCH variant, for launches of a few rounds only).
     const Acc* accs[4] = {&acc00, &acc01, &acc10, &acc11};
     GP<T> tbase = altTarget ? (GP<T>)altTarget + (int64_t)blockIdx.y * altStride : data;
     GP<T> ptr[16];
@@ -1882,6 +1911,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       T old[16];
 #pragma unroll
       for (int e = 0; e < 16; e++) old[e] = *ptr[e];  // masked-off entries point at valid memory
+#if defined(BSP_TRACE_UPD)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      UPD_STAMP(4, (long long)wall_clock64());
+#endif
 #pragma unroll
       for (int t = 0; t < 4; t++) {
 #pragma unroll
@@ -1891,6 +1924,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
   }
+#if defined(BSP_TRACE_UPD)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  UPD_STAMP(5, (long long)wall_clock64());
+#endif
 }
 
 // K5b  the bulk of the bulk: plain intra-lump tiles whose source width is a multiple of the K
