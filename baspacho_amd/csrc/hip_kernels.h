@@ -1081,7 +1081,7 @@ __shared__ unsigned bspTraceSlot;
 #define BSP_STAMP(slot)                                                        \
   if (threadIdx.x == ((slot) >= 4 ? BSP_TRACE_TID : 0) && blockIdx.x == 0 && BSP_STEP_STAMPS(slot)) { \
     if ((slot) == 0) bspTraceSlot = atomicAdd(&bspTraceCount, 1u) & 8191u;     \
-    bspTrace[bspTraceSlot * kTraceW + (slot)] = BSP_CLOCK();                   \
+    bspTrace[(bspTraceSlot & 8191u) * kTraceW + (slot)] = BSP_CLOCK();         \
   }
 // BSP_TRACE_TILE builds: per chain-step launch (ordinal passed by the host), the earliest / latest
 // start and the latest end over ALL its workgroups (wall clock), besides workgroup 0's record
@@ -1642,7 +1642,6 @@ template <typename T>
 __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const TrsmTask* tasks,
                                                  DataRef<T> dref) {
   __shared__ T lds[kTrsmLdsElems];
-  BSP_STAMP(4);
   const TrsmTask task = tasks[blockIdx.x];
   const PanelDesc pd = panels[task.panel];
   GP<T> data = pickData(dref);
@@ -1650,7 +1649,6 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
   GP<T> P = data + pd.diagOff + (int64_t)(nb + task.rowTile) * lda;
   const int rows = min(kTile, pd.rowsBelow - task.rowTile);
   trsmTileMfma<T>(data + pd.diagOff, P, lda, nb, rows, lds, lds + kPanelWidth * kTrsmLd);
-  BSP_STAMP(6);
 }
 
 template <typename T>
