@@ -1352,14 +1352,257 @@ __device__ __forceinline__ void potrfTiles(GP<T> A, int nb, int lda, T (*blk)[4]
   }
 }
 
+// BLOCKED form of the panel potrf (round 3; BSP_POTRF_BLOCKED=0 at build time restores potrfTiles).
+// 16-column blocks, two LDS buffers of 64 rows x 16 columns that alternate between blocks.  Per block J:
+//   * ONE wave factors the whole block column in registers, lane = row (diagonal tile and the rows
+//     below alike): right-looking, pivot and multipliers broadcast with v_readlane -- the Cholesky
+//     of the diagonal tile and the solve of the rows below are the same 16 column steps, nothing
+//     waits for another wave inside them; the result goes back to the buffer.  MEANWHILE the other
+//     waves give the tiles right of the block column the PREVIOUS block's rank-16 update (four
+//     v_mfma 16x16x4 per tile, operands from the other buffer);                   -- barrier --
+//   * thread (row, 4-column group) stores the final entries of L; every wave applies this block's
+//     update to its tile of the NEXT block column only and copies it out of the accumulators
+//     into the other buffer.                                                       -- barrier --
+// 8 barriers per panel instead of 32, no redundant pivot factorizations, the matrix cores work
+// behind the serial path.  In situ (tools/trace_potrf.py): 26.9 k -> see DESIGN.md clocks per panel.
+// Same contract as potrfTiles (accumulator-layout input after `pre`, identity padding beyond nb,
+// Ld / dinvOut).  Buffer layout: row R, column c at R * 16 + (c ^ key(R)), key = 2 ((R / 2) % 8) --
+// the lane-per-row walk and the MFMA operand fetch are both (nearly) conflict-free without padding.
+#ifndef BSP_POTRF_BLOCKED
+#define BSP_POTRF_BLOCKED 1
+#endif
+__device__ __forceinline__ int potrfColbufAt(int R, int c) { return R * 16 + (c ^ (((R >> 1) & 7) << 1)); }
+
+// One wave factors a block column of 16 columns held one row per lane (rows R of buf, lanes beyond
+// the last row idle along on a copy of it): the Cholesky of the diagonal tile and the solve of the
+// rows below are the same right-looking column steps.  Per column j the serial path is: pivot
+// (v_readlane) -> 1/sqrt (hardware estimate + Newton) -> scale -> update of column j + 1.  The
+// instruction order is pinned so that everything else fills its latencies: the multipliers of
+// columns j + 3 .. 15 come back from LDS as broadcast reads of the column just written (one LDS
+// instruction instead of two v_readlane on the vector pipe), and their updates are issued between
+// the Newton steps of the NEXT column.
+template <typename T>
+struct RsqrtChain;
+template <>
+struct RsqrtChain<double> {
+  static constexpr int kOps = 6;
+};
+template <>
+struct RsqrtChain<float> {
+  static constexpr int kOps = 3;
+};
+__device__ __forceinline__ double rsqEstimate(double x) { return __builtin_amdgcn_rsq(x); }
+__device__ __forceinline__ float rsqEstimate(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// (orders two values' definitions for the compiler: whatever is computed from `b` afterwards cannot be
+//  moved in front of the computation of `a` -- the DAG linearisation ignores sched_barrier for
+//  plain arithmetic)
+template <typename T>
+__device__ __forceinline__ void orderAfter(const T& a, T& b) {
+  asm volatile("" : "+v"(b) : "v"(a));  // (`a` is only read: its own consumers do not wait for `b`)
+}
+
+template <typename T, int J>
+__device__ __forceinline__ void potrfBlockColumn(T* buf, int R) {
+  T a[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) a[c] = buf[potrfColbufAt(R, c)];
+  // multipliers that came back from LDS: column j's are requested at the end of step j and used
+  // between the Newton steps of column j + 2 (a full step of latency budget); columns j + 1 and
+  // j + 2 get column j's update straight away, through v_readlane.
+  // (A variant with the pivots as a recurrence on uniform values, d_{j+1} = p - u^2 / d_j, and all
+  //  vector work as filler one column behind was measured slower: 18.3 k against 16.9 k clocks per
+  //  panel -- three columns of v_readlane updates per step instead of two.)
+  T m[3][16];
+  auto column = [&](auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int src = j >= 2 ? j - 2 : 0;      // column whose LDS-fed updates are applied now
+    constexpr int nDef = j >= 2 ? 15 - (src + 3) + 1 : 0;  // columns src + 3 .. 15
+    constexpr int nOps = RsqrtChain<T>::kOps;
+    constexpr int perOp = nDef > 0 ? (nDef + nOps - 1) / nOps : 0;
+    const T d = readLaneT(a[j], j);  // pivot (16 J + j, 16 J + j): lane j
+    T y = rsqEstimate(d);
+    const T h = T(-0.5) * d;
+    T t = T(0);
+#pragma unroll
+    for (int op = 0; op < nOps; op++) {
+      switch (op % 3) {
+        case 0: t = h * y; break;
+        case 1: t = fma(t, y, T(0.5)); break;
+        default: y = fma(y, t, y); break;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        if (q >= op * perOp && q < (op + 1) * perOp && q < nDef) {
+          const int k = src + 3 + q;
+          orderAfter(op % 3 == 2 ? y : t, a[k]);
+          a[k] -= a[src] * m[src % 3][k];
+        }
+      }
+    }
+    a[j] *= y;  // lane j: the diagonal entry; lanes > j: the multipliers; lanes < j: unused
+    buf[potrfColbufAt(R, j)] = a[j];  // (every lane: clamped lanes rewrite the last row's value)
+    if constexpr (j + 1 < 16) a[j + 1] -= a[j] * readLaneT(a[j], j + 1);
+    if constexpr (j + 2 < 16) {
+      orderAfter(a[j + 1], a[j + 2]);
+      a[j + 2] -= a[j] * readLaneT(a[j], j + 2);
+    }
+#pragma unroll
+    for (int k = j + 3; k < 16; k++) m[j % 3][k] = buf[potrfColbufAt(16 * J + k, j)];
+  };
+  staticFor<0, 16>(column);
+}
+
+template <typename T, typename Pre = NoPreUpdate>
+__device__ __forceinline__ void potrfTilesBlocked(GP<T> A, int nb, int lda, T* colbuf0, T* colbuf1,
+                                                  Pre pre = Pre(), T* Ld = nullptr,
+                                                  GP<T> dinvOut = nullptr) {
+  constexpr int NT = 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int i = tid >> 2, g = tid & 3;
+  using Acc = typename Mfma<T>::Acc;
+  Acc acc[NT];
+#pragma unroll
+  for (int tj = 0; tj < NT; tj++) {
+    if (tj <= w) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * w + Mfma<T>::row(lane, r), col = 16 * tj + li;
+        const int rl = min(row, nb - 1);
+        const T v = A[(int64_t)rl * lda + min(col, rl)];
+        acc[tj][r] = (row < nb && col <= row) ? v : ((row >= nb && col == row) ? T(1) : T(0));
+      }
+    } else {
+      acc[tj] = Acc{0, 0, 0, 0};
+    }
+  }
+  pre(acc);
+  BSP_STAMP(1);
+  if (Ld) {  // identity beyond nb, zero above the diagonal; the blocks fill in the rest
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int col = 4 * g + c;
+      Ld[i * kInvLd + col] = (i >= nb && (i & 15) == col) ? T(1) : T(0);
+    }
+  }
+  // tile (w, TJ) of this wave -> buf
+  auto publish = [&](auto TJc, T* buf) __attribute__((always_inline)) {
+    constexpr int TJ = decltype(TJc)::value;
+#pragma unroll
+    for (int r = 0; r < 4; r++) buf[potrfColbufAt(16 * w + Mfma<T>::row(lane, r), li)] = acc[TJ][r];
+  };
+  // acc[c] -= X_w X_c^T for the tiles c = C0 .. NT-1 of this wave (c <= w), X = solved block column in buf
+  auto update = [&](int c0, int c1, const T* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4) {
+      const T xa = -buf[potrfColbufAt(16 * w + li, k0 + lk)];
+#pragma unroll
+      for (int tj = 0; tj < NT; tj++) {
+        if (tj >= c0 && tj <= c1 && tj <= w) {
+          acc[tj] = Mfma<T>::run(xa, buf[potrfColbufAt(16 * tj + li, k0 + lk)], acc[tj]);
+        }
+      }
+    }
+  };
+  publish(std::integral_constant<int, 0>{}, colbuf0);
+  ldsBarrier();
+  auto block = [&](auto Jc) __attribute__((always_inline)) {
+    constexpr int J = decltype(Jc)::value;
+    if (16 * J >= nb) return;  // (uniform: the rest is identity padding)
+    T* cur = (J & 1) ? colbuf1 : colbuf0;
+    T* other = (J & 1) ? colbuf0 : colbuf1;
+    if (J == 1) { BSP_STAMP(4); }
+    auto storePrev = [&](int item) __attribute__((always_inline)) {  // block J - 1, from `other`
+      const int row = 16 * (J - 1) + (item >> 2), g4 = item & 3;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int col = 16 * (J - 1) + 4 * g4 + c;
+        if (row < nb && col < nb && col <= row) {
+          const T v = other[potrfColbufAt(row, 4 * g4 + c)];
+          A[(int64_t)row * lda + col] = v;
+          if (Ld && (row >> 4) == J - 1) Ld[row * kInvLd + 4 * g4 + c] = v;
+        }
+      }
+    };
+    if (w == J) {
+      // wave J factors rows 16 J .. 63 of the block column, lane = row
+      const int R = min(16 * J + lane, 16 * NT - 1);
+      potrfBlockColumn<T, J>(cur, R);
+    } else if (J >= 1) {
+      // meanwhile: the previous block's update of the tiles right of the block column, and its
+      // final entries to memory (three waves, (64 - 16 (J - 1)) x 4 items)
+      if (w > J) update(J + 1, NT - 1, other);
+      const int idx = 64 * (w < J ? w : w - 1) + lane;
+      for (int item = idx; item < 4 * (16 * NT - 16 * (J - 1)); item += 192) storePrev(item);
+    }
+    if (J == 1) { BSP_STAMP(5); }
+    ldsBarrier();
+    if (J == 1) { BSP_STAMP(6); }
+    // Final entries to memory (and to Ld): thread (row, 4-column group).  Off the serial path: when
+    // a next block follows, the waves that do not factor it store while it is factored.
+    auto storeBlock = [&](int item) __attribute__((always_inline)) {
+      const int row = 16 * J + (item >> 2), g4 = item & 3;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int col = 16 * J + 4 * g4 + c;
+        if (row < nb && col < nb && col <= row) {
+          const T v = cur[potrfColbufAt(row, 4 * g4 + c)];
+          A[(int64_t)row * lda + col] = v;
+          if (Ld && (row >> 4) == J) Ld[row * kInvLd + 4 * g4 + c] = v;
+        }
+      }
+    };
+    const bool nextBlock = J + 1 < NT && 16 * (J + 1) < nb;
+    if (!nextBlock) {
+      if (i >= 16 * J) storeBlock(tid - 64 * J);
+    }
+    if constexpr (J + 1 < NT) {
+      if (16 * (J + 1) < nb) {
+        // the next block column gets this block's update and is published; the tiles right of it
+        // wait until the next block's factorization runs
+        if (w > J) {
+          update(J + 1, J + 1, cur);
+          publish(std::integral_constant<int, J + 1>{}, other);
+        }
+        ldsBarrier();
+      }
+    }
+    if (J == 1) { BSP_STAMP(7); }
+  };
+  staticFor<0, NT>(block);
+  BSP_STAMP(2);
+  if (Ld) {
+    ldsBarrier();
+    T y[16];
+    invertColumn16(Ld + 16 * w * kInvLd, kInvLd, li, y);
+    if (lane < 16) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) dinvOut[(16 * w + r) * 16 + li] = y[r];
+    }
+  }
+}
+
+// the panel potrf the kernels call: blk .. sol are 4 x 64 x 4 contiguous values, buf2 another 1024
+template <typename T, typename Pre = NoPreUpdate>
+__device__ __forceinline__ void potrfPanelTiles(GP<T> A, int nb, int lda, T (*blk)[4], T (*sol)[4],
+                                                T* buf2, Pre pre = Pre(), T* Ld = nullptr,
+                                                GP<T> dinvOut = nullptr) {
+#if BSP_POTRF_BLOCKED
+  potrfTilesBlocked<T, Pre>(A, nb, lda, &blk[0][0], buf2, pre, Ld, dinvOut);
+#else
+  potrfTiles<T, 4, Pre>(A, nb, lda, blk, sol, pre, Ld, dinvOut);
+#endif
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
                                                   const int32_t* levelPanels, DataRef<T> dref) {
-  __shared__ T blk[3 * kPanelWidth][4];
-  __shared__ T sol[kPanelWidth][4];
+  __shared__ T blk[8 * kPanelWidth][4];  // (ring of three column blocks + sol / the blocked form's two buffers)
+  T(*sol)[4] = blk + 3 * kPanelWidth;
   BSP_STAMP(0);
   const PanelDesc pd = panels[levelPanels[blockIdx.x]];
-  potrfTiles<T, 4>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, blk, sol);
+  potrfPanelTiles<T>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, blk, sol, &blk[4 * kPanelWidth][0]);
   BSP_STAMP(3);
 }
 
@@ -1372,12 +1615,12 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
 template <typename T>
 __global__ __launch_bounds__(256) void potrfPanelDirect(PanelDesc pd, DataRef<T> dref,
                                                         T* dinvOut) {
-  __shared__ T blk[3 * kPanelWidth][4];
-  __shared__ T sol[kPanelWidth][4];
+  __shared__ T blk[8 * kPanelWidth][4];
+  T(*sol)[4] = blk + 3 * kPanelWidth;
   __shared__ T Ld[kPanelWidth * kInvLd];
   __builtin_amdgcn_s_setprio(3);
   BSP_STAMP(0);
-  potrfTiles<T, 4>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, blk, sol, NoPreUpdate(), Ld,
+  potrfPanelTiles<T>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, blk, sol, &blk[4 * kPanelWidth][0], NoPreUpdate(), Ld,
                    (GP<T>)dinvOut + (size_t)blockIdx.y * kDinvBatchStride);
   BSP_STAMP(3);
 }
@@ -2315,8 +2558,9 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
     }
   };
   BSP_STAMP(0);
-  potrfTiles<T, 4>(data + next.diagOff, nb, next.lda, blk, sol, pre, Ld,
-                   (GP<T>)dinvOut + (size_t)blockIdx.y * kDinvBatchStride);
+  // (As is free once `pre` has run: the blocked form's second buffer)
+  potrfPanelTiles<T>(data + next.diagOff, nb, next.lda, blk, sol, As, pre, Ld,
+                     (GP<T>)dinvOut + (size_t)blockIdx.y * kDinvBatchStride);
   BSP_STAMP(3);
 }
 
@@ -2503,8 +2747,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       ldsBarrier();  // XB is about to become the potrf's blk / sol / Ld
     };
     BSP_STAMP(0);
-    potrfTiles<T, 4>(data + next.diagOff, next.nb, next.lda, blk, sol, pre, Ld,
-                     (GP<T>)dinvOutBase + (size_t)blockIdx.y * kDinvBatchStride);
+    static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd + 4 * kPanelWidth * 4 <= kTile * kXbLd, "second potrf buffer fits in XB");
+    potrfPanelTiles<T>(data + next.diagOff, next.nb, next.lda, blk, sol,
+                       XB + 4 * kPanelWidth * 4 + kPanelWidth * kInvLd, pre, Ld,
+                       (GP<T>)dinvOutBase + (size_t)blockIdx.y * kDinvBatchStride);
     yieldPublish(yieldFlag, 0u);
     BSP_STAMP(3);
     BSP_EXTENT_END(traceId, true);

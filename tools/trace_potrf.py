@@ -31,7 +31,9 @@ print("records", len(tr), "(clock units as clock64() counts them)")
 print("mean load/pre %.0f  loop %.0f  tail %.0f  total %.0f" % (*d.mean(axis=0), d.sum(axis=1).mean()))
 ok = tr[:, 4] > 0
 s = tr[ok]
-print("step 6: pivot chain %.0f  barrier-1 %.0f  update+mfma+barrier-2 %.0f  | whole step %.0f  (loop/16 = %.0f)" % (
+# (blocked potrf: slots 4-7 are stamped by thread BSP_TRACE_TID inside block 1: after the publish
+#  barrier / after the register factorization / after the second barrier / end of the block)
+print("step 6 (blocked form: block 1): pivot chain | factor %.0f  barrier %.0f  update+mfma+barrier %.0f  | whole %.0f  (loop/16 = %.0f)" % (
     (s[:, 5] - s[:, 4]).mean(), (s[:, 6] - s[:, 5]).mean(), (s[:, 7] - s[:, 6]).mean(),
     (s[:, 7] - s[:, 4]).mean(), d[:, 1].mean() / 16))
 for q in (10, 50, 90):
