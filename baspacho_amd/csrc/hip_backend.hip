@@ -350,6 +350,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_BLOCK_SOLVE")) blockSolve = e[0] != '0';
     if (const char* e = std::getenv("BSP_SOLVE_INV")) solveInv = e[0] != '0';
     if (const char* e = std::getenv("BSP_UPD_PREFETCH_WGS")) updPrefetchMaxWgs = std::atoll(e);
+    if (const char* e = std::getenv("BSP_TILE_YIELD")) tileYield = e[0] == '1';
     if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
     if (const char* e = std::getenv("BSP_ELIM_FACTOR_STAGED")) elimFactorStaged = e[0] != '0';
@@ -478,8 +479,10 @@ struct HipSymbolicCtx : SymbolicCtx {
   // it runs on (cooperative CU yield, hip_kernels.h)
   unsigned* yieldWord() {
     if (!yieldBuf.ptr) {
-      yieldBuf.resize(256);
-      hipCHECK(hipMemset(yieldBuf.ptr, 0, 256));
+      // word 0: the potrf workgroup's CU; words 64 .. 64 + 2048: chain tiles counted per CU (TILE YIELD)
+      const size_t bytes = 4 * (hipk::kYieldTableOffset + hipk::kYieldTableSize);
+      yieldBuf.resize(bytes);
+      hipCHECK(hipMemset(yieldBuf.ptr, 0, bytes));
     }
     return reinterpret_cast<unsigned*>(yieldBuf.ptr);
   }
@@ -543,6 +546,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   };
   std::map<const void*, SolveInvList> solveInvLists;
   bool solveInv = true;  // BSP_SOLVE_INV=0: the substitution kernels of rounds 1-2
+  bool tileYield = false;  // BSP_TILE_YIELD=1: bulk workgroups also pause for the chain's ordinary tiles
   int64_t updPrefetchMaxWgs = 2048;  // updateTile<PREFETCH> for launches of up to this many workgroups (BSP_UPD_PREFETCH_WGS; -1: never)
   DevBuf elimPackBuf;  // packed copy of the solved blocks of a sparse-elimination range (BSP_ELIM_PACK=1)
   PtrRing ptrRing;
@@ -582,7 +586,8 @@ struct HipNumericCtx : NumericCtx<T> {
       // (cooperative CU yield, hip_kernels.h: side-stream launches of a single matrix only)
       const unsigned* yf = (extraLds && batchSize == 1 && sym.bulkYield) ? sym.yieldWord() : nullptr;
       hipk::updateTileBulk<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, pad,
-                                stream>>>(plan.updTasksFat.as<UpdTaskFat>() + begin, ref, yf, atomicMask);
+                                stream>>>(plan.updTasksFat.as<UpdTaskFat>() + begin, ref, yf,
+                                          atomicMask | ((yf && sym.tileYield) ? 0x100 : 0));
       return;
     }
     // (launches of at most ~2 rounds of workgroups: the latency-bound variant, hip_kernels.h)
@@ -935,7 +940,8 @@ struct HipNumericCtx : NumericCtx<T> {
           }
           hipk::chainStep<BT><<<dim3(nUpd + extra, gy.y), 256, 0, sym.stream>>>(
               plan.host.panels[lr.directPanel], plan.host.segs[lr.directSeg], (int)nUpd, nextPanel,
-              fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
+              (fuse ? 1 : 0) | ((lookahead && batchSize == 1 && sym.bulkYield && sym.tileYield) ? 2 : 0), ref,
+              rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
               memOff, kMem, (lookahead && batchSize == 1 && sym.bulkYield) ? sym.yieldWord() : nullptr,
               sym.traceLaunchId++, kMem0, extra, atomicFromCol, memColBegin, memColEnd);
           potrfFused = fuse;

@@ -79,6 +79,39 @@ __device__ __forceinline__ void yieldWhile(const unsigned* flag, unsigned key) {
   }
 }
 
+// TILE YIELD (round 3, opt-in BSP_TILE_YIELD=1): the chain's ordinary tile workgroups announce
+// themselves too, in a per-CU counter behind the potrf word (index = the 11 low bits of cuKey()):
+// beside three bulk workgroups a chain tile gets a quarter of the matrix pipe and lives 25-30 us of
+// which ~10 are its own (tools/trace_extents.py: the tiles, not the potrf workgroup, end a step).
+// MEASURED: the chain's launches shrink from 4.40 to 3.80 ms and the bulk launches grow from 6.07 to
+// 6.50 ms -- factor() 6.30 -> 6.53 ms (FLAT-50k 27.0 -> 27.7): the phase is bound by the matrix
+// pipe's total work, what the chain gains the bulk stream loses.  Off by default.
+constexpr int kYieldTableOffset = 64;    // words
+constexpr int kYieldTableSize = 2048;    // counters
+__device__ __forceinline__ unsigned cuSlot() { return cuKey() & (kYieldTableSize - 1); }
+__device__ __forceinline__ void tileYieldEnter(unsigned* flag, int on) {
+  if (on && flag && threadIdx.x == 0) {
+    __hip_atomic_fetch_add((GP<unsigned>)flag + kYieldTableOffset + cuSlot(), 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void tileYieldLeave(unsigned* flag, int on) {
+  if (on && flag && threadIdx.x == 0) {
+    __hip_atomic_fetch_add((GP<unsigned>)flag + kYieldTableOffset + cuSlot(), ~0u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// bulk side: pause while the potrf word names this CU or a chain tile is counted on it (bounded)
+__device__ __forceinline__ void yieldWhileAny(const unsigned* flag, unsigned key) {
+  for (int spin = 0; spin < 48; spin++) {
+    __builtin_amdgcn_s_sleep(16);
+    const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)yieldPeek(flag));
+    const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)yieldPeek(flag + kYieldTableOffset + (key & (kYieldTableSize - 1))));
+    if (a != key && b == 0u) break;
+  }
+}
+
 __device__ __forceinline__ void waveSync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -2239,6 +2272,9 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
     if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
     // (cooperative CU yield: the word is fetched with the chunk and looked at after it has landed)
     const unsigned yf = yieldFlag ? yieldPeek(yieldFlag) : 0u;
+    const unsigned yt = (yieldFlag && (atomicMask & 0x100))
+                            ? yieldPeek(yieldFlag + kYieldTableOffset + (myCu & (kYieldTableSize - 1)))
+                            : 0u;
 #pragma unroll
     for (int it = 0; it < NI; it++) {
       __builtin_amdgcn_global_load_lds((GV)(srcA[it] + kBase), (LV)(As + RPI * (4 * it + wave) * KC),
@@ -2253,8 +2289,12 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (yieldFlag && (unsigned)__builtin_amdgcn_readfirstlane((int)yf) == myCu) {
-      yieldWhile(yieldFlag, myCu);
+    if (yieldFlag) {
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)yt) != 0u) {
+        yieldWhileAny(yieldFlag, myCu);
+      } else if ((unsigned)__builtin_amdgcn_readfirstlane((int)yf) == myCu) {
+        yieldWhile(yieldFlag, myCu);
+      }
     }
     if (!skipUpper) {
 #pragma unroll
@@ -2721,6 +2761,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   GP<const T> Lkk = data + pd.diagOff;
   GP<T> P = data + pd.diagOff + (int64_t)nb * lda;  // the panel's rows below, in place
 
+  const int tileYield = fuse >> 1;  // (bit 1 of `fuse`: TILE YIELD on)
+  fuse &= 1;
   if (fuse && blockIdx.x == 0) {
     // tile (0,0) = the next panel's diagonal block: update it inside the potrf and factor it
     __builtin_amdgcn_s_setprio(3);
@@ -2759,6 +2801,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   __builtin_amdgcn_s_setprio(BSP_TILE_PRIO);
   BSP_STAMP_TILE(4);
+  tileYieldEnter(yieldFlag, tileYield);
   const bool extra = extraDiag && (int)blockIdx.x == nTasks;  // (grid = nTasks + 1 then)
   int idx = fuse ? 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1) : xcdContiguous(blockIdx.x, nTasks);
   int colTile = sd.q0, rowTile;
@@ -2823,6 +2866,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
+  tileYieldLeave(yieldFlag, tileYield);
   BSP_STAMP_TILE(7);
   BSP_EXTENT_END(traceId, false);
 }
