@@ -104,10 +104,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int c = 0; c < nChunks; c++) {
       const int buf = NBUF > 1 ? c % NBUF : 0;
       if (NBUF == 1) {
-        if (c > 0) __syncthreads();
-        if (EPI != 4 || c == 0) request(c * KC, 0);
+        if (c > 0 && EPI != 6) __syncthreads();
+        if ((EPI != 4 && EPI != 6) || c == 0) request(c * KC, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (EPI != 6 || c == 0) __syncthreads();
         if (EPI == 3 && c == nChunks - 1) {
           GPm tg = D + t.tgtOff;
 #pragma unroll
@@ -493,7 +493,7 @@ int main(int argc, char** argv) {
   };
   if (argc > 1 && argv[1][0] == 'q') {
     // quads (2 x 2 tiles) of full rows, XCD-contiguous; the same tiles as a plain list for S1
-    printf("%-10s%9s%9s%9s%9s%9s%9s%9s%9s\n", "tiles", "S1@3", "S1st@3", "S1nold@3", "S1nomm@3", "Q32@2", "Q32st@2", "Q32nold", "Q32nomm");
+    printf("%-10s%9s%9s%9s%9s%9s%9s%9s%9s\n", "tiles", "S1@3", "S1st@3", "S1nold@3", "S1nomm@3", "Q32@2", "Q32st@2", "S1nobar@3", "S1nobar@4");
     for (int nt : {768, 1536, 3072, 6144}) {
       std::vector<Task> quads, tiles;
       const int b = 2, base = 256 * (b + 1);
@@ -536,8 +536,8 @@ int main(int argc, char** argv) {
       r[3] = run<32, 1, false, 5>(dT, nT, data, lda, ticket, 3, K);
       r[4] = runQuad<32, 0>(dQ, nQ, data, lda, 2, K);
       r[5] = runQuad<32, 1>(dQ, nQ, data, lda, 2, K);
-      r[6] = runQuad<32, 4>(dQ, nQ, data, lda, 2, K);
-      r[7] = runQuad<32, 5>(dQ, nQ, data, lda, 2, K);
+      r[6] = run<32, 1, false, 6>(dT, nT, data, lda, ticket, 3, K);
+      r[7] = run<32, 1, false, 6>(dT, nT, data, lda, ticket, 4, K);
       printf("%-10d", nT);
       for (auto& x : r) printf("%9.1f", x.tf);
       printf("   TF/s\n%-10s", "");
