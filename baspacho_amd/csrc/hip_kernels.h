@@ -2822,8 +2822,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int ri = rowTile + 16 * w + n, rj = colTile + 16 * w + n;
   Acc D[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   if (kMem > 0 && !extra && colTile >= memColBegin && colTile < memColEnd) {
-    ChainTile<T>::multiplyMem(data + memOff, lda, kMem, rowTile, colTile, rowsBelow, segEnd,
-                              rowTile == colTile, XB, D);
+    // Tile (0,0) of the block-wide segment skips the panels that applied their update to it early
+    // (extraDiag; kMem0 = what is left).  With a fused potrf that tile belongs to workgroup 0, above;
+    // a block-last step whose update is this ONE tile (a last outer block of a single panel, no rows
+    // below the lump) is not fused, and took all kMem columns again: lump widths of 256 k + 64, k >= 2,
+    // got the updates of the block's first three panels twice (found by tools/stress.py seed 9426).
+    const int skip = (rowTile == sd.q0 && colTile == sd.q0) ? kMem - kMem0 : 0;
+    if (kMem - skip > 0) {
+      ChainTile<T>::multiplyMem(data + memOff + skip, lda, kMem - skip, rowTile, colTile, rowsBelow,
+                                segEnd, rowTile == colTile, XB, D);
+    }
   }
   ChainTile<T> ct;
   ct.load(rawIn, Lkk, dinv, lda, nb, ri, rj, rowsBelow, colEnd, rowTile == colTile);

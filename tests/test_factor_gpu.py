@@ -293,6 +293,32 @@ def test_lump_widths_around_panel_and_block_boundaries(dtype):
         assert np.linalg.norm(X - want) / np.linalg.norm(want) < (1e-10 if dtype == np.float64 else 1e-4), W
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_last_lump_ending_in_short_outer_blocks(dtype):
+    """ONE dense lump (no rows below it) whose last outer block is short: widths 256 k + r for
+    r = 1 .. 64 .. 255.  With r = 64 and k >= 2 the block-last step of the last full block updates a
+    single tile, is therefore not fused with the next potrf, and used to apply the block's first
+    three panels to that tile twice (they had applied their update early): relative error ~1e-5 in
+    the last 64 x 64 block, found by tools/stress.py seed 9426 in round 3."""
+    for W in (320, 576, 832, 1600, 513, 575, 577, 639, 640, 704, 768, 1088 + 8, 1344):
+        sizes, tot = [], 0
+        while tot < W:
+            s = min(8 if W % 8 == 0 else 1 + len(sizes) % 5, W - tot)
+            sizes.append(s)
+            tot += s
+        nparam = len(sizes)
+        cols = [list(range(c, nparam)) for c in range(nparam)]
+        ss = T.columns_to_structure(cols)
+        sol = B.create_solver(B.Settings(), np.asarray(sizes, dtype=np.int64), ss, [])
+        data = spd_data(sol, 11 + W, dtype=dtype)
+        L, A = dense_lower_chol(sol, data)
+        got = lower_of(sol, _gpu_factor(sol, data))
+        err = np.linalg.norm(got - L) / np.linalg.norm(L)
+        assert err < (1e-12 if dtype == np.float64 else 2e-5), (W, err)
+        tail = np.linalg.norm(got[-64:, -64:] - L[-64:, -64:]) / np.linalg.norm(L[-64:, -64:])
+        assert tail < (1e-11 if dtype == np.float64 else 1e-4), (W, tail)
+
+
 @pytest.mark.parametrize("knob", ["BSP_NO_LOOKAHEAD=1", "BSP_DIRECT_CHAIN=0", "BSP_FUSE_POTRF=0",
                                   "BSP_SPLIT_DIAG=0", "BSP_ELIM_FACTOR_DESC=0", "BSP_ELIM_FACTOR_STAGED=0", "BSP_GATHER_FUSED_LOAD=0", "BSP_GATHER_FUSED_LOAD=2",
                                   "BSP_MERGED_CHAIN=0", "BSP_BULK_KERNEL=0", "BSP_EARLY_FORK=0",
