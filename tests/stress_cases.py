@@ -57,3 +57,25 @@ def run_case(seed, big=False):
     err = np.linalg.norm(yout.cpu().numpy().astype(np.float64) - ref) / np.linalg.norm(ref)
     assert err < tol * 10, ("addMv", err, desc)
     return desc
+
+
+def run_width_case(W, tail, dtype=np.float64):
+    """a dense lump of width W (spans of 8, a ragged last one), optionally followed by a second lump of
+    `tail` columns that most of its spans see; returns the relative error of the device factor
+    against numpy.  tools/sweep_widths.py walks every W; tests/test_stress_gpu.py a slice around the
+    panel (64) and outer-block (256) boundaries."""
+    sizes = [8] * (W // 8) + ([W % 8] if W % 8 else [])
+    n0 = len(sizes)
+    sizes = sizes + [7] * (tail // 7)
+    nparam = len(sizes)
+    cols = [list(range(c, n0)) + [q for q in range(n0, nparam) if (q + c) % 4 != 0] for c in range(n0)]
+    cols += [list(range(c, nparam)) for c in range(n0, nparam)]
+    ss = T.columns_to_structure(cols)
+    st = B.Settings(findSparseEliminationRanges=False)
+    sol = B.create_solver(st, np.asarray(sizes, dtype=np.int64), ss, [])
+    d = spd_data(sol, 5 + W, dtype=dtype)
+    dev = to_dev(d)
+    sol.factor(dev)
+    L, A = dense_lower_chol(sol, d)
+    got = lower_of(sol, dev.cpu().numpy())
+    return np.linalg.norm(got - L) / np.linalg.norm(L)

@@ -16,3 +16,24 @@ def test_random_case(seed):
 def test_random_case_wide_lumps(seed):
     """300-900 parameters, denser: wide lumps, chain steps and lookahead units"""
     run_case(seed, big=True)
+
+
+def test_seed_that_found_the_single_tile_block_last_step():
+    """tools/stress.py seed 9426 (round 3): a last lump 1600 = 6 x 256 + 64 columns wide"""
+    run_case(9426)
+
+
+@pytest.mark.parametrize("tail", [0, 70])
+def test_lump_width_slice(tail):
+    """every lump width around the panel (64) and outer-block (256) boundaries, with and without a
+    second lump below (tools/sweep_widths.py walks 1 .. 1100: round 3 ran it clean)"""
+    import numpy as np
+    from stress_cases import run_width_case
+    widths = list(range(56, 72)) + list(range(250, 262)) + list(range(314, 326)) + list(range(506, 518)) + \
+        list(range(570, 582)) + [832, 1088, 1089]
+    for W in widths:
+        err = run_width_case(W, tail)
+        assert err < 1e-12, (W, tail, err)
+    for W in (64, 320, 576, 577):
+        err = run_width_case(W, tail, dtype=np.float32)
+        assert err < 2e-5, (W, tail, err)
