@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python tools/stress.py 20000 3000 2>&1 | tail -6
-timeout 1500 python tools/stress.py 40000 700 big 2>&1 | tail -6
+timeout 900 python tools/stress.py 50000 600 2>&1 | grep -v amdgpu | tail -6
+timeout 900 python tools/stress.py 60000 200 big 2>&1 | grep -v amdgpu | tail -6

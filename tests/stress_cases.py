@@ -56,6 +56,19 @@ def run_case(seed, big=False):
     ref = A @ xin.astype(np.float64)
     err = np.linalg.norm(yout.cpu().numpy().astype(np.float64) - ref) / np.linalg.norm(ref)
     assert err < tol * 10, ("addMv", err, desc)
+    # factorUpTo(k) then factorFrom(k) == factor, for a random lump boundary beyond the elimination
+    # ranges (PartialFactorSolveTest.cpp:37-155)
+    er = sol.sparseEliminationRanges()
+    dense_from = int(er[-1]) if len(er) else 0
+    if sol.numLumps() - dense_from >= 2:
+        lump = int(rng.integers(dense_from + 1, sol.numLumps()))
+        span = int(sol.skel()["lumpToSpan"][lump])
+        d2 = to_dev(datas[0])
+        sol.factorUpTo(d2, span)
+        sol.factorFrom(d2, span)
+        got = lower_of(sol, d2.cpu().numpy())
+        err = np.linalg.norm(got - L) / np.linalg.norm(L)
+        assert err < tol, ("partial", span, err, desc)
     return desc
 
 
@@ -78,4 +91,12 @@ def run_width_case(W, tail, dtype=np.float64):
     sol.factor(dev)
     L, A = dense_lower_chol(sol, d)
     got = lower_of(sol, dev.cpu().numpy())
-    return np.linalg.norm(got - L) / np.linalg.norm(L)
+    err = np.linalg.norm(got - L) / np.linalg.norm(L)
+    # the device solve on the same factor (block triangles through inverted diagonal blocks, wide lumps)
+    n = sol.order()
+    rhs = np.random.default_rng(W).standard_normal(n).astype(dtype)
+    v = to_dev(rhs)
+    sol.solve(dev, v, n, 1)
+    X = np.linalg.solve(A, rhs.astype(np.float64))
+    serr = np.linalg.norm(v.cpu().numpy().astype(np.float64) - X) / np.linalg.norm(X)
+    return max(err, serr * (1e-2 if dtype == np.float64 else 1e-1))
