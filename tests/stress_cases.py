@@ -100,3 +100,48 @@ def run_width_case(W, tail, dtype=np.float64):
     X = np.linalg.solve(A, rhs.astype(np.float64))
     serr = np.linalg.norm(v.cpu().numpy().astype(np.float64) - X) / np.linalg.norm(X)
     return max(err, serr * (1e-2 if dtype == np.float64 else 1e-1))
+
+
+def run_family_case(seed):
+    """the reference's structured families at random small sizes (TestingMatGen.cpp: grid, meridians,
+    flat + Schur set; Bench.cpp:290-367 uses them at benchmark size): deep elimination trees, which
+    the random column structures of run_case do not produce.  Device factor + solve against numpy."""
+    rng = np.random.default_rng(seed)
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        w, h = int(rng.integers(4, 40)), int(rng.integers(4, 40))
+        ss = T.gen_grid(w, h, float(rng.choice([1.0, 0.6, 0.25])), int(rng.integers(1, 4)), seed)
+        ranges = []
+    elif kind == 1:
+        ss = T.gen_meridians(int(rng.integers(2, 7)), int(rng.integers(20, 150)), 0.5, int(rng.integers(3, 25)),
+                             int(rng.integers(5, 60)), int(rng.integers(0, 3)), int(rng.integers(0, 3)), seed)
+        ranges = []
+    else:
+        base = T.gen_flat(int(rng.integers(20, 200)), float(rng.choice([0.02, 0.1, 0.3])), seed)
+        k = int(rng.integers(10, 400))
+        ss = T.add_schur_set(base, k, float(rng.choice([0.02, 0.1])), seed + 1000)
+        ranges = [0, k] if rng.random() < 0.6 else []
+    n_par = ss.order()
+    pmax = int(rng.choice([1, 2, 3, 6]))
+    sizes = rng.integers(1, pmax + 1, size=n_par).astype(np.int64) if rng.random() < 0.5 else np.full(n_par, pmax, dtype=np.int64)
+    dtype = np.float64 if rng.random() < 0.7 else np.float32
+    tol = 1e-9 if dtype == np.float64 else 3e-4
+    desc = dict(seed=seed, kind=["grid", "meridians", "flat+schur"][kind], params=n_par, pmax=pmax, dtype=dtype.__name__)
+    sol = B.create_solver(B.Settings(), sizes, ss, ranges)
+    n = sol.order()
+    if n > 6000:
+        return desc  # (dense check too slow)
+    data = spd_data(sol, 3 + seed, dtype=dtype)
+    dev = to_dev(data)
+    sol.factor(dev)
+    L, A = dense_lower_chol(sol, data)
+    got = lower_of(sol, dev.cpu().numpy())
+    err = np.linalg.norm(got - L) / np.linalg.norm(L)
+    assert err < tol, ("factor", err, desc)
+    rhs = rng.standard_normal(n).astype(dtype)
+    v = to_dev(rhs)
+    sol.solve(dev, v, n, 1)
+    X = np.linalg.solve(A, rhs.astype(np.float64))
+    err = np.linalg.norm(v.cpu().numpy().astype(np.float64) - X) / np.linalg.norm(X)
+    assert err < tol * 50, ("solve", err, desc)
+    return desc
