@@ -113,8 +113,9 @@ def run_family_case(seed):
         ss = T.gen_grid(w, h, float(rng.choice([1.0, 0.6, 0.25])), int(rng.integers(1, 4)), seed)
         ranges = []
     elif kind == 1:
-        ss = T.gen_meridians(int(rng.integers(2, 7)), int(rng.integers(20, 150)), 0.5, int(rng.integers(3, 25)),
-                             int(rng.integers(5, 60)), int(rng.integers(0, 3)), int(rng.integers(0, 3)), seed)
+        band = int(rng.integers(3, 25))
+        ss = T.gen_meridians(int(rng.integers(2, 7)), band + int(rng.integers(0, 130)), 0.5, band,
+                             band + int(rng.integers(0, 40)), int(rng.integers(0, 3)), int(rng.integers(0, 3)), seed)
         ranges = []
     else:
         base = T.gen_flat(int(rng.integers(20, 200)), float(rng.choice([0.02, 0.1, 0.3])), seed)

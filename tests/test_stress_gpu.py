@@ -37,3 +37,10 @@ def test_lump_width_slice(tail):
     for W in (64, 320, 576, 577):
         err = run_width_case(W, tail, dtype=np.float32)
         assert err < 2e-5, (W, tail, err)
+
+
+@pytest.mark.parametrize("seed", range(0, 24))
+def test_structured_family_case(seed):
+    """grid / meridians / flat + Schur-set structures at random small sizes (deep elimination trees)"""
+    from stress_cases import run_family_case
+    run_family_case(seed)
