@@ -287,6 +287,15 @@ void Solver::internalSolveLRange(SolveCtx<T>& slvCtx, const T* matData, int64_t 
   const int64_t upToLump = factorSkel.spanToLump[endSpanIndex];
 
   if (slvCtx.hasFusedSolve()) {
+    // (the same range checks as the op-by-op loop below makes on its way: Solver.cpp:281-290)
+    for (size_t r = 0; r + 1 < sparseElimRanges.size(); r++) {
+      const int64_t rb = sparseElimRanges[r], re = sparseElimRanges[r + 1];
+      if (re > upToLump) {
+        BASPACHO_CHECK_EQ(rb, upToLump);
+        break;
+      }
+      if (startLump > rb) BASPACHO_CHECK_GE(startLump, re);
+    }
     slvCtx.solveLRange(matData, startLump, upToLump, vecData, stride);
     return;
   }
@@ -333,6 +342,18 @@ void Solver::internalSolveLtRange(SolveCtx<T>& slvCtx, const T* matData, int64_t
   const int64_t upToLump = factorSkel.spanToLump[endSpanIndex];
 
   if (slvCtx.hasFusedSolve()) {
+    // (the checks of the op-by-op loop below: Solver.cpp:383-392)
+    for (int64_t r = (int64_t)sparseElimRanges.size() - 2; r >= 0; r--) {
+      const int64_t rb = sparseElimRanges[r], re = sparseElimRanges[r + 1];
+      if (re > upToLump) {
+        BASPACHO_CHECK_LE(rb, upToLump);
+        continue;
+      }
+      if (rb < startLump) {
+        BASPACHO_CHECK_GE(startLump, re);
+        break;
+      }
+    }
     slvCtx.solveLtRange(matData, startLump, upToLump, vecData, stride);
     return;
   }

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_stress_gpu.py -x -q -m gpu 2>&1 | tail -3
+python -m pytest tests/test_solve_gpu.py tests/test_solve_perop_gpu.py -x -q -m gpu 2>&1 | tail -5

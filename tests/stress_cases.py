@@ -56,6 +56,31 @@ def run_case(seed, big=False):
     ref = A @ xin.astype(np.float64)
     err = np.linalg.norm(yout.cpu().numpy().astype(np.float64) - ref) / np.linalg.norm(ref)
     assert err < tol * 10, ("addMv", err, desc)
+    # partial solves at a random lump boundary (PartialFactorSolveTest.cpp:157-262): forward
+    # substitution over the leading then the trailing columns is solveL, the backward one in the
+    # opposite order solveLt, and solveL then solveLt is solve (checked against numpy above)
+    er0 = sol.sparseEliminationRanges()
+    first_dense = int(er0[-1]) if len(er0) else 0
+    if sol.numLumps() - first_dense >= 2:
+        # (a boundary inside an elimination range is a precondition failure, Solver.cpp:281-290)
+        span = int(sol.skel()["lumpToSpan"][int(rng.integers(first_dense + 1, sol.numLumps()))])
+        ref_v = v.cpu().numpy().astype(np.float64)
+        w1 = to_dev(rhs)
+        sol.solveLUpTo(devs[0], span, w1, n, nrhs)
+        sol.solveLFrom(devs[0], span, w1, n, nrhs)
+        w2 = to_dev(rhs)
+        sol.solveL(devs[0], w2, n, nrhs)
+        a1, a2 = w1.cpu().numpy().astype(np.float64), w2.cpu().numpy().astype(np.float64)
+        err = np.linalg.norm(a1 - a2) / np.linalg.norm(a2)
+        assert err < tol * 10, ("solveL split", span, err, desc)
+        sol.solveLtFrom(devs[0], span, w1, n, nrhs)
+        sol.solveLtUpTo(devs[0], span, w1, n, nrhs)
+        sol.solveLt(devs[0], w2, n, nrhs)
+        a1, a2 = w1.cpu().numpy().astype(np.float64), w2.cpu().numpy().astype(np.float64)
+        err = np.linalg.norm(a1 - ref_v) / np.linalg.norm(ref_v)
+        assert err < tol * 50, ("solveLt split", span, err, desc)
+        err = np.linalg.norm(a2 - ref_v) / np.linalg.norm(ref_v)
+        assert err < tol * 50, ("solveL + solveLt", err, desc)
     # factorUpTo(k) then factorFrom(k) == factor, for a random lump boundary beyond the elimination
     # ranges (PartialFactorSolveTest.cpp:37-155)
     er = sol.sparseEliminationRanges()

@@ -331,3 +331,28 @@ def test_batched_partial_factor_and_solves(dtype):
         for q in range(nb):
             got = vs[q].cpu().numpy().astype(np.float64)
             assert np.linalg.norm(got - refs[q]) / max(np.linalg.norm(refs[q]), 1e-30) < tol * 10, (name, q)
+
+
+def test_partial_solve_boundary_inside_an_elimination_range_is_an_error():
+    """Solver.cpp:281-290: solveLUpTo / solveLFrom with a boundary strictly inside a sparse-elimination
+    range is a precondition failure ("Check failed"), on the fused device path as on the op-by-op one;
+    a boundary at the end of the ranges or beyond is fine (tools/stress.py checks those numerically)"""
+    sol, _, _ = solver_random(61, fill=0.03, elim=(0, 40))
+    ranges = sol.sparseEliminationRanges()
+    assert len(ranges) >= 2 and ranges[1] - ranges[0] >= 2
+    sk = sol.skel()
+    inside = int(sk["lumpToSpan"][int(ranges[0]) + 1])
+    data = spd_data(sol, 3)
+    d = to_dev(data)
+    sol.factor(d)
+    n = sol.order()
+    v = to_dev(T.random_data(n, -1, 1, 5))
+    with pytest.raises(RuntimeError, match="Check failed"):
+        sol.solveLUpTo(d, inside, v, n, 1)
+    with pytest.raises(RuntimeError, match="Check failed"):
+        sol.solveLFrom(d, inside, v, n, 1)
+    with pytest.raises(RuntimeError, match="Check failed"):
+        sol.solveLtFrom(d, inside, v, n, 1)
+    edge = int(sk["lumpToSpan"][int(ranges[-1])])
+    sol.solveLUpTo(d, edge, v, n, 1)
+    sol.solveLFrom(d, edge, v, n, 1)
