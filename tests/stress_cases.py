@@ -81,6 +81,20 @@ def run_case(seed, big=False):
         assert err < tol * 50, ("solveLt split", span, err, desc)
         err = np.linalg.norm(a2 - ref_v) / np.linalg.norm(ref_v)
         assert err < tol * 50, ("solveL + solveLt", err, desc)
+    # one case in five: the same factor and solve through the reference's op-by-op loops over the
+    # per-op NumericCtx / SolveCtx virtuals (MatOps.h:113-184; bsp_force_per_op)
+    if rng.random() < 0.2:
+        d3 = to_dev(datas[0])
+        w3 = to_dev(rhs)
+        with sol.forcePerOp():
+            sol.factor(d3)
+            sol.solve(d3, w3, n, nrhs)
+        got = lower_of(sol, d3.cpu().numpy())
+        err = np.linalg.norm(got - L) / np.linalg.norm(L)
+        assert err < tol, ("per-op factor", err, desc)
+        a3 = w3.cpu().numpy().astype(np.float64).reshape(nrhs, n).T
+        err = np.linalg.norm(a3 - X) / np.linalg.norm(X)
+        assert err < tol * 50, ("per-op solve", err, desc)
     # factorUpTo(k) then factorFrom(k) == factor, for a random lump boundary beyond the elimination
     # ranges (PartialFactorSolveTest.cpp:37-155)
     er = sol.sparseEliminationRanges()
