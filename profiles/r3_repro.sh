@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_solve_gpu.py tests/test_solve_perop_gpu.py -x -q -m gpu 2>&1 | tail -5
+for i in 1 2 3; do timeout 600 python -m pytest tests/test_concurrency_gpu.py -x -q -m gpu 2>&1 | tail -4; done
