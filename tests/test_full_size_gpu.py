@@ -267,3 +267,19 @@ def test_c5_bal1723_real_hessian_fp32_preconditioned_cg(bal1723_real):
     r = grad.clone()
     sol.addMvFrom(A, 0, x, sol.order(), r, sol.order(), 1, -1.0)
     assert float(r.norm() / grad.norm()) < 1e-9
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_data_offsets_beyond_32_bits(prec):
+    """maximum sizes: ONE dense lump of order 65 600 = 4.3e9 values (34 GB in fp64), so that element
+    offsets pass 2^31 AND 2^32: factor (vector probe), solveL, solveLt, solve -- tools/huge_lump.py,
+    which builds and checks everything on the device in row blocks (a subprocess: 70 GB of device
+    memory are released when it ends)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "huge_lump.py"), "65600", prec],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "OK" in r.stdout
