@@ -674,3 +674,30 @@ def test_packed_elimination_operands(monkeypatch, dtype):
     data2 = spd_data(sol2, 3, dtype=dtype)
     L, _ = dense_lower_chol(sol2, data2)
     assert np.linalg.norm(lower_of(sol2, _gpu_factor(sol2, data2)) - L) < EPS[dtype][1]
+
+
+def test_empty_and_trivial_structures():
+    """edge cases: no parameters at all (factor and solve are no-ops on empty device buffers), a
+    single 1 x 1 block, a block-diagonal matrix (every lump eliminated, no update at all), fp64 + fp32"""
+    import torch
+    ss = T.columns_to_structure([])
+    sol = B.create_solver(B.Settings(), np.zeros(0, dtype=np.int64), ss, [])
+    assert sol.order() == 0 and sol.dataSize() == 0
+    d = torch.zeros(0, dtype=torch.float64, device="cuda")
+    sol.factor(d)
+    sol.solve(d, torch.zeros(0, dtype=torch.float64, device="cuda"), 0, 1)
+    for dtype in (np.float64, np.float32):
+        sol = B.create_solver(B.Settings(), np.ones(1, dtype=np.int64), T.columns_to_structure([[0]]), [])
+        d = to_dev(np.array([9.0], dtype=dtype))
+        sol.factor(d)
+        assert abs(float(d.cpu()[0]) - 3.0) < 1e-6
+        v = to_dev(np.array([6.0], dtype=dtype))
+        sol.solve(d, v, 1, 1)
+        assert abs(float(v.cpu()[0]) - 6.0 / 9.0) < 1e-6
+        for find in (True, False):
+            sol = B.create_solver(B.Settings(findSparseEliminationRanges=find), np.full(50, 3, dtype=np.int64),
+                                  T.columns_to_structure([[c] for c in range(50)]), [])
+            data = spd_data(sol, 4, dtype=dtype)
+            L, A = dense_lower_chol(sol, data)
+            got = lower_of(sol, _gpu_factor(sol, data))
+            assert np.linalg.norm(got - L) / np.linalg.norm(L) < (1e-13 if dtype == np.float64 else 1e-5)
