@@ -701,3 +701,26 @@ def test_empty_and_trivial_structures():
             L, A = dense_lower_chol(sol, data)
             got = lower_of(sol, _gpu_factor(sol, data))
             assert np.linalg.norm(got - L) / np.linalg.norm(L) < (1e-13 if dtype == np.float64 else 1e-5)
+
+
+def test_indefinite_input_fails_silently_with_nans():
+    """numerical breakdown is silent in the reference (NaN / Inf in `data`, no exception, no hang:
+    SURVEY 8b "Errors"); the same here, for a wide dense lump (chain + lookahead units, the bounded
+    yield spins) and for a structure with an elimination range"""
+    import torch
+    nparam = 1100 // 4
+    cols = [list(range(c, nparam)) for c in range(nparam)]
+    sol = B.create_solver(B.Settings(), np.full(nparam, 4, dtype=np.int64), T.columns_to_structure(cols), [])
+    data = T.random_data(sol.dataSize(), -1.0, 1.0, 5)      # no damping: indefinite
+    d = to_dev(data)
+    sol.factor(d)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(d).all())
+    v = to_dev(T.random_data(sol.order(), -1, 1, 6))
+    sol.solve(d, v, sol.order(), 1)
+    torch.cuda.synchronize()
+    sol2, _, _ = solver_random(61, fill=0.05, elim=(0, 40))
+    d2 = to_dev(T.random_data(sol2.dataSize(), -1.0, 1.0, 7))
+    sol2.factor(d2)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(d2).all())
