@@ -320,6 +320,11 @@ class Solver:
                 return False
         return _Scope()
 
+    def _testSetFault(self, kind):
+        """TESTING, fault injection (bsp_test_set_fault): 1 = factor() skips the sparse-elimination
+        update, 0 = off"""
+        _check(self._lib.bsp_test_set_fault(self._h, ctypes.c_int32(kind)))
+
     def collectOpStats(self, on=True):
         """Solver::enableStats + per-op samples of the per-op boundary (bsp_collect_op_stats)"""
         _check(self._lib.bsp_collect_op_stats(self._h, ctypes.c_int32(1 if on else 0)))

@@ -17,6 +17,9 @@ using namespace BaSpaCho;
 struct bsp_solver {
   SolverPtr solver;
   ComputationModel model;  // storage for a user-supplied model
+  // BAL layout already validated for (numPts, numCams, camSize): the parameter sizes of a solver
+  // never change, so the O(numPts + numCams) walk of checkBalLayout runs once, not per LM iteration
+  int64_t balOk[3] = {-1, -1, -1};
 };
 
 static thread_local std::string g_lastError;
@@ -267,6 +270,12 @@ int bsp_force_per_op(bsp_solver* s, int32_t on) {
   BSP_CATCH
 }
 
+int bsp_test_set_fault(bsp_solver* s, int32_t kind) {
+  BSP_TRY
+  hipBackendSetFault(s->solver->internalSymbolicContext(), kind);
+  BSP_CATCH
+}
+
 template <typename T>
 static void doElim(bsp_solver* s, T* d, int64_t idx) {
   const auto& ranges = s->solver->sparseEliminationRanges();
@@ -466,8 +475,9 @@ int bsp_bal_linearize_f64(int64_t numObs, const int64_t* obsCam, const int64_t* 
 // bsp_bal_fill_hessian_*: the kernels hard-code 3 x 3 point blocks, 9 x 9 camera blocks and 9 x 3
 // camera-point blocks, points first -- a solver with any other parameter sizes would send their
 // atomics out of bounds, so the layout is checked on the host before the launch
-static void checkBalLayout(const BaSpaCho::Solver& solver, int64_t numPts, int64_t numCams,
-                           int64_t camSize = 9) {
+static void checkBalLayout(bsp_solver* s, int64_t numPts, int64_t numCams, int64_t camSize = 9) {
+  if (s->balOk[0] == numPts && s->balOk[1] == numCams && s->balOk[2] == camSize) return;
+  const BaSpaCho::Solver& solver = *s->solver;
   if (camSize != 9 && camSize != 6) throw std::runtime_error("bsp_bal_fill_hessian: camera size must be 9 or 6");
   BASPACHO_CHECK_GE(numPts, 0);
   BASPACHO_CHECK_GE(numCams, 0);
@@ -482,6 +492,9 @@ static void checkBalLayout(const BaSpaCho::Solver& solver, int64_t numPts, int64
                                std::to_string(camSize) + ")");
     }
   }
+  s->balOk[0] = numPts;
+  s->balOk[1] = numCams;
+  s->balOk[2] = camSize;
 }
 
 int bsp_bal_fill_hessian_f64(bsp_solver* s, int64_t numPts, int64_t numCams, int64_t numObs,
@@ -489,7 +502,7 @@ int bsp_bal_fill_hessian_f64(bsp_solver* s, int64_t numPts, int64_t numCams, int
                              const double* Jp, const double* res, double lambda, double* data,
                              double* grad, int64_t* dbg, void* stream) {
   BSP_TRY
-  checkBalLayout(*s->solver, numPts, numCams);
+  checkBalLayout(s, numPts, numCams);
   balFillHessian<double>(s->solver->deviceAccessor(), 9, numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
                          res, lambda, data, grad, dbg, stream);
   BSP_CATCH
@@ -499,7 +512,7 @@ int bsp_bal_fill_hessian_f32(bsp_solver* s, int64_t numPts, int64_t numCams, int
                              const double* Jp, const double* res, float lambda, float* data,
                              float* grad, int64_t* dbg, void* stream) {
   BSP_TRY
-  checkBalLayout(*s->solver, numPts, numCams);
+  checkBalLayout(s, numPts, numCams);
   balFillHessian<float>(s->solver->deviceAccessor(), 9, numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
                         res, lambda, data, grad, dbg, stream);
   BSP_CATCH
@@ -517,7 +530,7 @@ int bsp_bal_fill_hessian_se3_f64(bsp_solver* s, int64_t numPts, int64_t numCams,
                                  const double* Jp, const double* res, double lambda, double* data,
                                  double* grad, void* stream) {
   BSP_TRY
-  checkBalLayout(*s->solver, numPts, numCams, 6);
+  checkBalLayout(s, numPts, numCams, 6);
   balFillHessian<double>(s->solver->deviceAccessor(), 6, numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
                          res, lambda, data, grad, nullptr, stream);
   BSP_CATCH
@@ -527,7 +540,7 @@ int bsp_bal_fill_hessian_se3_f32(bsp_solver* s, int64_t numPts, int64_t numCams,
                                  const double* Jp, const double* res, float lambda, float* data,
                                  float* grad, void* stream) {
   BSP_TRY
-  checkBalLayout(*s->solver, numPts, numCams, 6);
+  checkBalLayout(s, numPts, numCams, 6);
   balFillHessian<float>(s->solver->deviceAccessor(), 6, numPts, numCams, numObs, obsCam, obsPt, Jc, Jp,
                         res, lambda, data, grad, nullptr, stream);
   BSP_CATCH

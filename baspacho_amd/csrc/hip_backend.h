@@ -33,7 +33,7 @@ struct HipPlanStats {
          trsmFlops = 0, potrfFlops = 0, trsmFlopsMerged = 0, potrfFlopsFused = 0;
   int64_t numLaunches = 0, numLevels = 0, numPanels = 0, numSegs = 0, numUpdTasks = 0,
           numTrsmTasks = 0, chainTabEntries = 0, maxPanelsInLevel = 0, numAtomicUpdTasks = 0,
-          numGatherGroups = 0,  // > 0: the elimination update overlaps the dense phase
+          numGatherGroups = 0,  // (always 0 since round 4: the overlapped elimination was removed)
           numForkLevels = 0;
   double deferredFlops = 0;
 };
@@ -56,6 +56,11 @@ int hipBackendReadExtents(unsigned long long* out, int maxLaunches);
 // TESTING: make factor() take the reference-style per-op loop (potrf/trsm/saveSyrkGemm/
 // prepareAssemble/assemble/doElimination virtuals) instead of the fused path
 void hipBackendForcePerOp(SymbolicCtx& sym, bool on);
+
+// TESTING, fault injection for the full-size parity tests: kind 1 = factor() does not launch the
+// sparse-elimination update (the factor is then wrong and the checks must say so), 0 = off.
+// Never read from the environment: a leaked variable cannot corrupt a caller's factor.
+void hipBackendSetFault(SymbolicCtx& sym, int kind);
 
 HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t upToLump);
 

@@ -59,26 +59,22 @@ struct DevBuf {
   const U* as() const { return reinterpret_cast<const U*>(ptr); }
 };
 
-// The launch sequence of one factor() over a plan, captured once as a hipGraph (see factorViaGraph).
-struct FactorGraph {
-  hipGraphExec_t exec = nullptr;
-  DevBuf slot;  // device array of the batch's data pointers: every kernel of the graph reads its matrix through it
-  const void *dinvPtr = nullptr, *rawPtr = nullptr;  // scratch of the SymbolicCtx the captured launches point into
-  int calls = 0;
-  FactorGraph() {}
-  FactorGraph(const FactorGraph&) = delete;
-  ~FactorGraph() {
-    if (exec) (void)hipGraphExecDestroy(exec);
-  }
+// block solves through inverted diagonal blocks (denseLevels): per level list of a plan, the panels
+// whose diagonal blocks are inverted (built and uploaded on the first solve)
+struct SolveInvList {
+  bool built = false;
+  int64_t count = 0;
+  DevBuf list;
+  vector<int32_t> slotOfGroup;
 };
 
 struct DevPlan {
   HipPlanHost host;
-  std::map<std::pair<int, int>, FactorGraph> graphs;  // by (sizeof scalar, batch size)
+  // keyed by the address of a level list that lives inside `host` (host.levels, an elimination
+  // range's bigLevels): the entries die with the plan, an address is never reused under them
+  std::map<const void*, SolveInvList> solveInvLists;
   DevBuf panels, srcs, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
-      updTasks, updTasksFat, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc,
-      elimPackSlot,
-      elimPairSlot, elimRows, elimRowSlots;
+      updTasks, updTasksFat, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc;
   int64_t numUpdTasks = 0;
   vector<int64_t> slowPrefix;  // tasks [0, i) that updateTileBulk cannot take
   // forward-solve gather lists, built on the first solve that needs them
@@ -136,10 +132,6 @@ struct DevPlan {
     }
     elimChainLump.upload(host.elimChainLump);
     elimLumpDesc.upload(host.elimLumpDesc);
-    elimPackSlot.upload(host.elimPackSlot);
-    elimPairSlot.upload(host.elimPairSlot);
-    elimRows.upload(host.elimRows);
-    elimRowSlots.upload(host.elimRowSlots);
     elimItems.upload(host.elimItems);
     elimPairOffJ.upload(host.elimPairOffJ);
     elimPairOffI.upload(host.elimPairOffI);
@@ -158,9 +150,6 @@ struct DevPlan {
     drop(host.updTasks);
     drop(host.elimChainLump);
     drop(host.elimLumpDesc);
-    drop(host.elimPairSlot);
-    drop(host.elimRows);
-    drop(host.elimRowSlots);
     drop(host.elimItems);
     drop(host.elimPairOffJ);
     drop(host.elimPairOffI);
@@ -191,9 +180,7 @@ struct PtrRing {
     dev.release();
     slotBytes = 0;
   }
-  // dstFixed: copy to that device address instead of the ring's own device slot (the pointer array a
-  // captured graph reads, below); the pinned staging slot still comes from the ring
-  const void* push(const void* src, size_t bytes, hipStream_t stream, void* dstFixed = nullptr) {
+  const void* push(const void* src, size_t bytes, hipStream_t stream) {
     if (bytes > slotBytes) {  // (first call, or a larger batch than ever before)
       if (slotBytes) hipCHECK(hipDeviceSynchronize());
       release();
@@ -206,7 +193,7 @@ struct PtrRing {
     next = (next + 1) % kSlots;
     if (used[s]) hipCHECK(hipEventSynchronize(ev[s]));
     std::memcpy(host + s * slotBytes, src, bytes);
-    char* d = dstFixed ? reinterpret_cast<char*>(dstFixed) : reinterpret_cast<char*>(dev.ptr) + s * slotBytes;
+    char* d = reinterpret_cast<char*>(dev.ptr) + s * slotBytes;
     hipCHECK(hipMemcpyAsync(d, host + s * slotBytes, bytes, hipMemcpyHostToDevice, stream));
     hipCHECK(hipEventRecord(ev[s], stream));
     used[s] = true;
@@ -278,9 +265,7 @@ struct LaunchTimer {
 // time per Solver is the contract (Solver.h); two Solvers factoring concurrently share these
 // streams and are merely ordered on them.
 struct SharedStreams {
-  hipStream_t side = nullptr, due = nullptr, elim = nullptr;
-  hipStream_t capture = nullptr;  // origin stream of graph captures (the caller's stream may be the
-                                  // legacy default stream, which cannot be captured)
+  hipStream_t side = nullptr, due = nullptr;
 };
 inline SharedStreams& sharedStreams() {
   static std::mutex mu;
@@ -296,10 +281,8 @@ inline SharedStreams& sharedStreams() {
     // chain on this stack (hipExtStreamCreateWithCUMask is not honoured: a masked saturating kernel
     // ran on all 256 CUs, tools/throttle_probe.hip), what does is s_setprio inside the chain kernels
     hipCHECK(hipStreamCreateWithPriority(&st.side, hipStreamNonBlocking, least));
-    const char* e = std::getenv("BSP_DUE_PRIO");  // (=1: highest priority for the due units -- measured: no effect)
-    hipCHECK(hipStreamCreateWithPriority(&st.due, hipStreamNonBlocking, (e && e[0] == '1') ? greatest : least));
-    hipCHECK(hipStreamCreateWithPriority(&st.elim, hipStreamNonBlocking, least));
-    hipCHECK(hipStreamCreateWithFlags(&st.capture, hipStreamNonBlocking));
+    // (highest priority for the due units: measured, no effect)
+    hipCHECK(hipStreamCreateWithPriority(&st.due, hipStreamNonBlocking, least));
   }
   return st;
 }
@@ -344,31 +327,12 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipSymbolicCtx(const CoalescedBlockMatrixSkel& skel_, const vector<int64_t>& permutation_)
       : skel(skel_), permutation(permutation_) {
     if (const char* e = std::getenv("BSP_NO_LOOKAHEAD")) lookaheadEnabled = e[0] == '0';
-    if (const char* e = std::getenv("BSP_BULK_EXTRA_LDS")) bulkExtraLds = dueExtraLds = (unsigned)atoi(e);
-    if (const char* e = std::getenv("BSP_DUE_EXTRA_LDS")) dueExtraLds = (unsigned)atoi(e);
-    if (const char* e = std::getenv("BSP_FUSE_POTRF")) fusePotrf = e[0] != '0';
     if (const char* e = std::getenv("BSP_BLOCK_SOLVE")) blockSolve = e[0] != '0';
     if (const char* e = std::getenv("BSP_SOLVE_INV")) solveInv = e[0] != '0';
-    if (const char* e = std::getenv("BSP_UPD_PREFETCH_WGS")) updPrefetchMaxWgs = std::atoll(e);
-    if (const char* e = std::getenv("BSP_TILE_YIELD")) tileYield = e[0] == '1';
-    if (const char* e = std::getenv("BSP_SPLIT_DIAG")) splitDiag = e[0] != '0';
-    if (const char* e = std::getenv("BSP_ELIM_FACTOR_DESC")) elimFactorDesc = e[0] != '0';
-    if (const char* e = std::getenv("BSP_ELIM_FACTOR_STAGED")) elimFactorStaged = e[0] != '0';
-    if (const char* e = std::getenv("BSP_GATHER_FUSED_LOAD")) gatherFusedLoad = atoi(e);
-    if (const char* e = std::getenv("BSP_DIRECT_CHAIN")) directChain = e[0] != '0';
-    if (const char* e = std::getenv("BSP_MERGED_CHAIN")) mergedChain = e[0] != '0';
-    if (const char* e = std::getenv("BSP_EARLY_FORK")) earlyFork = e[0] != '0';
-    if (const char* e = std::getenv("BSP_MERGED_BLOCK_LAST")) mergedBlockLast = e[0] != '0';
-    if (const char* e = std::getenv("BSP_BULK_KERNEL")) bulkKernel = e[0] != '0';
-    if (const char* e = std::getenv("BSP_BULK_YIELD")) bulkYield = e[0] != '0';
-    if (const char* e = std::getenv("BSP_EARLY_DIAG")) earlyDiag = e[0] != '0';
-    if (const char* e = std::getenv("BSP_MERGE_DEF")) mergeDeferred = e[0] != '0';
     // the plan builder's switches: read here, once per Solver, handed to every buildHipPlan call
-    // and recorded in the plan; launchLevels takes dueStream / dueSplit from the plan it runs
+    // and recorded in the plan; launchLevels takes dueStream from the plan it runs
     planOpts = HipPlanOptions::fromEnv();
-    nowSplit = planOpts.nowSplit;
     if (const char* e = std::getenv("BSP_LOOKAHEAD_MIN_GF")) lookaheadMinFlops = 1e9 * std::atof(e);
-    if (const char* e = std::getenv("BSP_GRAPH")) graphMode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -378,6 +342,49 @@ struct HipSymbolicCtx : SymbolicCtx {
   virtual void setSparseElimRanges(const vector<int64_t>& ranges) override {
     sparseElimRanges = ranges;
     plans.clear();
+    prepareDevice();
+  }
+
+  // The reference builds its SymbolicCtx and every SymElimCtx in the Solver constructor
+  // (Solver.cpp:24-40), so that its first factor() costs what every later one does.  Same here: when
+  // a GPU is visible at construction, the full-range factor plan is built and uploaded, the skeleton
+  // mirrors, scratch buffers, auxiliary streams and the event pool are created and the kernels' code
+  // object is loaded (one empty launch) -- all on the device that is current NOW.  A Solver whose
+  // first real use happens with another device current re-binds there (nothing of the eager state
+  // has been handed out yet); plans of partial ranges stay lazy.  Without a GPU (symbolic analysis
+  // on a host-only box) nothing happens here.
+  void prepareDevice() {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+      (void)hipGetLastError();
+      return;
+    }
+    if (std::getenv("BSP_LAZY_PLAN")) return;  // (A/B: the lazy behaviour of rounds 1-3)
+    struct Scope {
+      bool& f;
+      explicit Scope(bool& f_) : f(f_) { f = true; }
+      ~Scope() { f = false; }
+    } scope(inPrepare);
+    const int64_t nLumps = (int64_t)skel.lumpStart.size() - 1;
+    if (nLumps <= 0) return;
+    DevPlan& plan = planFor(sparseElimRanges, 0, nLumps, /*tag=*/0);
+    ensureSkelOnDevice();
+    (void)streams();
+    (void)yieldWord();
+    // scratch of the chain kernels, sized for one fp64 matrix (grown later for batches)
+    dinvScratch.resize((size_t)hipk::kDinvBatchStride * sizeof(double));
+    if (plan.host.maxChainRows > 0) {
+      rawScratch.resize((size_t)2 * plan.host.maxChainRows * kTile * sizeof(double));
+    }
+    const size_t wantEvents = 8 + 4 * (size_t)plan.host.numForkLevels;
+    while (events.size() < wantEvents) {
+      hipEvent_t e;
+      hipCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      events.push_back(e);
+    }
+    hipk::warmupKernel<<<1, 64, 0, stream>>>();
+    hipCHECK(hipStreamSynchronize(stream));
+    eagerOnly = true;
   }
 
   virtual void setStream(void* s) override { stream = (hipStream_t)s; }
@@ -388,6 +395,26 @@ struct HipSymbolicCtx : SymbolicCtx {
     int cur = -1;
     hipCHECK(hipGetDevice(&cur));
     if (device < 0) device = cur;
+    if (cur != device && eagerOnly) {
+      // only the constructor's eager state lives on `device`: move to the device of the first use
+      // (a device buffer is freed on whatever device is current)
+      plans.clear();
+      for (hipEvent_t e : events) (void)hipEventDestroy(e);
+      events.clear();
+      nextEvent = 0;
+      dinvScratch.release();
+      rawScratch.release();
+      yieldBuf.release();
+      for (DevBuf* b : {&dSpanStart, &dSpanToLump, &dLumpStart, &dSpanOffsetInLump, &dChainColPtr,
+                        &dChainRowSpan, &dChainData, &dChainRowsTillEnd, &dBoardColPtr,
+                        &dBoardChainColOrd, &dPermutation}) {
+        b->release();
+      }
+      skelUploaded = false;
+      shared = nullptr;
+      device = cur;
+    }
+    if (!inPrepare) eagerOnly = false;
     if (cur != device) {
       throw std::runtime_error("HIP backend: this Solver was first used on device " +
                                std::to_string(device) + " but the current device is " +
@@ -479,15 +506,13 @@ struct HipSymbolicCtx : SymbolicCtx {
   // it runs on (cooperative CU yield, hip_kernels.h)
   unsigned* yieldWord() {
     if (!yieldBuf.ptr) {
-      // word 0: the potrf workgroup's CU; words 64 .. 64 + 2048: chain tiles counted per CU (TILE YIELD)
-      const size_t bytes = 4 * (hipk::kYieldTableOffset + hipk::kYieldTableSize);
+      const size_t bytes = 256;  // word 0: the potrf workgroup's CU
       yieldBuf.resize(bytes);
       hipCHECK(hipMemset(yieldBuf.ptr, 0, bytes));
     }
     return reinterpret_cast<unsigned*>(yieldBuf.ptr);
   }
   hipStream_t dueSideStream() { return streams().due; }
-  hipStream_t elimStream() { return streams().elim; }
   hipEvent_t eventFromPool() {
     if (nextEvent == events.size()) {
       hipEvent_t e;
@@ -505,31 +530,19 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipKernelProfile* profile = nullptr;
   bool profileInSitu = false;  // profile with the lookahead schedule left on (two streams)
   bool lookaheadEnabled = true;
-  unsigned bulkExtraLds = 6 * 1024;
-  unsigned dueExtraLds = 6 * 1024;  // LDS padding of the due units' launches (BSP_DUE_EXTRA_LDS)
+  // LDS padding of side-stream launches: three bulk workgroups per CU, so that a chain workgroup
+  // always finds a slot
+  static constexpr unsigned bulkExtraLds = 6 * 1024, dueExtraLds = 6 * 1024;
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
   SharedStreams* shared = nullptr;  // this device's auxiliary streams (streams())
-  HipPlanOptions planOpts;     // the plan builder's switches (BSP_DUE_STREAM, BSP_DUE_SPLIT, BSP_BULK_ROW_MAJOR, ...)
-  bool mergeDeferred = false;  // BSP_MERGE_DEF=1: due + optional lookahead units of a block in one launch
+  HipPlanOptions planOpts;     // the plan builder's switches (BSP_DUE_STREAM, BSP_BULK_AHEAD, ...)
   double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
-  int graphMode = 0;           // factor() as a captured hipGraph (BSP_GRAPH): 0 never (default: measured no faster, see factorViaGraph), 1 always, 2 launch-bound plans only
-  bool earlyDiag = true;       // intra-block chain steps pre-apply their panel to the next block's tile (0,0) (BSP_EARLY_DIAG=0 disables)
-  bool nowSplit = false;       // opt-in BSP_NOW_SPLIT=1: block-last steps leave column tiles 2-3 of their now-update to the next two steps
-  bool bulkYield = true;       // bulk tiles pause on the CU of the chain's potrf workgroup (BSP_BULK_YIELD=0 disables)
-  int gatherFusedLoad = 1;  // MFMA gather, wave loads per pair (BSP_GATHER_FUSED_LOAD): 1 -> one (both blocks of a pair; default), 0 -> two, 2 -> half (fp64: two pairs per 16-byte-per-lane load through an LDS slot; measured 1.15 against 1.17 ms for the kernel and nothing for factor(): at 5.2 TB/s of fetch the kernel is on the memory system, not the texture addresser, any more)
-  bool elimFactorStaged = true; // ... staged through LDS with coalesced wave loads (BSP_ELIM_FACTOR_STAGED=0: direct loads, K1t)
-  bool elimFactorDesc = true;  // descriptor-driven factor of <= 4-wide eliminated lumps
-  bool splitDiag = true;    // tile-0 update of a block-wide segment split between the trsm launch and the potrf workgroup
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
-  bool fusePotrf = true;    // next panel's potrf inside the update launch (BSP_FUSE_POTRF=0 disables)
-  bool bulkKernel = true;   // self-contained tasks + 16-byte staging for plain intra-lump tiles (BSP_BULK_KERNEL=0: table-driven updateTile)
-  bool mergedBlockLast = true;  // the block-last step (rank-256 now-update) as one chain-step launch too
-  bool earlyFork = true;    // fork the side stream before the level's own update launch (BSP_EARLY_FORK=0: after)
-  bool mergedChain = true;  // trsm + update (+ next potrf) of an intra-block step in one launch (BSP_MERGED_CHAIN=0 disables)
-  bool directChain = true;  // descriptor-by-value kernels on one-panel levels (BSP_DIRECT_CHAIN=0 disables)
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
   int device = -1;  // device of the first use (checkDevice)
+  bool inPrepare = false;
+  bool eagerOnly = false;  // so far only prepareDevice() has touched `device` (cleared by the first plan use)
   int traceLaunchId = 0;  // ordinal of the chain-step launches (trace builds only)
   // scratch that outlives the per-call NumericCtx / SolveCtx objects (those are created and
   // destroyed around every factor() / solve(), Solver.cpp:176,223, while their kernels may still be
@@ -538,19 +551,9 @@ struct HipSymbolicCtx : SymbolicCtx {
   // block solves through inverted diagonal blocks (denseLevels): the inverses of one solve call, and
   // per level list the panels whose diagonal blocks are inverted (uploaded once)
   DevBuf solveInvScratch;
-  struct SolveInvList {
-    bool built = false;
-    int64_t count = 0;
-    DevBuf list;
-    vector<int32_t> slotOfGroup;
-  };
-  std::map<const void*, SolveInvList> solveInvLists;
   bool solveInv = true;  // BSP_SOLVE_INV=0: the substitution kernels of rounds 1-2
-  bool tileYield = false;  // BSP_TILE_YIELD=1: bulk workgroups also pause for the chain's ordinary tiles
-  int64_t updPrefetchMaxWgs = 2048;  // updateTile<PREFETCH> for launches of up to this many workgroups (BSP_UPD_PREFETCH_WGS; -1: never)
-  DevBuf elimPackBuf;  // packed copy of the solved blocks of a sparse-elimination range (BSP_ELIM_PACK=1)
+  static constexpr int64_t updPrefetchMaxWgs = 2048;  // updateTile<PREFETCH> for launches of up to this many workgroups
   PtrRing ptrRing;
-  bool rowFormAttrSet[2] = {false, false};  // elimRowMfma dynamic-LDS attribute (fp64, fp32)
   std::map<std::pair<int64_t, int64_t>, std::pair<std::unique_ptr<DevBuf>, size_t>> addMvTileLists;
 
   bool skelUploaded = false;
@@ -578,21 +581,20 @@ struct HipNumericCtx : NumericCtx<T> {
   void launchUpdate(DevPlan& plan, int64_t begin, int64_t end, hipk::DataRef<BT> ref,
                     hipStream_t stream, BT* altTarget = nullptr, int64_t altStride = 0,
                     unsigned extraLds = 0, int atomicMask = 1) {
-    if (sym.bulkKernel && altTarget == nullptr && end < (int64_t)plan.slowPrefix.size() &&
+    if (altTarget == nullptr && end < (int64_t)plan.slowPrefix.size() &&
         plan.slowPrefix[end] == plan.slowPrefix[begin]) {
       // (32 KB of static LDS instead of updateTile's 34.8: 3 KB more padding keeps it at three
       //  workgroups per CU next to a chain workgroup)
       const unsigned pad = extraLds ? extraLds + 3072 : 0;
       // (cooperative CU yield, hip_kernels.h: side-stream launches of a single matrix only)
-      const unsigned* yf = (extraLds && batchSize == 1 && sym.bulkYield) ? sym.yieldWord() : nullptr;
+      const unsigned* yf = (extraLds && batchSize == 1) ? sym.yieldWord() : nullptr;
       hipk::updateTileBulk<BT><<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, pad,
-                                stream>>>(plan.updTasksFat.as<UpdTaskFat>() + begin, ref, yf,
-                                          atomicMask | ((yf && sym.tileYield) ? 0x100 : 0));
+                                stream>>>(plan.updTasksFat.as<UpdTaskFat>() + begin, ref, yf, atomicMask);
       return;
     }
     // (launches of at most ~2 rounds of workgroups: the latency-bound variant, hip_kernels.h)
     const int64_t wgs = (end - begin) * (int64_t)batchSize;
-    const bool few = sym.updPrefetchMaxWgs >= 0 && wgs <= sym.updPrefetchMaxWgs;
+    const bool few = wgs <= sym.updPrefetchMaxWgs;
     auto kern = few ? hipk::updateTile<BT, true> : hipk::updateTile<BT, false>;
     // (Asking for enough dynamic LDS that only ceil(workgroups / CUs) of a small launch fit on a CU,
     //  in case the dispatcher packs them four to a CU: no effect at batch 1 / 8 / 64 -- it does not.)
@@ -610,57 +612,25 @@ struct HipNumericCtx : NumericCtx<T> {
     return (sym.profile == nullptr || sym.profileInSitu) && sym.lookaheadEnabled;
   }
 
-  // gatherDone (overlapped elimination, launchElim): one event per gather group, recorded on the
-  // elimination stream; levels name the group they need (LevelRange::waitGather / defWaitGather*)
   void launchLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::DataRef<BT> ref,
-                    LaunchTimer& timer, const vector<hipEvent_t>* gatherDone = nullptr) {
+                    LaunchTimer& timer) {
     const dim3 gy(1, (unsigned)batchSize, 1);
     // (side streams only when the lookahead units are worth their forks, HipPlanHost::lookaheadPays;
     //  otherwise the same launches go in line)
     const bool lookahead = lookaheadOn() && plan.host.lookaheadPays(batchSize, sym.lookaheadMinFlops);
-    int waitedMain = -1, waitedSide = -1, waitedDue = -1;  // gather groups the streams already wait for
-    auto waitGather = [&](hipStream_t st, int group, int& waited) {
-      if (!gatherDone || group <= waited) return;
-      group = std::min<int>(group, (int)gatherDone->size() - 1);
-      if (group > waited) hipCHECK(hipStreamWaitEvent(st, (*gatherDone)[group], 0));
-      waited = group;
-    };
     vector<hipEvent_t> defDone(levels.size(), nullptr);  // due units of a level complete
     vector<hipEvent_t> optDone(levels.size(), nullptr);  // ... its optional units (due-stream mode)
-    vector<hipEvent_t> due0Done(levels.size(), nullptr); // ... the first column tile of its due units
-    // NOW SPLIT (LevelRange::nowHeadTiles): a block-last step left the finished block's rank-256
-    // update of the next block's column tiles 2 and 3 to that block's first two steps
-    struct Carry {
-      int64_t level = -1;    // the block-last level that split (its soon task lists are the fallback)
-      int64_t srcOff = 0;    // SrcDesc::off of the finished block (row 0 = first row of the next block)
-      int32_t lda = 0, K = 0, lump = -1;
-      int step = 0;          // steps of the next block that took their column tile so far (0..2)
-    } carry;
-    // fallback: a carried column tile that no merged chain step can take goes as plain bulk tiles
-    auto flushCarry = [&]() {
-      if (carry.level < 0) return;
-      const LevelRange& bl = levels[carry.level];
-      const int64_t b = carry.step == 0 ? bl.soonBegin : bl.soonMid;
-      if (carry.step < 2 && bl.soonEnd > b) {
-        timer.begin(kProfUpdate);
-        launchUpdate(plan, b, bl.soonEnd, ref, sym.stream);
-        timer.end();
-      }
-      carry.level = -1;
-    };
     // (fp32: its atomics cost more than the second stream returns -- BAL-871 5.86 against 5.22 ms,
     //  BAL-1723 20.5 against 18.8 -- so single-precision calls keep the one-side-stream order, and
     //  the tasks' "two streams may meet" bit is masked off)
-    const bool dueStream = plan.host.opts.dueStream && !sym.mergeDeferred && sizeof(BT) == 8;
+    const bool dueStream = plan.host.opts.dueStream && sizeof(BT) == 8;
     const int sideMask = dueStream ? 3 : 1;
     // fork level of the same lump's previous block (-1: none)
     auto prevFork = [&](int64_t f) -> int64_t { return f >= 0 ? levels[f].waitDefLevel : -1; };
-    // firstTileOnly (DUE SPLIT): the caller only needs the first column tile of the due units
-    // complete (it accumulates into the others with atomics)
-    auto waitDeferred = [&](int64_t f, bool firstTileOnly = false) {
+    auto waitDeferred = [&](int64_t f) {
       // everything the side streams owe to the column block this level is about to touch
       if (f < 0 || !defDone[f]) return;
-      hipCHECK(hipStreamWaitEvent(sym.stream, (firstTileOnly && due0Done[f]) ? due0Done[f] : defDone[f], 0));
+      hipCHECK(hipStreamWaitEvent(sym.stream, defDone[f], 0));
       const int64_t pf = prevFork(f);
       if (dueStream && pf >= 0 && optDone[pf]) hipCHECK(hipStreamWaitEvent(sym.stream, optDone[pf], 0));
     };
@@ -674,7 +644,7 @@ struct HipNumericCtx : NumericCtx<T> {
     // staging buffer of the chain (chainStep): unsolved rows of the current / next panel
     const int64_t rawSlot = plan.host.maxChainRows * kTile;
     BT* rawBase = nullptr;
-    if (rawSlot > 0 && sym.mergedChain) {
+    if (rawSlot > 0) {
       sym.rawScratch.resize((size_t)batchSize * 2 * rawSlot * sizeof(BT));
       rawBase = const_cast<BT*>(sym.rawScratch.as<BT>());
     }
@@ -684,14 +654,11 @@ struct HipNumericCtx : NumericCtx<T> {
     // applies the rest from memory
     int extraApplied = 0;
     bool extraBroken = false;
-    const bool earlyDiag = sym.earlyDiag && sym.mergedChain && sym.mergedBlockLast && sym.fusePotrf &&
-                           sym.directChain;
     for (size_t li = 0; li < levels.size(); li++) {
       const LevelRange& lr = levels[li];
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
-      const bool direct = sym.directChain && lr.directPanel >= 0;
-      waitGather(sym.stream, lr.waitGather, waitedMain);
+      const bool direct = lr.directPanel >= 0;
       const int slot = dinvSlot;
       dinvSlot ^= 1;
       BT* dinvCur = dinvBase + slot * hipk::kDinvSlot;
@@ -713,10 +680,9 @@ struct HipNumericCtx : NumericCtx<T> {
       }
       // (decided before the trsm launch: with splitK one extra workgroup of that launch already
       //  touches tile 0 of the block-wide segment)
-      const bool fuse = direct && lr.directSeg >= 0 && lr.fuseNext && sym.fusePotrf &&
-                        li + 1 < levels.size() && levels[li + 1].directPanel >= 0 &&
-                        lr.updEnd > lr.updBegin;
-      int splitK = (fuse && sym.splitDiag && nT) ? lr.splitK : 0;
+      const bool fuse = direct && lr.directSeg >= 0 && lr.fuseNext && li + 1 < levels.size() &&
+                        levels[li + 1].directPanel >= 0 && lr.updEnd > lr.updBegin;
+      int splitK = (fuse && nT) ? lr.splitK : 0;
       const bool directUpd = direct && lr.directSeg >= 0 && lr.updEnd > lr.updBegin;
       // does this level's update stage the next panel's rows?
       const bool stage = rawBase && directUpd && lr.rawNext && li + 1 < levels.size() &&
@@ -735,8 +701,8 @@ struct HipNumericCtx : NumericCtx<T> {
         const PanelDesc& pdc = plan.host.panels[lr.directPanel];
         if (!sd.outer && sr.K == pdc.nb) {
           merged = true;
-        } else if (sd.outer == 1 && sym.mergedBlockLast && sr.K > pdc.nb &&
-                   (sr.K - pdc.nb) % kTile == 0 && sr.rowsBelow == pdc.rowsBelow && sr.lda == pdc.lda) {
+        } else if (sd.outer == 1 && sr.K > pdc.nb && (sr.K - pdc.nb) % kTile == 0 &&
+                   sr.rowsBelow == pdc.rowsBelow && sr.lda == pdc.lda) {
           merged = true;
           memOff = sr.off;
           kMem = sr.K - pdc.nb;
@@ -766,61 +732,8 @@ struct HipNumericCtx : NumericCtx<T> {
         timer.end();
       }
       // (a second wait on the same event would still cost a ~6 us bubble between the launches)
-      // DUE SPLIT: a merged block-last step waits for the first column tile of the due units only
-      const bool nowAtomic = merged && kMem > 0 && lookahead && dueStream && lr.waitDefLevel >= 0 &&
-                             due0Done[lr.waitDefLevel] != nullptr;
-      // NOW SPLIT: does this step take the carried column tile?  (merged intra-block step of the
-      // same lump whose segment holds at least the column tile in question and one before it)
-      int memColBegin = 0, memColEnd = INT32_MAX;
-      if (carry.level >= 0) {
-        bool take = false;
-        if (merged && kMem == 0 && lr.directSeg >= 0) {
-          const SegDesc& sd = plan.host.segs[lr.directSeg];
-          const PanelDesc& pdc = plan.host.panels[lr.directPanel];
-          take = pdc.lump == carry.lump && pdc.lda == carry.lda && !sd.outer && sd.kind == kSegIntra &&
-                 sd.q0 == 0 && sd.m >= 2 * kTile && pdc.nb == kPanelWidth;
-        }
-        if (take) {
-          // rows of the finished block's source are indexed from the next block's first row; this
-          // panel's rows below start 64 (step 0) or 128 (step 1) rows further down
-          memOff = carry.srcOff + (int64_t)kTile * (carry.step + 1) * carry.lda;
-          kMem = carry.K;
-          memColBegin = kTile;
-          memColEnd = 2 * kTile;
-          if (++carry.step == 2) carry.level = -1;
-        } else {
-          flushCarry();
-        }
-      }
-      const bool carried = memColEnd != INT32_MAX;
-      // CHAIN WINDOW segment (SegDesc::pad bit 2): its tiles in the NEXT outer block's columns may
-      // meet lookahead units of the side streams (none yet before this chain's first fork; all
-      // waited for at a block-last panel, bit 3).  The merged chain kernel subtracts there with
-      // atomics; any other kernel of the fallback modes joins the side streams first.
-      int atomicFromCol = INT32_MAX;
-      if (nowAtomic && lr.directSeg >= 0) atomicFromCol = plan.host.segs[lr.directSeg].q0 + kTile;
-      if (lookahead && lr.directSeg >= 0 && (sideUsed || dueUsed)) {
-        const SegDesc& sd = plan.host.segs[lr.directSeg];
-        if ((sd.pad & 4) && !(sd.pad & 8)) {
-          if (merged || direct) {   // (the direct chain kernels take the column from here on)
-            atomicFromCol = sd.q0 + sd.firstChainOrd;
-          } else {
-            hipEvent_t j1 = sym.eventFromPool();
-            hipCHECK(hipEventRecord(j1, sym.sideStream()));
-            hipCHECK(hipStreamWaitEvent(sym.stream, j1, 0));
-            if (dueUsed) {
-              hipEvent_t j2 = sym.eventFromPool();
-              hipCHECK(hipEventRecord(j2, sym.dueSideStream()));
-              hipCHECK(hipStreamWaitEvent(sym.stream, j2, 0));
-            }
-          }
-        }
-      }
       if (!waitedDef && lookahead && lr.waitDefLevel >= 0 && defDone[lr.waitDefLevel]) {
-        waitDeferred(lr.waitDefLevel, nowAtomic);
-      }
-      if (lookahead && lr.waitDue1Level >= 0 && defDone[lr.waitDue1Level]) {
-        hipCHECK(hipStreamWaitEvent(sym.stream, defDone[lr.waitDue1Level], 0));
+        waitDeferred(lr.waitDefLevel);
       }
       const bool anyDef = lr.defEnd > lr.defBegin;
       auto forkSide = [&]() {
@@ -833,17 +746,6 @@ struct HipNumericCtx : NumericCtx<T> {
         // first the tiles the next block's own update must wait for, then (event) the rest:
         // the side stream keeps running them while the chain goes on, and the next block's
         // deferred tiles queue up right behind
-        if (sym.mergeDeferred && lr.defEnd > lr.defBegin) {
-          // (experiment: due and optional units of a block as ONE launch, due tiles first)
-          waitGather(sym.sideStream(), lr.defWaitGatherEnd, waitedSide);
-          timer.begin(kProfUpdate, sym.sideStream());
-          launchUpdate(plan, lr.defBegin, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds, sideMask);
-          timer.end();
-          defDone[li] = sym.eventFromPool();
-          hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
-          sideUsed = true;
-          return;
-        }
         if (dueStream) {
           // due units on their own stream, beside the optional ones (both accumulate with atomics
           // where they can meet: hip_plan.cpp, pushUnit).  They must not overtake the optional
@@ -853,31 +755,16 @@ struct HipNumericCtx : NumericCtx<T> {
           const int64_t f2 = lr.optWaitLevel;
           if (f2 >= 0 && optDone[f2]) hipCHECK(hipStreamWaitEvent(due, optDone[f2], 0));
           if (lr.defMid > lr.defBegin) {
-            waitGather(due, lr.defWaitGatherMid, waitedDue);
-            if (plan.host.opts.dueSplit && lr.defMid0 > lr.defBegin && lr.defMid > lr.defMid0) {
-              timer.begin(kProfUpdate, due);
-              launchUpdate(plan, lr.defBegin, lr.defMid0, ref, due, nullptr, 0, sym.dueExtraLds, sideMask);
-              timer.end();
-              due0Done[li] = sym.eventFromPool();
-              hipCHECK(hipEventRecord(due0Done[li], due));
-              timer.begin(kProfUpdate, due);
-              launchUpdate(plan, lr.defMid0, lr.defMid, ref, due, nullptr, 0, sym.dueExtraLds, sideMask);
-              timer.end();
-            } else {
-              timer.begin(kProfUpdate, due);
-              launchUpdate(plan, lr.defBegin, lr.defMid, ref, due, nullptr, 0, sym.dueExtraLds, sideMask);
-              timer.end();
-            }
+            timer.begin(kProfUpdate, due);
+            launchUpdate(plan, lr.defBegin, lr.defMid, ref, due, nullptr, 0, sym.dueExtraLds, sideMask);
+            timer.end();
           }
           defDone[li] = sym.eventFromPool();
           hipCHECK(hipEventRecord(defDone[li], due));
           if (lr.defEnd > lr.defMid) {
-            waitGather(sym.sideStream(), lr.defWaitGatherEnd, waitedSide);
             timer.begin(kProfUpdate, sym.sideStream());
             launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds, sideMask);
             timer.end();
-          }
-          if (lr.defEnd > lr.defMid) {  // (an early-due level has no optional units)
             optDone[li] = sym.eventFromPool();
             hipCHECK(hipEventRecord(optDone[li], sym.sideStream()));
           }
@@ -885,7 +772,6 @@ struct HipNumericCtx : NumericCtx<T> {
           return;
         }
         if (lr.defMid > lr.defBegin) {
-          waitGather(sym.sideStream(), lr.defWaitGatherMid, waitedSide);
           timer.begin(kProfUpdate, sym.sideStream());
           launchUpdate(plan, lr.defBegin, lr.defMid, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds, sideMask);
           timer.end();
@@ -893,7 +779,6 @@ struct HipNumericCtx : NumericCtx<T> {
         defDone[li] = sym.eventFromPool();
         hipCHECK(hipEventRecord(defDone[li], sym.sideStream()));
         if (lr.defEnd > lr.defMid) {
-          waitGather(sym.sideStream(), lr.defWaitGatherEnd, waitedSide);
           timer.begin(kProfUpdate, sym.sideStream());
           launchUpdate(plan, lr.defMid, lr.defEnd, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds, sideMask);
           timer.end();
@@ -902,32 +787,17 @@ struct HipNumericCtx : NumericCtx<T> {
       };
       // (the lookahead units read this level's panel columns and write columns the level's own
       //  update does not touch: they can be forked before it)
-      const bool forkEarly = sym.earlyFork && !merged;  // (merged: the panel is solved in the launch)
+      const bool forkEarly = !merged;  // (merged: the panel is solved in the launch)
       if (lookahead && anyDef && forkEarly) forkSide();
       const int64_t updBegin = lr.updBegin;
       if (lr.updEnd > updBegin) {
         timer.begin(direct && lr.directSeg >= 0 ? kProfChainUpdate : kProfUpdate);
-        unsigned nUpd = (unsigned)(lr.updEnd - updBegin);
-        // NOW SPLIT: only the first two column tiles of the block-wide update stay in this launch
-        const bool split = merged && kMem > 0 && !carried && fuse && sym.nowSplit &&
-                           lr.soonEnd > lr.soonBegin && lr.nowHeadTiles > 0 &&
-                           (unsigned)lr.nowHeadTiles < nUpd && li + 2 < levels.size();
-        if (split) {
-          const SegDesc& sd = plan.host.segs[lr.directSeg];
-          const SrcDesc& sr = plan.host.srcs[sd.src];
-          nUpd = (unsigned)lr.nowHeadTiles;
-          carry.level = (int64_t)li;
-          carry.srcOff = sr.off;
-          carry.lda = sr.lda;
-          carry.K = sr.K;
-          carry.lump = plan.host.panels[lr.directPanel].lump;
-          carry.step = 0;
-        }
+        const unsigned nUpd = (unsigned)(lr.updEnd - updBegin);
         if (merged) {
           int kMem0 = kMem, extra = 0;
-          if (kMem == 0 || carried) {  // intra-block step
+          if (kMem == 0) {  // intra-block step
             kMem0 = 0;
-            if (earlyDiag && lr.extraDiag && !extraBroken && fuse) {
+            if (lr.extraDiag && !extraBroken && fuse) {
               extra = 1;
               extraApplied++;
             } else {
@@ -940,10 +810,9 @@ struct HipNumericCtx : NumericCtx<T> {
           }
           hipk::chainStep<BT><<<dim3(nUpd + extra, gy.y), 256, 0, sym.stream>>>(
               plan.host.panels[lr.directPanel], plan.host.segs[lr.directSeg], (int)nUpd, nextPanel,
-              (fuse ? 1 : 0) | ((lookahead && batchSize == 1 && sym.bulkYield && sym.tileYield) ? 2 : 0), ref,
-              rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
-              memOff, kMem, (lookahead && batchSize == 1 && sym.bulkYield) ? sym.yieldWord() : nullptr,
-              sym.traceLaunchId++, kMem0, extra, atomicFromCol, memColBegin, memColEnd);
+              fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
+              memOff, kMem, (lookahead && batchSize == 1) ? sym.yieldWord() : nullptr,
+              sym.traceLaunchId++, kMem0, extra);
           potrfFused = fuse;
         } else if (fuse) {
           if (extraApplied > 0) {
@@ -954,7 +823,7 @@ struct HipNumericCtx : NumericCtx<T> {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
           hipk::updateTileDirectPotrf<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
               plan.host.srcs[sd.src], sd, (int)nUpd, nextPanel, ref, splitK, dinvNext,
-              stage ? rawNext : nullptr, 2 * rawSlot, atomicFromCol);
+              stage ? rawNext : nullptr, 2 * rawSlot);
           potrfFused = true;
         } else if (direct && lr.directSeg >= 0) {
           if (extraApplied > 0) {
@@ -965,7 +834,7 @@ struct HipNumericCtx : NumericCtx<T> {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
           hipk::updateTileDirect<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
               plan.host.srcs[sd.src], sd, (int)nUpd, ref, stage ? rawNext : nullptr, nextPanel.nb,
-              2 * rawSlot, atomicFromCol);
+              2 * rawSlot);
         } else {
           launchUpdate(plan, updBegin, lr.updEnd, ref, sym.stream);
         }
@@ -986,7 +855,6 @@ struct HipNumericCtx : NumericCtx<T> {
         }
       }
     }
-    flushCarry();  // (a split is only planned with two more steps to come: nothing left here)
     if (sideUsed) {  // join: everything on the side stream(s) happens-before what follows
       hipEvent_t join = sym.eventFromPool();
       hipCHECK(hipEventRecord(join, sym.sideStream()));
@@ -997,46 +865,21 @@ struct HipNumericCtx : NumericCtx<T> {
       hipCHECK(hipEventRecord(join, sym.dueSideStream()));
       hipCHECK(hipStreamWaitEvent(sym.stream, join, 0));
     }
-    // (and everything on the elimination stream)
-    if (gatherDone && !gatherDone->empty()) waitGather(sym.stream, (int)gatherDone->size() - 1, waitedMain);
   }
 
   void launchElim(DevPlan& plan, const ElimRangePlan& er, hipk::DataRef<BT> ref,
-                  LaunchTimer& timer, vector<hipEvent_t>* gatherDoneOut = nullptr) {
+                  LaunchTimer& timer) {
     hipk::SkelDev sk = sym.skelDev();
     const unsigned gy = (unsigned)batchSize;
     const int64_t nLumps = er.lumpEnd - er.lumpBegin;
     if (nLumps <= 0) return;
     const unsigned gF = (unsigned)((nLumps + 3) / 4);
     timer.begin(kProfElimFactor);
-    // packed copy of the solved blocks for the gather update (ElimRangePlan::packRows)
-    const bool packed = er.packRows > 0 && er.maxWidth <= 4 && sym.elimFactorDesc && er.useGather &&
-                        !er.useRowForm;
-    if (er.packRows > 0 && !packed) {
-      throw std::runtime_error("HIP backend: this plan's sparse-elimination update reads packed operands "
-                               "(BSP_ELIM_PACK=1), which the selected kernels do not write");
-    }
-    const int64_t packStride = er.packSlots * kElimPackSlot;
-    BT* packBuf = nullptr;
-    if (packed) {
-      sym.elimPackBuf.resize((size_t)(packStride * batchSize) * sizeof(BT));
-      packBuf = reinterpret_cast<BT*>(sym.elimPackBuf.ptr);
-    }
-    if (er.maxWidth <= 4 && sym.elimFactorDesc && sym.elimFactorStaged && !packed) {
+    if (er.maxWidth <= 4) {
       const int64_t perWg = 4 * hipk::kTinyPerWave;
       hipk::elimFactorTinyStaged<BT><<<dim3((unsigned)((nLumps + perWg - 1) / perWg), gy), 256, 0,
                                       sym.stream>>>(
           plan.elimLumpDesc.as<ElimLumpDesc>() + er.descBegin, ref, (int)nLumps);
-    } else if (er.maxWidth <= 4 && sym.elimFactorDesc) {
-      const int64_t perWg = 4 * hipk::kTinyPerWave;
-      hipk::elimFactorTiny<BT><<<dim3((unsigned)((nLumps + perWg - 1) / perWg), gy), 256, 0,
-                                sym.stream>>>(
-          plan.elimLumpDesc.as<ElimLumpDesc>() + er.descBegin, ref, (int)nLumps,
-          packed ? plan.elimPackSlot.as<int32_t>() + er.packSlotOff : nullptr, er.packRows, packBuf,
-          packStride);
-    } else if (er.maxWidth <= 4) {
-      hipk::elimFactorSmall<BT, 4><<<dim3(gF, gy), 256, 0, sym.stream>>>(sk, ref, er.lumpBegin,
-                                                                        er.lumpEnd);
     } else if (er.maxWidth <= 8) {
       hipk::elimFactorSmall<BT, 8><<<dim3(gF, gy), 256, 0, sym.stream>>>(sk, ref, er.lumpBegin,
                                                                         er.lumpEnd);
@@ -1047,52 +890,22 @@ struct HipNumericCtx : NumericCtx<T> {
     timer.end();
     launchLevels(plan, er.bigLevels, ref, timer);
     const int64_t nChains = er.chainEnd - er.chainBegin;
-    // FAULT INJECTION (BSP_FAULT_DROP_ELIM_UPDATE=1, tests only): the whole sparse-elimination
-    // update is dropped -- the factor of everything the eliminated columns touch is then wrong, and
-    // the full-size parity tests must notice (tests/test_full_size_gpu.py)
-    if (plan.host.opts.dropElimUpdate) return;
-    if (er.useRowForm) {
-      const int64_t nRows = er.rowEnd - er.rowBegin;
-      const int ldsBytes = sizeof(BT) == 8 ? er.rowLdsBytes : er.rowLdsBytesF32;
-      bool& attrSet = sym.rowFormAttrSet[sizeof(BT) == 8 ? 0 : 1];  // per device = per Solver
-      if (!attrSet) {
-        hipCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hipk::elimRowMfma<BT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attrSet = true;
-      }
-      timer.begin(kProfElimUpdate);
-      hipk::elimRowMfma<BT><<<dim3((unsigned)nRows, gy), 1024, (size_t)ldsBytes, sym.stream>>>(
-          plan.elimRows.as<ElimRowItem>() + er.rowBegin, plan.elimRowSlots.as<ElimRowSlot>(),
-          plan.elimPairOffJ.as<uint32_t>(), plan.elimPairOffI.as<uint32_t>(),
-          plan.elimPairSlot.as<uint16_t>(), ref, (uint32_t)(sym.skel.dataSize() - 1));
-      timer.end();
-    } else if (er.useGather && er.overlapLump >= 0 && lookaheadOn() && plan.host.opts.elimOverlap &&
-               gatherDoneOut != nullptr) {
-      // OVERLAPPED with the dense phase: the groups (items by outer block of the target column)
-      // run in order on a stream of their own; the caller hands the events to launchLevels
-      hipEvent_t fork = sym.eventFromPool();
-      hipCHECK(hipEventRecord(fork, sym.stream));
-      hipCHECK(hipStreamWaitEvent(sym.elimStream(), fork, 0));
-      for (size_t q = 0; q + 1 < er.groupItem.size(); q++) {
-        const int64_t n = er.groupItem[q + 1] - er.groupItem[q];
-        if (n > 0) {
-          timer.begin(kProfElimUpdate, sym.elimStream());
-          hipk::elimGatherMfma<BT><<<dim3((unsigned)((n + 3) / 4), gy), 256, 0, sym.elimStream()>>>(
-              plan.elimItems.as<ElimGatherItem>() + er.groupItem[q], plan.elimPairOffJ.as<uint32_t>(),
-              plan.elimPairOffI.as<uint32_t>(), ref, (int)n, packBuf, packStride, sym.gatherFusedLoad);
-          timer.end();
-        }
-        hipEvent_t done = sym.eventFromPool();
-        hipCHECK(hipEventRecord(done, sym.elimStream()));
-        gatherDoneOut->push_back(done);
-      }
-    } else if (er.useGather) {
+    // FAULT INJECTION (bsp_test_set_fault, tests only): the whole sparse-elimination update is
+    // dropped -- the factor of everything the eliminated columns touch is then wrong, and the
+    // full-size parity tests must notice (tests/test_full_size_gpu.py)
+    if (sym.planOpts.dropElimUpdate) {
+      static bool warned = false;
+      if (!warned) fprintf(stderr, "baspacho_amd: FAULT INJECTION ACTIVE -- sparse-elimination update dropped (tests only)\n");
+      warned = true;
+      return;
+    }
+    if (er.useGather) {
       const int64_t nItems = er.itemEnd - er.itemBegin;
       if (nItems > 0) {
         timer.begin(kProfElimUpdate);
         hipk::elimGatherMfma<BT><<<dim3((unsigned)((nItems + 3) / 4), gy), 256, 0, sym.stream>>>(
             plan.elimItems.as<ElimGatherItem>() + er.itemBegin, plan.elimPairOffJ.as<uint32_t>(),
-            plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems, packBuf, packStride, sym.gatherFusedLoad);
+            plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems);
         timer.end();
       }
       const int64_t nWide = er.ldsEnd - er.ldsBegin;
@@ -1131,16 +944,15 @@ struct HipNumericCtx : NumericCtx<T> {
   // every launch of a factor over `plan`, in order, on sym.stream and the auxiliary streams
   void enqueueFactor(DevPlan& plan, hipk::DataRef<BT> ref, LaunchTimer& timer) {
     sym.resetEventPool();
-    vector<hipEvent_t> gatherDone;  // filled when the last range's update overlaps the dense phase
-    for (const ElimRangePlan& er : plan.host.elimRanges) {
-      launchElim(plan, er, ref, timer, &er == &plan.host.elimRanges.back() ? &gatherDone : nullptr);
-    }
-    launchLevels(plan, plan.host.levels, ref, timer, gatherDone.empty() ? nullptr : &gatherDone);
+    for (const ElimRangePlan& er : plan.host.elimRanges) launchElim(plan, er, ref, timer);
+    launchLevels(plan, plan.host.levels, ref, timer);
   }
 
+  // (factor() as ONE captured hipGraph launch was built in round 2 and measured no faster on this
+  //  stack -- GRID 82x82 1.66-1.79 against 1.74-1.77 ms, BAL-871 7.15 = 7.16: the runtime plays a
+  //  graph back as the same packets on the same queues -- and removed in round 4)
   virtual void factorRange(T* data, int64_t startLump, int64_t upToLump) override {
     DevPlan& plan = sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
-    if (factorViaGraph(plan, data)) return;
     hipk::DataRef<BT> ref = makeRef(data);
     LaunchTimer timer(sym.stream, sym.profile);
     enqueueFactor(plan, ref, timer);
@@ -1150,58 +962,6 @@ struct HipNumericCtx : NumericCtx<T> {
 
   // host array of the matrices' device pointers (one entry for a single matrix)
   void dataPointers(T* data, vector<BT*>& out);
-
-  // factor() as ONE graph launch.  A launch-bound structure (GRID 82x82: 127 dependent launches of
-  // 10-20 us) leaves the device idle between kernels whenever the runtime's per-launch bookkeeping
-  // falls behind (rocprofv3: runs of 40-50 us gaps in the middle of a factor, 0.3-0.4 of 1.7 ms);
-  // a captured graph is submitted as a whole.  The sequence is captured on the plan's SECOND use
-  // (the first one allocates the scratch the launches point into), from an internal stream, with
-  // the auxiliary streams joining through the same events as in the plain schedule; the matrices
-  // are reached through a pointer array in device memory that is rewritten before every launch,
-  // so one graph serves every data buffer.  Returns false when the call should go the plain way.
-  // MEASURED (profiles/ab_graph.sh): no gain on this stack -- GRID 82x82 1.66-1.79 against 1.74-1.77
-  // ms, block-tridiagonal 0.195 against 0.183, small BAL 0.825 against 0.80, BAL-871 7.15 = 7.16,
-  // FLAT-50k 28.2 against 28.6, 64 x GRID 12.65 = 12.65: the runtime plays a graph back as the same
-  // packets on the same queues.  Kept opt-in (BSP_GRAPH=1 always, =2 launch-bound plans) and tested.
-  bool factorViaGraph(DevPlan& plan, T* data) {
-    if (sym.graphMode == 0 || sym.profile || sym.forcePerOp) return false;
-    if (sym.graphMode == 2 && !plan.host.launchBound()) return false;
-    FactorGraph& g = plan.graphs[{(int)sizeof(BT), batchSize}];
-    if (++g.calls == 1) return false;
-    if (g.exec && (g.dinvPtr != sym.dinvScratch.ptr || g.rawPtr != sym.rawScratch.ptr)) {
-      (void)hipGraphExecDestroy(g.exec);  // (another plan has grown the scratch since)
-      g.exec = nullptr;
-    }
-    if (!g.exec) {
-      g.slot.resize(std::max<size_t>((size_t)batchSize * sizeof(BT*), 256));
-      hipk::DataRef<BT> ref{nullptr, (BT* const*)g.slot.ptr};
-      hipStream_t user = sym.stream, cap = sym.streams().capture;
-      hipCHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
-      sym.stream = cap;
-      hipGraph_t graph = nullptr;
-      try {
-        LaunchTimer timer(cap, nullptr);
-        enqueueFactor(plan, ref, timer);
-      } catch (...) {
-        sym.stream = user;
-        (void)hipStreamEndCapture(cap, &graph);
-        if (graph) (void)hipGraphDestroy(graph);
-        throw;
-      }
-      sym.stream = user;
-      hipCHECK(hipStreamEndCapture(cap, &graph));
-      hipError_t err = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      hipCHECK(err);
-      g.dinvPtr = sym.dinvScratch.ptr;
-      g.rawPtr = sym.rawScratch.ptr;
-    }
-    vector<BT*> ptrs;
-    dataPointers(data, ptrs);
-    sym.ptrRing.push(ptrs.data(), ptrs.size() * sizeof(BT*), sym.stream, g.slot.ptr);
-    hipCHECK(hipGraphLaunch(g.exec, sym.stream));
-    return true;
-  }
 
   virtual void doElimination(const SymElimCtx& elimData, T* data, int64_t lumpsBegin,
                              int64_t lumpsEnd) override {
@@ -1487,7 +1247,7 @@ struct HipSolveCtx : SolveCtx<T> {
     int64_t invBatchStride = 0;
     const vector<int32_t>* invSlot = nullptr;
     if (sym.solveInv && sym.blockSolve) {  // (blockSolve off: one-off level lists of the per-op path)
-      auto& ent = sym.solveInvLists[&levels];
+      auto& ent = plan.solveInvLists[&levels];
       if (!ent.built) {
         vector<PanelDesc> list;
         ent.slotOfGroup.assign(groups.size(), -1);
@@ -1709,10 +1469,10 @@ struct HipSolveCtx : SolveCtx<T> {
     plan.host = buildDenseOpPlan(n, 0, offset, /*potrfOnly=*/true, /*vecOff=*/offC);
     vector<LevelRange> levels = plan.host.levels;  // (upload() keeps the level table)
     plan.upload();
-    const bool bs = sym.blockSolve;
-    sym.blockSolve = false;  // (the block kernels expect the chain flags of a factor plan)
-    denseLevels<BACKWARD>(plan, levels, makeRef(data, C, ldc));
-    sym.blockSolve = bs;
+    {
+      FlagOff noBlocks(sym.blockSolve);  // (the block kernels expect the chain flags of a factor plan)
+      denseLevels<BACKWARD>(plan, levels, makeRef(data, C, ldc));
+    }
     hipCHECK(hipGetLastError());
   }
   virtual void solveL(const T* data, int64_t offset, int64_t n, T* C, int64_t offC,
@@ -1889,6 +1649,12 @@ void hipBackendForcePerOp(SymbolicCtx& sym, bool on) {
   h->forcePerOp = on;
 }
 
+void hipBackendSetFault(SymbolicCtx& sym, int kind) {
+  HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
+  BASPACHO_CHECK_NOTNULL(h);
+  h->planOpts.dropElimUpdate = kind == 1;
+}
+
 void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof, bool inSitu) {
   HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
   BASPACHO_CHECK_NOTNULL(h);
@@ -1928,9 +1694,6 @@ HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t up
   s.numAtomicUpdTasks = atomicTasks;
   s.numForkLevels = p.numForkLevels;
   s.deferredFlops = p.deferredFlops;
-  if (!p.elimRanges.empty() && p.elimRanges.back().overlapLump >= 0 && p.opts.elimOverlap) {
-    s.numGatherGroups = (int64_t)p.elimRanges.back().groupItem.size() - 1;
-  }
   return s;
 }
 

@@ -79,39 +79,6 @@ __device__ __forceinline__ void yieldWhile(const unsigned* flag, unsigned key) {
   }
 }
 
-// TILE YIELD (round 3, opt-in BSP_TILE_YIELD=1): the chain's ordinary tile workgroups announce
-// themselves too, in a per-CU counter behind the potrf word (index = the 11 low bits of cuKey()):
-// beside three bulk workgroups a chain tile gets a quarter of the matrix pipe and lives 25-30 us of
-// which ~10 are its own (tools/trace_extents.py: the tiles, not the potrf workgroup, end a step).
-// MEASURED: the chain's launches shrink from 4.40 to 3.80 ms and the bulk launches grow from 6.07 to
-// 6.50 ms -- factor() 6.30 -> 6.53 ms (FLAT-50k 27.0 -> 27.7): the phase is bound by the matrix
-// pipe's total work, what the chain gains the bulk stream loses.  Off by default.
-constexpr int kYieldTableOffset = 64;    // words
-constexpr int kYieldTableSize = 2048;    // counters
-__device__ __forceinline__ unsigned cuSlot() { return cuKey() & (kYieldTableSize - 1); }
-__device__ __forceinline__ void tileYieldEnter(unsigned* flag, int on) {
-  if (on && flag && threadIdx.x == 0) {
-    __hip_atomic_fetch_add((GP<unsigned>)flag + kYieldTableOffset + cuSlot(), 1u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-__device__ __forceinline__ void tileYieldLeave(unsigned* flag, int on) {
-  if (on && flag && threadIdx.x == 0) {
-    __hip_atomic_fetch_add((GP<unsigned>)flag + kYieldTableOffset + cuSlot(), ~0u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// bulk side: pause while the potrf word names this CU or a chain tile is counted on it (bounded)
-__device__ __forceinline__ void yieldWhileAny(const unsigned* flag, unsigned key) {
-  for (int spin = 0; spin < 48; spin++) {
-    __builtin_amdgcn_s_sleep(16);
-    const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)yieldPeek(flag));
-    const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane(
-        (int)yieldPeek(flag + kYieldTableOffset + (key & (kYieldTableSize - 1))));
-    if (a != key && b == 0u) break;
-  }
-}
-
 __device__ __forceinline__ void waveSync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -232,123 +199,18 @@ __global__ __launch_bounds__(256) void elimFactorSmall(SkelDev sk, DataRef<T> dr
   }
 }
 
-// K1t  the same for lumps of width <= 4 (the 3-wide point columns of bundle adjustment), driven by
-// ElimLumpDesc: one descriptor load, then the diagonal block (every lane reads all of it) and the
-// lane's row in flight together; the n x n Cholesky runs redundantly in every lane's registers
-// (hardware rsq + Newton, no LDS, no wave synchronisation, no division).  K1 spends ~7 dependent
-// memory round trips per wave and is latency bound at 2 TB/s.
-constexpr int kTinyPerWave = 4, kTinyPasses = 4;
-template <typename T>
-__global__ __launch_bounds__(256) void elimFactorTiny(const ElimLumpDesc* descs, DataRef<T> dref,
-                                                      int numLumps, const int32_t* packSlot = nullptr,
-                                                      int packRows = 0, T* packBuf = nullptr,
-                                                      int64_t packStride = 0) {
-  // packBuf: second copy of every solved below block, block b of lump idx at slot packSlot[idx] + b
-  // (kElimPackSlot elements each; all blocks have packRows rows): the operands of the gather update
-  // kTinyPerWave lumps per wave (64 / kTinyPerWave lanes each), kTinyPasses rows per lane in
-  // flight: the kernel is bound by the bytes in flight per wave slot, not by bandwidth
-  constexpr int G = 64 / kTinyPerWave, NPASS = kTinyPasses;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & (G - 1);
-  const int idx = (blockIdx.x * 4 + wave) * kTinyPerWave + lane / G;
-  if (idx >= numLumps) return;
-  const ElimLumpDesc ld = descs[idx];
-  const int n = ld.n;
-  if (n > 4) return;  // (the caller checks the range's maximum width)
-  GP<T> D = pickData(dref) + ld.diagOff;
-  GP<T> B = D + n * n;
-  GP<T> packed = packBuf ? (GP<T>)packBuf + blockIdx.y * packStride +
-                               (int64_t)packSlot[idx] * kElimPackSlot
-                         : nullptr;
-  // diagonal block (lower part), padded with the identity
-  T a[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-#pragma unroll
-    for (int j = 0; j <= i; j++) {
-      const T v = D[min(i, n - 1) * n + min(j, n - 1)];
-      a[i][j] = (i < n && j < n) ? v : (i == j ? T(1) : T(0));
-    }
-  }
-  // the first passes of rows of this lane (rows sub, sub + G, ...)
-  T x[NPASS][4];
-#pragma unroll
-  for (int p = 0; p < NPASS; p++) {
-    const int r = sub + G * p;
-    GP<const T> row = B + (int64_t)(r < ld.rowsBelow ? r : 0) * n;
-#pragma unroll
-    for (int j = 0; j < 4; j++) x[p][j] = row[min(j, n - 1)];
-  }
-  // Cholesky in registers: l[i][j], inv[j] = 1 / l[j][j]
-  T inv[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    T d = a[j][j];
-#pragma unroll
-    for (int k = 0; k < j; k++) d -= a[j][k] * a[j][k];
-    inv[j] = fastRsqrt(d);
-    a[j][j] = d * inv[j];
-#pragma unroll
-    for (int i = j + 1; i < 4; i++) {
-      T s = a[i][j];
-#pragma unroll
-      for (int k = 0; k < j; k++) s -= a[i][k] * a[j][k];
-      a[i][j] = s * inv[j];
-    }
-  }
-  // write the factor of the diagonal block: lane e of the half holds entry e = i * n + j
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-#pragma unroll
-    for (int j = 0; j <= i; j++) {
-      if (i < n && sub == i * n + j) D[i * n + j] = a[i][j];
-    }
-  }
-  // rows below: x * L^T = b
-  for (int r0 = sub; r0 < ld.rowsBelow; r0 += G * NPASS) {
-#pragma unroll
-    for (int p = 0; p < NPASS; p++) {
-      const int r = r0 + G * p;
-      if (r >= ld.rowsBelow) continue;
-      GP<T> row = B + (int64_t)r * n;
-      T y[4];
-      if (r0 == sub) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) y[j] = x[p][j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) y[j] = row[min(j, n - 1)];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        T s = y[j];
-#pragma unroll
-        for (int i = 0; i < j; i++) s -= y[i] * a[j][i];
-        y[j] = s * inv[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (j < n) row[j] = y[j];
-      }
-      if (packed) {
-        const int blk = r / packRows, rr = r - blk * packRows;
-        GP<T> prow = packed + blk * kElimPackSlot + rr * n;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (j < n) prow[j] = y[j];
-        }
-      }
-    }
-  }
-}
-
-// K1s  K1t with the eliminated columns STAGED through LDS.  A wave's four lumps are neighbours in
+// lumps of width <= 4 (the 3-wide point columns of bundle adjustment) are driven by ElimLumpDesc: one
+// descriptor load, the n x n Cholesky redundantly in every lane's registers (hardware rsq + Newton,
+// no wave synchronisation, no division), kTinyPerWave lumps per wave.
+constexpr int kTinyPerWave = 4;
+// K1s  the eliminated columns STAGED through LDS.  A wave's four lumps are neighbours in
 // memory (an elimination range is laid out lump after lump, each column one dense (n + rows) x n
 // block), so the wave reads its whole stretch -- typically ~600 values -- with fully coalesced
-// 512-byte wave loads, all issued back to back, factors and solves out of LDS (16 lanes per lump as
-// in K1t, the n x n Cholesky redundantly in registers) and writes the stretch back the same way.
-// K1t reads every 24-byte row with three 8-byte loads per lane and the diagonal block with six more
-// per lane: ~18 wave instructions of ~270 useful bytes each per four lumps, and it ran at 2.9 TB/s
-// (0.36 of the HBM roofline) on the 527 480 point columns of BAL-871.  A stretch that does not fit
+// 512-byte wave loads, all issued back to back, factors and solves out of LDS (16 lanes per lump,
+// the n x n Cholesky redundantly in registers) and writes the stretch back the same way.
+// (The direct form of rounds 1-2 read every 24-byte row with three 8-byte loads per lane and the
+// diagonal block with six more per lane: ~18 wave instructions of ~270 useful bytes each per four
+// lumps, 2.9 TB/s on the 527 480 point columns of BAL-871.)  A stretch that does not fit
 // the scratch (heavy-tail points seen by dozens of cameras) takes the direct path lump by lump.
 template <typename T>
 using LP = __attribute__((address_space(3))) T*;
@@ -683,25 +545,18 @@ __global__ __launch_bounds__(256) void elimGather(const ElimGatherItem* items, c
 template <typename T>
 __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* items,
                                                       const uint32_t* offJ, const uint32_t* offI,
-                                                      DataRef<T> dref, int numItems,
-                                                      const T* packBuf = nullptr,
-                                                      int64_t packStride = 0, int fusedLoad = 1) {
-  // packBuf: the pair offsets point into the packed copy of the solved blocks (elimFactorTiny)
+                                                      DataRef<T> dref, int numItems) {
   // pairs whose operand loads are in flight together.  With items of at most 128 pairs the kernel is
   // not bound by a wave's own round trips any more: 4 / 8 / 16 give 6.87-6.92 / 6.95-6.99 / 7.03 ms on
   // BAL-871 (fewer registers, more waves ready to issue)
-#ifdef BSP_GATHER_U
-  constexpr int U = BSP_GATHER_U;
-#else
   constexpr int U = 4;
-#endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
   const int idx = blockIdx.x * 4 + wave;
   if (idx >= numItems) return;
   const ElimGatherItem it = items[idx];
   GP<T> data = pickData(dref);
-  GP<const T> src = packBuf ? (GP<const T>)packBuf + blockIdx.y * packStride : (GP<const T>)data;
+  GP<const T> src = (GP<const T>)data;
   const int rows = it.rows, cols = it.cols, n = it.n;
   using Acc = typename Mfma<T>::Acc;
   Acc acc = {0, 0, 0, 0};
@@ -714,59 +569,9 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
   // MFMA operand layout (lane (i, k) wants element i * n + k) is restored through the LDS crossbar
   // (ds_bpermute: no LDS memory, four 32-bit permutes per pair).
   const int EA = rows * n, EB = cols * n;
-  // TWO pairs per load instruction (fp64): 16 bytes per lane, lane group g = lane / 16 fetches block
-  // (pair g / 2, B_j or B_i) two elements per lane, the wave's 1 KB lands lane-linear in a private LDS
-  // slot (one ds_write_b128) where element e of group g is simply slot[32 g + e], and the MFMA
-  // operands are read back from there.  The texture addresser spends ~22 cycles per wave load
-  // whatever it fetches (PMC, profiles/r03_pmc_ta_*.txt): 4 blocks per instruction instead of 2.
-  // (the last lane of an odd-sized block reads 8 bytes past it: inside the numeric data, a source
-  //  block is always followed by the column its pairs update, or by the rest of its 32-element slot)
-  if constexpr (sizeof(T) == 8) {
-    if (fusedLoad >= 2 && n <= 4 && EA <= 32 && EB <= 32) {
-      typedef double d2 __attribute__((ext_vector_type(2)));
-      typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // (blocks are 8-byte aligned)
-      typedef __attribute__((address_space(1))) const d2u* GP2;
-      constexpr int S = U / 2;  // wave loads in flight
-      __shared__ __attribute__((aligned(16))) double stage[4][S][128];
-      const int g = lane >> 4, q = lane & 15, hp = g >> 1, isI = g & 1;
-      const bool ldOk = 2 * q < (isI ? EB : EA);
-      const bool okA = li < rows && lk < n, okB = li < cols && lk < n;
-      const int idxA = okA ? li * n + lk : 0, idxB = 32 + (okB ? li * n + lk : 0);
-      for (int base = it.pairBegin; base < it.pairEnd; base += 64) {
-        const int cnt = min(64, it.pairEnd - base);
-        const uint32_t myJ = lane < cnt ? offJ[base + lane] : 0u;
-        const uint32_t myI = lane < cnt ? offI[base + lane] : 0u;
-        for (int t0 = 0; t0 < cnt; t0 += U) {
-          d2 v[S];
-#pragma unroll
-          for (int s2 = 0; s2 < S; s2++) {
-            const int ta = min(t0 + 2 * s2, cnt - 1), tb = min(t0 + 2 * s2 + 1, cnt - 1);
-            const uint32_t oja = (uint32_t)__builtin_amdgcn_readlane((int)myJ, ta);
-            const uint32_t oia = (uint32_t)__builtin_amdgcn_readlane((int)myI, ta);
-            const uint32_t ojb = (uint32_t)__builtin_amdgcn_readlane((int)myJ, tb);
-            const uint32_t oib = (uint32_t)__builtin_amdgcn_readlane((int)myI, tb);
-            const uint32_t o = hp ? (isI ? oib : ojb) : (isI ? oia : oja);
-            v[s2] = *(GP2)((GP<const double>)src + o + (ldOk ? 2 * q : 0));
-          }
-#pragma unroll
-          for (int s2 = 0; s2 < S; s2++) *(d2*)&stage[wave][s2][2 * lane] = v[s2];
-          waveSync();
-#pragma unroll
-          for (int s2 = 0; s2 < S; s2++) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-              const bool live = t0 + 2 * s2 + h < cnt;
-              const double a = stage[wave][s2][64 * h + idxA], b = stage[wave][s2][64 * h + idxB];
-              acc = Mfma<T>::run((okA && live) ? a : 0.0, okB ? b : 0.0, acc);
-            }
-          }
-          waveSync();  // (the slots are rewritten by the next group of pairs)
-        }
-      }
-      goto gathered;
-    }
-  }
-  if (fusedLoad && n <= 4 && EA <= 32 && EB <= 32) {
+  // (two pairs per load instruction -- 16 bytes per lane through a private LDS slot -- was measured at
+  //  1.15 against 1.17 ms for the kernel and nothing for factor(): round 3, removed in round 4)
+  if (n <= 4 && EA <= 32 && EB <= 32) {
     const int half = lane >> 5, e = lane & 31;
     const bool ldOk = half ? e < EB : e < EA;
     const uint32_t eOff = ldOk ? (uint32_t)e : 0u;
@@ -831,7 +636,6 @@ __global__ __launch_bounds__(256) void elimGatherMfma(const ElimGatherItem* item
     }
   }
   }
-gathered:
   GP<T> target = data + it.tgtOff;
   GP<T> ptr[4];
   bool ok[4];
@@ -853,144 +657,6 @@ gathered:
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       if (ok[g]) *ptr[g] = old[g] - acc[g];
-    }
-  }
-}
-
-// K2r  ROW FORM of the sparse-elimination update.  K2m fetches both source blocks of every pair
-// from wherever they lie (7 GB of L2 misses for 0.64 GB of distinct source data on BAL-871: the
-// waves of one row of targets drift apart, nothing is reused in L2).  Here one workgroup (16
-// waves) owns one ROW of targets (sj, *): its pairs are ordered by source column, so the blocks
-// B_i a column contributes are the contiguous head of that column and B_j is its next block;
-// every pair is one v_mfma 16x16x4 into a fresh accumulator whose valid entries are added to the
-// target's slot in LDS (ds_add_f64); when the row is done the slots are subtracted from memory,
-// once, without atomics (a row belongs to one workgroup).
-template <typename T>
-__global__ __launch_bounds__(1024) void elimRowMfma(const ElimRowItem* rowItems,
-                                                    const ElimRowSlot* slots, const uint32_t* offJ,
-                                                    const uint32_t* offI, const uint16_t* slotIdx,
-                                                    DataRef<T> dref, uint32_t lastElem) {
-  extern __shared__ __align__(16) unsigned char ldsRaw[];
-  constexpr int U = 8, WAVES = 16;
-  const ElimRowItem it = rowItems[blockIdx.x];
-  T* acc = reinterpret_cast<T*>(ldsRaw);
-  const int nSlots = it.slotEnd - it.slotBegin;
-  ElimRowSlot* tab = reinterpret_cast<ElimRowSlot*>(acc + ((it.ldsElems + 3) & ~3));
-  const int tid = threadIdx.x;
-  for (int e = tid; e < it.ldsElems; e += 1024) acc[e] = T(0);
-  for (int s = tid; s < nSlots; s += 1024) tab[s] = slots[it.slotBegin + s];
-  __syncthreads();
-  GP<T> data = pickData(dref);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int rows = it.rows, n = it.n;
-  using Acc = typename Mfma<T>::Acc;
-  // add the valid entries of one pair's product to its slot
-  auto deposit = [&](const Acc& prod, int s) {
-    const int cols = tab[s].cols, ldsOff = tab[s].ldsOff;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int r = Mfma<T>::row(lane, g);
-      if (r < rows && li < cols) unsafeAtomicAdd(&acc[ldsOff + r * cols + li], prod[g]);
-    }
-  };
-  if (n <= 4) {
-    // one MFMA per pair; operand loads of the NEXT group of 8 pairs are in flight while the
-    // current group is multiplied and deposited, the offsets of the next 64 pairs are fetched
-    // one batch ahead
-    const bool okA = li < rows && lk < n, okK = lk < n;
-    const uint32_t eA = okA ? (uint32_t)(li * n + lk) : 0u;
-    const uint32_t eB = (uint32_t)(li * n + min(lk, n - 1));
-    int base = it.pairBegin + 64 * wave;
-    uint32_t nxJ = 0, nxI = 0;
-    int nxS = 0;
-    auto fetchMeta = [&](int b0) {
-      const int c = min(64, it.pairEnd - b0);
-      nxJ = (b0 < it.pairEnd && lane < c) ? offJ[b0 + lane] : 0u;
-      nxI = (b0 < it.pairEnd && lane < c) ? offI[b0 + lane] : 0u;
-      nxS = (b0 < it.pairEnd && lane < c) ? (int)slotIdx[b0 + lane] : 0;
-    };
-    fetchMeta(base);
-    for (; base < it.pairEnd; base += 64 * WAVES) {
-      const int cnt = min(64, it.pairEnd - base);
-      const uint32_t myJ = nxJ, myI = nxI;
-      const int myS = nxS;
-      fetchMeta(base + 64 * WAVES);
-      T a0[U], b0[U], a1[U], b1[U];
-      auto issue = [&](int t0, T* a, T* b) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int t = min(t0 + u, cnt - 1);
-          const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)myJ, t);
-          const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)myI, t);
-          a[u] = data[oj + eA];
-          b[u] = data[min(oi + eB, lastElem)];
-        }
-      };
-      auto consume = [&](int t0, const T* a, const T* b) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          if (t0 + u < cnt) {  // wave-uniform
-            const int s = __builtin_amdgcn_readlane(myS, t0 + u);
-            const int cols = tab[s].cols;
-            const Acc prod = Mfma<T>::run(okA ? a[u] : T(0), (okK && li < cols) ? b[u] : T(0),
-                                          Acc{0, 0, 0, 0});
-            deposit(prod, s);
-          }
-        }
-      };
-      issue(0, a0, b0);
-      for (int t0 = 0; t0 < cnt; t0 += 2 * U) {
-        if (t0 + U < cnt) issue(t0 + U, a1, b1);
-        consume(t0, a0, b0);
-        if (t0 + 2 * U < cnt) issue(t0 + 2 * U, a0, b0);
-        if (t0 + U < cnt) consume(t0 + U, a1, b1);
-      }
-    }
-  } else {
-    for (int base = it.pairBegin + 64 * wave; base < it.pairEnd; base += 64 * WAVES) {
-      const int cnt = min(64, it.pairEnd - base);
-      const uint32_t myJ = lane < cnt ? offJ[base + lane] : 0u;
-      const uint32_t myI = lane < cnt ? offI[base + lane] : 0u;
-      const int myS = lane < cnt ? (int)slotIdx[base + lane] : 0;
-      for (int t = 0; t < cnt; t++) {
-        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)myJ, t);
-        const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)myI, t);
-        const int s = __builtin_amdgcn_readlane(myS, t);
-        const int cols = tab[s].cols;
-        Acc prod = {0, 0, 0, 0};
-        for (int k0 = 0; k0 < n; k0 += 4) {
-          const int k = k0 + lk;
-          const bool okA = li < rows && k < n, okB = li < cols && k < n;
-          const T a = okA ? data[oj + (uint32_t)(li * n + k)] : T(0);
-          const T b = okB ? data[oi + (uint32_t)(li * n + k)] : T(0);
-          prod = Mfma<T>::run(a, b, prod);
-        }
-        deposit(prod, s);
-      }
-    }
-  }
-  __syncthreads();
-  // subtract the row's accumulators from the targets
-  for (int e = tid; e < it.ldsElems; e += 1024) {
-    int lo = 0, hi = nSlots;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (tab[mid].ldsOff <= e) {
-        lo = mid;
-      } else {
-        hi = mid;
-      }
-    }
-    const ElimRowSlot sd = tab[lo];
-    const int e2 = e - sd.ldsOff, r = e2 / sd.cols, c = e2 - r * sd.cols;
-    if (!((sd.flags & 2) && c > r)) {
-      GP<T> p = data + sd.tgtOff + (int64_t)r * sd.tgtStride + c;
-      if (it.shared) {
-        atomicSub(p, acc[e]);
-      } else {
-        *p -= acc[e];
-      }
     }
   }
 }
@@ -1210,182 +876,7 @@ __device__ __forceinline__ void invertColumn16(const T* Lb, int ldl, int n, T (&
   }
 }
 
-template <typename T, int NT, typename Pre = NoPreUpdate>
-__device__ __forceinline__ void potrfTiles(GP<T> A, int nb, int lda, T (*blk)[4], T (*sol)[4],
-                                           Pre pre = Pre(), T* Ld = nullptr,
-                                           GP<T> dinvOut = nullptr) {
-  // The block lives in MFMA accumulator layout: wave w owns tile row w (16x16 tiles (w,0..w));
-  // lane l / register r of tile (ti,tj) hold row 16ti + Mfma::row(l,r), column 16tj + (l&15).
-  // One step per 4-column pivot block.  The serial path of a step touches only LDS and the
-  // vector ALU; the matrix cores keep the trailing block up to date BEHIND it:
-  //   * a column block is copied out of the accumulators ("published") into a ring slot two
-  //     steps before it becomes the pivot block, and brought up to date there by thread (i,g) =
-  //     (tid/4, tid%4) with 4 FMAs per step -- so a step never waits for the MFMA of the
-  //     previous one, nor for a round trip through the accumulator layout;
-  //   * (1) thread (i,g) factors the 4x4 pivot redundantly (hardware rsq + Newton), solves row i
-  //     against it, publishes sol[i][g] (zero for rows that are done) and stores the final entry
-  //     L(i, 4J+g) straight to memory;  -- barrier --
-  //   * (2) thread-level update of the next two column blocks; every live tile gets the rank-4
-  //     update  D -= sol_rows * sol_cols^T  as ONE v_mfma 16x16x4 (fire and forget);  -- barrier --
-  // Finished columns are protected by the zeros in sol, so full-tile updates need no masks.
-  // Strictly-upper entries are carried as finite mirror values and never written back; rows and
-  // columns beyond nb are padded with the identity.
-  constexpr int N = 16 * NT;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
-  const int i = tid >> 2, g = tid & 3;
-  using Acc = typename Mfma<T>::Acc;
-  Acc acc[NT];
-#pragma unroll
-  for (int tj = 0; tj < NT; tj++) {
-    if (tj <= w) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = 16 * w + Mfma<T>::row(lane, r), col = 16 * tj + li;
-        const int rl = min(row, nb - 1);
-        const T v = A[(int64_t)rl * lda + min(col, rl)];
-        acc[tj][r] = (row < nb && col <= row) ? v : ((row >= nb && col == row) ? T(1) : T(0));
-      }
-    } else {
-      acc[tj] = Acc{0, 0, 0, 0};
-    }
-  }
-  pre(acc);
-  BSP_STAMP(1);
-  const int nSteps = (nb + 3) >> 2;
-  // copy column block c (columns 4c..4c+3, rows of the tile rows that hold them) out of the
-  // accumulators into ring slot c % 3
-  auto publish = [&](int c) {
-    const int tjc = c >> 2, cbase = 4 * (c & 3);
-    if (w >= tjc && li >= cbase && li < cbase + 4) {
-      T(*dst)[4] = blk + (c % 3) * N;
-#pragma unroll
-      for (int tj = 0; tj < NT; tj++) {
-        if (tj == tjc) {
-#pragma unroll
-          for (int r = 0; r < 4; r++) dst[16 * w + Mfma<T>::row(lane, r)][li - cbase] = acc[tj][r];
-        }
-      }
-    }
-  };
-  if (Ld) {  // identity beyond nb, zero above the diagonal; the steps fill in the rest
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int col = 4 * g + c;
-      Ld[i * kInvLd + col] = (i >= nb && (i & 15) == col) ? T(1) : T(0);
-    }
-  }
-  publish(0);
-  if (nSteps > 1) publish(1);
-  ldsBarrier();
-  auto step = [&](auto Jc) __attribute__((always_inline)) {
-    const int J = Jc;  // integral_constant: a compile-time constant after inlining
-    if (J >= nSteps) return;
-    if (J == 6) { BSP_STAMP(4); }
-    const int j0 = 4 * J, tjJ = J >> 2;
-    T(*raw)[4] = blk + (J % 3) * N;
-    // (1) pivot block + own row
-    const T p00 = raw[j0][0];
-    const T p10 = raw[j0 + 1][0], p11 = raw[j0 + 1][1];
-    const T p20 = raw[j0 + 2][0], p21 = raw[j0 + 2][1], p22 = raw[j0 + 2][2];
-    const T p30 = raw[j0 + 3][0], p31 = raw[j0 + 3][1], p32 = raw[j0 + 3][2],
-            p33 = raw[j0 + 3][3];
-    const T r0 = raw[i][0], r1 = raw[i][1], r2 = raw[i][2], r3 = raw[i][3];
-    const T i0 = fastRsqrt(p00);
-    const T l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
-    const T q11 = p11 - l10 * l10;
-    const T i1 = fastRsqrt(q11);
-    const T l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
-    const T q22 = p22 - l20 * l20 - l21 * l21;
-    const T i2 = fastRsqrt(q22);
-    const T l32 = (p32 - l30 * l20 - l31 * l21) * i2;
-    const T q33 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
-    const T i3 = fastRsqrt(q33);
-    const bool below = i >= j0 + 4;
-    // own row solved against the pivot block.  For a row INSIDE the pivot block the same recurrence
-    // reproduces its entries of L (u_g = l(i, 4J+g) for g <= i - j0, operation for operation what
-    // the redundant 4x4 factorization above computes), so the value to store is u_g for every
-    // live row -- no select between "solved" and "in-pivot" values, whose nest of divergent
-    // branches cost a fifth of the step.  What is published for the updates is zero for rows that
-    // are done or inside the block.
-    const T u0 = r0 * i0;
-    const T u1 = (r1 - u0 * l10) * i1;
-    const T u2 = (r2 - u0 * l20 - u1 * l21) * i2;
-    const T u3 = (r3 - u0 * l30 - u1 * l31 - u2 * l32) * i3;
-    const T c0 = below ? u0 : T(0), c1 = below ? u1 : T(0), c2 = below ? u2 : T(0),
-            c3 = below ? u3 : T(0);
-    const T u01 = (g & 1) ? u1 : u0, u23 = (g & 1) ? u3 : u2;
-    const T ufin = (g & 2) ? u23 : u01;
-    sol[i][g] = below ? ufin : T(0);
-    if (J == 6) { BSP_STAMP(5); }
-    // (the previous step's MFMAs have had the whole pivot chain to complete: no stall here)
-    if (J + 2 < nSteps) publish(J + 2);  // state: rank-4 updates of steps < J
-    if (i < nb && j0 + g < nb && i - j0 >= g) {
-      A[(int64_t)i * lda + j0 + g] = ufin;
-      if (Ld && (i >> 4) == tjJ) Ld[i * kInvLd + ((j0 + g) & 15)] = ufin;
-    }
-    ldsBarrier();
-    if (J == 6) { BSP_STAMP(6); }
-    // (2) bring the next two column blocks up to date, rank-4 update of every live tile.  Every LDS
-    // read of the section is issued before the first use (one round trip instead of four): rows
-    // past the end are clamped, ring slots that are not live are read and written as they are
-    // (nothing reads them as a pivot block again; a conditional store would pull its loads into
-    // the branch).
-    {
-      T(*nx1)[4] = blk + ((J + 1) % 3) * N;
-      T(*nx2)[4] = blk + ((J + 2) % 3) * N;
-      const int jr1 = min(j0 + 4 + g, N - 1), jr2 = min(j0 + 8 + g, N - 1);
-      T s1[4], s2[4], sb[NT];
-#pragma unroll
-      for (int k = 0; k < 4; k++) s1[k] = sol[jr1][k];
-#pragma unroll
-      for (int k = 0; k < 4; k++) s2[k] = sol[jr2][k];
-      const T n1 = nx1[i][g], n2 = nx2[i][g];
-      const T sa = -sol[16 * w + li][lk];
-#pragma unroll
-      for (int tj = 0; tj < NT; tj++) sb[tj] = sol[16 * tj + li][lk];
-      nx1[i][g] = n1 - (c0 * s1[0] + c1 * s1[1] + c2 * s1[2] + c3 * s1[3]);
-      nx2[i][g] = n2 - (c0 * s2[0] + c1 * s2[1] + c2 * s2[2] + c3 * s2[3]);
-      // tile columns left of the pivot are final (compile-time).  Tiles above the diagonal
-      // (tj > w) get a zero operand instead of a branch: a branch would pull the operand reads
-      // behind it -- a second LDS round trip on the serial path -- and the wave with all tiles live
-      // sets the pace of the step anyway.  The MFMAs run while the wave sits in the barrier and in
-      // the LDS reads of the next step: fp64 MFMA and fp64 VALU share one pipe, so a variant with
-      // ONE barrier per step (next pivot block kept in registers, computed redundantly by every
-      // thread) only moved the wait for them in front of the next pivot chain (measured: 1920
-      // against 1730 clocks per step).
-#pragma unroll
-      for (int tj = 0; tj < NT; tj++) {
-        if (tj >= tjJ) acc[tj] = Mfma<T>::run(tj <= w ? sa : T(0), sb[tj], acc[tj]);
-      }
-    }
-    ldsBarrier();
-    if (J == 6) { BSP_STAMP(7); }
-  };
-
-  // (compile-time step index: tile and column-block indices are constants -- a rolled loop
-  //  spends a quarter of every step in ~25 scalar branches around them)
-#ifdef BSP_POTRF_PARTIAL_UNROLL  // A/B: let the compiler peel a few steps and loop over the rest
-#pragma unroll
-  for (int Jr = 0; Jr < 4 * NT; Jr++) {
-    if (Jr >= nSteps) break;
-    step(Jr);
-  }
-#else
-  staticFor<0, 4 * NT>(step);
-#endif
-  BSP_STAMP(2);
-  if (Ld) {  // (the last step ended with a barrier)
-    T y[16];
-    invertColumn16(Ld + 16 * w * kInvLd, kInvLd, li, y);
-    if (lane < 16) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) dinvOut[(16 * w + r) * 16 + li] = y[r];
-    }
-  }
-}
-
-// BLOCKED form of the panel potrf (round 3; BSP_POTRF_BLOCKED=0 at build time restores potrfTiles).
+// BLOCKED form of the panel potrf (round 3; the 4-column-step form of rounds 1-2 is in the history).
 // 16-column blocks, two LDS buffers of 64 rows x 16 columns that alternate between blocks.  Per block J:
 //   * ONE wave factors the whole block column in registers, lane = row (diagonal tile and the rows
 //     below alike): right-looking, pivot and multipliers broadcast with v_readlane -- the Cholesky
@@ -1398,12 +889,8 @@ __device__ __forceinline__ void potrfTiles(GP<T> A, int nb, int lda, T (*blk)[4]
 //     into the other buffer.                                                       -- barrier --
 // 8 barriers per panel instead of 32, no redundant pivot factorizations, the matrix cores work
 // behind the serial path.  In situ (tools/trace_potrf.py): 26.9 k -> see DESIGN.md clocks per panel.
-// Same contract as potrfTiles (accumulator-layout input after `pre`, identity padding beyond nb,
-// Ld / dinvOut).  Buffer layout: row R, column c at R * 16 + (c ^ key(R)), key = 2 ((R / 2) % 8) --
+// Contract: accumulator-layout input after `pre`, identity padding beyond nb, Ld / dinvOut.  Buffer layout: row R, column c at R * 16 + (c ^ key(R)), key = 2 ((R / 2) % 8) --
 // the lane-per-row walk and the MFMA operand fetch are both (nearly) conflict-free without padding.
-#ifndef BSP_POTRF_BLOCKED
-#define BSP_POTRF_BLOCKED 1
-#endif
 __device__ __forceinline__ int potrfColbufAt(int R, int c) { return R * 16 + (c ^ (((R >> 1) & 7) << 1)); }
 
 // One wave factors a block column of 16 columns held one row per lane (rows R of buf, lanes beyond
@@ -1621,11 +1108,8 @@ template <typename T, typename Pre = NoPreUpdate>
 __device__ __forceinline__ void potrfPanelTiles(GP<T> A, int nb, int lda, T (*blk)[4], T (*sol)[4],
                                                 T* buf2, Pre pre = Pre(), T* Ld = nullptr,
                                                 GP<T> dinvOut = nullptr) {
-#if BSP_POTRF_BLOCKED
+  (void)sol;
   potrfTilesBlocked<T, Pre>(A, nb, lda, &blk[0][0], buf2, pre, Ld, dinvOut);
-#else
-  potrfTiles<T, 4, Pre>(A, nb, lda, blk, sol, pre, Ld, dinvOut);
-#endif
 }
 
 template <typename T>
@@ -2272,9 +1756,6 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
     if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
     // (cooperative CU yield: the word is fetched with the chunk and looked at after it has landed)
     const unsigned yf = yieldFlag ? yieldPeek(yieldFlag) : 0u;
-    const unsigned yt = (yieldFlag && (atomicMask & 0x100))
-                            ? yieldPeek(yieldFlag + kYieldTableOffset + (myCu & (kYieldTableSize - 1)))
-                            : 0u;
 #pragma unroll
     for (int it = 0; it < NI; it++) {
       __builtin_amdgcn_global_load_lds((GV)(srcA[it] + kBase), (LV)(As + RPI * (4 * it + wave) * KC),
@@ -2289,12 +1770,8 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (yieldFlag) {
-      if ((unsigned)__builtin_amdgcn_readfirstlane((int)yt) != 0u) {
-        yieldWhileAny(yieldFlag, myCu);
-      } else if ((unsigned)__builtin_amdgcn_readfirstlane((int)yf) == myCu) {
-        yieldWhile(yieldFlag, myCu);
-      }
+    if (yieldFlag && (unsigned)__builtin_amdgcn_readfirstlane((int)yf) == myCu) {
+      yieldWhile(yieldFlag, myCu);
     }
     if (!skipUpper) {
 #pragma unroll
@@ -2382,8 +1859,7 @@ __device__ __forceinline__ int xcdContiguous(int b, int n) {
 template <typename T>
 __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const SegDesc& sd, int idx,
                                                      GP<T> data, T* As, T* Bs,
-                                                     GP<T> rawOut = nullptr, int nbNext = 0,
-                                                     int atomicFromCol = 0x7fffffff) {
+                                                     GP<T> rawOut = nullptr, int nbNext = 0) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
   int colTile = sd.q0, rowTile;
   for (;;) {
@@ -2478,15 +1954,11 @@ __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const Se
       for (int reg = 0; reg < 4; reg++) {
         const int qr = rowTile + wr + (t >> 1) * 16 + Mfma<T>::row(lane, reg);
         if (qc < segEnd && qr < pd.rowsBelow && qr >= qc && qr >= sd.rowMin) {
-          if (colTile >= atomicFromCol) {  // (CHAIN WINDOW: columns shared with lookahead units)
-            atomicSub(tgt + (int64_t)qr * sd.tgtStride + qc, (*accs[t])[reg]);
-          } else {
-            const T val = old[t * 4 + reg] - (*accs[t])[reg];
-            tgt[(int64_t)qr * sd.tgtStride + qc] = val;
-            // rows below the next panel's diagonal block, also to the chain's staging buffer
-            if (rawOut && colTile == 0 && qc < nbNext && qr >= nbNext) {
-              rawOut[(int64_t)(qr - nbNext) * kTile + qc] = val;
-            }
+          const T val = old[t * 4 + reg] - (*accs[t])[reg];
+          tgt[(int64_t)qr * sd.tgtStride + qc] = val;
+          // rows below the next panel's diagonal block, also to the chain's staging buffer
+          if (rawOut && colTile == 0 && qc < nbNext && qr >= nbNext) {
+            rawOut[(int64_t)(qr - nbNext) * kTile + qc] = val;
           }
         }
       }
@@ -2497,14 +1969,13 @@ __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const Se
 template <typename T>
 __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, int nTasks,
                                                         DataRef<T> dref, T* rawOut, int nbNext,
-                                                        int64_t rawStride, int atomicFromCol) {
+                                                        int64_t rawStride) {
   constexpr int LD = kUpdChunk + 2;
   __shared__ T As[kTile * LD];
   __shared__ T Bs[kTile * LD];
   __builtin_amdgcn_s_setprio(BSP_TILE_PRIO);
   updateTileDirectBody<T>(pd, sd, xcdContiguous(blockIdx.x, nTasks), pickData(dref), As, Bs,
-                          rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr, nbNext,
-                          atomicFromCol);
+                          rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr, nbNext);
 }
 
 // K5f  the same launch with the NEXT panel's potrf fused in.  Tile 0 of the segment is the next
@@ -2537,7 +2008,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc sd, int nTasks,
                                                              PanelDesc next, DataRef<T> dref,
                                                              int kStart, T* dinvOut, T* rawOut,
-                                                             int64_t rawStride, int atomicFromCol) {
+                                                             int64_t rawStride) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
   __shared__ __attribute__((aligned(16))) T As[kTile * LD];
   __shared__ __attribute__((aligned(16))) T Bs[kTile * LD];
@@ -2548,7 +2019,7 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
     GP<T> raw = rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr;
     // (the bulk tile body -- operands straight to LDS, no register prefetch -- was measured
     //  slower for these tiles: they run on the chain's stream, where latency counts)
-    updateTileDirectBody<T>(pd, sd, idx, data, As, Bs, raw, next.nb, atomicFromCol);
+    updateTileDirectBody<T>(pd, sd, idx, data, As, Bs, raw, next.nb);
     return;
   }
   __builtin_amdgcn_s_setprio(3);
@@ -2733,16 +2204,7 @@ template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void chainStep(
     PanelDesc pd, SegDesc sd, int nTasks, PanelDesc next, int fuse, DataRef<T> dref,
     const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase,
-    int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag,
-    int atomicFromCol, int memColBegin, int memColEnd) {
-  // atomicFromCol: tiles whose column tile starts at or beyond this below-row index subtract with
-  // atomics -- DUE SPLIT block-last steps (everything right of the first column tile) and CHAIN
-  // WINDOW steps (the next outer block's columns, shared with lookahead units); INT_MAX: none
-  // memColBegin / memColEnd (NOW SPLIT, LevelRange::nowHeadTiles): only the tiles of column tiles
-  // [memColBegin, memColEnd) (below-row indices) take the kMem source columns at memOff -- the
-  // block-last step passes [0, INT_MAX); the first two steps of the next block pass the ONE column
-  // tile that still owes the previous block's rank-256 update, with memOff pointing at that block's
-  // solved rows (shifted to this panel's row origin)
+    int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag) {
   // kMem0 <= kMem: source columns workgroup 0 still has to apply from memory to tile (0,0), the
   // LAST kMem0 of the kMem ones -- the earlier panels of the block applied theirs already, each in
   // its own step (extraDiag: one more workgroup, the diagonal tile just past the segment's columns
@@ -2761,8 +2223,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   GP<const T> Lkk = data + pd.diagOff;
   GP<T> P = data + pd.diagOff + (int64_t)nb * lda;  // the panel's rows below, in place
 
-  const int tileYield = fuse >> 1;  // (bit 1 of `fuse`: TILE YIELD on)
-  fuse &= 1;
   if (fuse && blockIdx.x == 0) {
     // tile (0,0) = the next panel's diagonal block: update it inside the potrf and factor it
     __builtin_amdgcn_s_setprio(3);
@@ -2801,7 +2261,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   __builtin_amdgcn_s_setprio(BSP_TILE_PRIO);
   BSP_STAMP_TILE(4);
-  tileYieldEnter(yieldFlag, tileYield);
   const bool extra = extraDiag && (int)blockIdx.x == nTasks;  // (grid = nTasks + 1 then)
   int idx = fuse ? 1 + xcdContiguous(blockIdx.x - 1, nTasks - 1) : xcdContiguous(blockIdx.x, nTasks);
   int colTile = sd.q0, rowTile;
@@ -2821,7 +2280,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int colEnd = extra ? segEnd + kTile : segEnd;  // columns this tile may write
   const int ri = rowTile + 16 * w + n, rj = colTile + 16 * w + n;
   Acc D[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-  if (kMem > 0 && !extra && colTile >= memColBegin && colTile < memColEnd) {
+  if (kMem > 0 && !extra) {
     // Tile (0,0) of the block-wide segment skips the panels that applied their update to it early
     // (extraDiag; kMem0 = what is left).  With a fused potrf that tile belongs to workgroup 0, above;
     // a block-last step whose update is this ONE tile (a last outer block of a single panel, no rows
@@ -2862,7 +2321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int reg = 0; reg < 4; reg++) {
       const int qr = rowTile + 16 * w + Mfma<T>::row(lane, reg);
       if (qc < colEnd && qr < rowsBelow && qr >= qc && qr >= sd.rowMin) {
-        if (extra || colTile >= atomicFromCol) {
+        if (extra) {
           atomicSub(tgt + (int64_t)qr * sd.tgtStride + qc, D[t][reg]);
         } else {
           const T val = old[t * 4 + reg] - D[t][reg];
@@ -2874,13 +2333,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
-  tileYieldLeave(yieldFlag, tileYield);
   BSP_STAMP_TILE(7);
   BSP_EXTENT_END(traceId, false);
 }
 
 // (A 128x128-tile variant of K5 -- 4x4 MFMA tiles per wave, 70 KB LDS, 2 workgroups per CU -- was
 // measured at 32-35 TF/s against 42 for the 64x64 tile at K = 256, and removed.)
+
+// empty launch: loads this translation unit's code object (HipSymbolicCtx::prepareDevice)
+__global__ void warmupKernel() {}
 
 // ------------------------------------------------------------------------------------------
 // Measurement helper: sustained rate of back-to-back independent v_mfma_f64_16x16x4_f64 (4

@@ -58,17 +58,12 @@ struct SegDesc {
   int32_t m;             // number of columns
   int64_t tgtBase;       // intra: data offset of element (row q=0, col q=0) of the target region
   int32_t tgtStride;     // row stride of the target lump
-  int32_t firstChainOrd; // board: below-diagonal chain ordinal of the segment's first chain;
-                         // intra WINDOW segment (pad bit 2): number of leading columns that lie in
-                         // the panel's own outer block -- the rest belong to the next block, where
-                         // lookahead units may be at work (those tiles subtract with atomics)
+  int32_t firstChainOrd; // board: below-diagonal chain ordinal of the segment's first chain
   int64_t chainTabPtr;   // board: index into chainOffTab of that chain's entry
   int32_t outer;         // 1: source is a complete outer block (rank-kOuterWidth update)
   int32_t lump;          // lump owning the source columns
   int32_t rowMin;        // rows (below-row index) smaller than this are left untouched
-  int32_t pad;           // bit 0: several writers in one launch, bit 1: writers of two side streams may
-                         // meet, bit 2: WINDOW segment (chainWindow), bit 3: window segment of a
-                         // block-last panel (the level waits for the lookahead units of its target)
+  int32_t pad;           // bit 0: several writers in one launch, bit 1: writers of two side streams may meet
 };
 
 struct UpdTask {
@@ -108,13 +103,6 @@ struct LevelRange {
   // [defBegin, defMid): the deferred tiles in the columns of the outer block AFTER the next one,
   // i.e. the only ones the next block's own update launch must wait for; they run first
   int64_t defMid = 0;
-  // DUE SPLIT (due-stream mode): [defBegin, defMid0) = the due tiles of the FIRST column tile of
-  // column block b + 2 -- what the next block's last step needs complete (it stages those columns
-  // for the block after and factors their tile (0,0)); [defMid0, defMid) = column tiles 1..3, which
-  // that step only adds to (with atomics) and which have to be complete one step later, when block
-  // b + 2 starts (waitDue1Level).  defMid0 == defMid: no split.
-  int64_t defMid0 = 0;
-  int64_t waitDue1Level = -1;  // level whose [defMid0, defMid) tiles this level needs complete
   // DIRECT chain kernels (hip_kernels.h): set when the level holds one panel; directSeg >= 0 when
   // its non-deferred tiles [updBegin, updEnd) are exactly the tiles of that one intra segment
   int32_t directPanel = -1, directSeg = -1;
@@ -133,10 +121,6 @@ struct LevelRange {
   int32_t rawNext = 0;
   int64_t waitDefLevel;          // index (within the same level list) of the level whose deferred
                                  // tiles must be complete before this level's update launch; -1
-  // OVERLAPPED ELIMINATION (ElimRangePlan::overlapLump): gather group that must be complete before
-  // this level's first launch on the execution stream / before its two deferred launches on the
-  // side stream (-1: none beyond what was already waited for)
-  int32_t waitGather = -1, defWaitGatherMid = -1, defWaitGatherEnd = -1;
   // intra-block step of a chain whose outer block is followed by another one: the step may also
   // apply its panel's rank-nb update to the NEXT block's tile (0,0) (chainStep, extraDiag), so that
   // the block-last step's potrf workgroup does not have to apply the whole block from memory
@@ -144,27 +128,6 @@ struct LevelRange {
   // due-stream mode: level whose OPTIONAL lookahead units (forked two outer blocks earlier: plain
   // read-modify-write on far columns) must be complete before this level's due units start; -1
   int64_t optWaitLevel = -1;
-  // NOW SPLIT (HipPlanOptions::nowSplit).  The block-last step of a chain applies the finished
-  // outer block (rank 256) to the NEXT block's 256 columns: ~390 tiles, two rounds of the one
-  // workgroup slot per CU the bulk tiles leave free, 46-84 us where an ordinary step takes 26 -- and
-  // the chain's next launch waits for all of them although it needs the first two column tiles only
-  // (it solves panel 0 and factors panel 1 of that block).  With the split the block-last step
-  // launches its first nowHeadTiles tasks (column tiles 0-1, column-tile-major as the direct kernels
-  // decode them) and the finished block's contribution to column tile 2 / 3 rides in the tiles of
-  // the next block's first / second step, which visit those columns anyway (chainStep: source
-  // columns from memory for one column tile, memCol): every launch of the chain is then about one
-  // round of its slot.  MEASURED (BAL-871, profiles/r3_ab_nowsplit.sh, tools/trace_extents.py): the
-  // block-last launch drops from 64-80 us to 28-41, but the two steps that inherit a column tile
-  // go from 34 / 45 us to 55 / 60 -- a tile with 256 source columns from memory takes ~50 us beside
-  // a saturated bulk stream whatever launch it is in -- and factor() stays at 6.87-6.91 ms against
-  // 6.85-6.88: opt-in, tested (test_schedule_variants).  A first variant that ran column tiles 2-3
-  // as bulk tiles on the due stream (event wait two steps later) was SLOWER, 7.56 ms: those tiles
-  // queue for slots behind the optional units like every due launch does.
-  // [soonBegin, soonMid) / [soonMid, soonEnd): the same tiles as self-contained
-  // bulk tasks (column tile 2 / 3), launched on the execution stream only if a following step turns
-  // out not to be a merged chain step (fallback, never the fast path).
-  int64_t soonBegin = 0, soonMid = 0, soonEnd = 0;
-  int32_t nowHeadTiles = 0;
 };
 
 // One work item of the gather-form sparse-elimination update: a target block (sj,si) of the
@@ -182,7 +145,6 @@ struct ElimGatherItem {
                             // items hold one or two pairs, and reading the list costs a dependent
                             // round trip (K2t)
 };
-constexpr int kElimPackSlot = 32;      // elements per slot of the packed operand copy
 constexpr int kGatherMaxElems = 256;   // rows*cols handled per wave (4 per lane)
 // pairs per work item: longer lists are split (the pieces subtract from the target with atomics).
 // One wave walks an item 8 pairs per memory round trip, so a 2048-pair item (the diagonal targets
@@ -195,31 +157,6 @@ constexpr uint32_t kGatherChunkElems = 0xffffffffu;  // optional slicing of the 
                                                      // cache-sized passes: measured 2x SLOWER on
                                                      // BAL-871 (more items + atomics), so disabled
 
-// one sparse-elimination range restricted to the planned lump range
-// ROW FORM of the sparse-elimination update (K2r, hip_kernels.h): one workgroup per ROW of target
-// blocks (all targets (sj, *) of one row span sj).  Its pairs are ordered by source column, then by
-// target column, so that for one source column the blocks B_i it needs are the contiguous head of
-// that column; every target of the row has an accumulator slot in LDS.
-struct ElimRowItem {
-  int32_t pairBegin, pairEnd;  // into elimPairOffJ / elimPairOffI / elimPairSlot
-  int32_t slotBegin, slotEnd;  // into elimRowSlots
-  int32_t ldsElems;            // accumulator values of the row (sum of rows x cols of its slots)
-  int16_t rows, n;             // |sj|, width of the source lumps
-  int32_t shared;              // 1: the row is cut into several items (by source column range)
-                               // that share its targets: subtract with atomics
-};
-constexpr int kRowFormMaxPairs = 12288;  // pairs per item: bounds the longest workgroup
-struct ElimRowSlot {
-  int64_t tgtOff;     // data offset of the target block
-  int32_t tgtStride;  // row stride of the target lump
-  int32_t ldsOff;     // first accumulator value of the slot
-  int16_t cols;       // |si|
-  int16_t flags;      // bit1: diagonal block (lower triangle only)
-  int32_t pad;
-};
-constexpr int kRowFormMaxLdsElems = 18432;  // 144 KB of fp64 accumulators per workgroup; rows with
-                                            // more are cut into parts by target column
-
 // One eliminated lump as the small-lump factor kernel wants it: everything behind one 16-byte load
 // instead of a chain of dependent skeleton lookups (the column is one dense (n + rows) x n block:
 // rows start right after the n x n diagonal block).
@@ -229,46 +166,21 @@ struct ElimLumpDesc {
   int32_t rowsBelow;
 };
 
+// one sparse-elimination range restricted to the planned lump range
 struct ElimRangePlan {
   int64_t lumpBegin, lumpEnd;
   int64_t chainBegin, chainEnd;  // absolute chain indices covered by the range
   int64_t chainLumpOff;          // offset into elimChainLump of chain `chainBegin`
   int32_t maxWidth;              // widest lump of the range
   int64_t descBegin = 0;         // offset into elimLumpDesc of lump `lumpBegin`
-  // PACKED OPERANDS (opt-in at plan time, see buildElimGather): every below-diagonal block of the
-  // range has packRows rows and fits a 32-element slot; the factor kernel then writes a second
-  // copy of each solved block at slot * kElimPackSlot of a scratch buffer, and the pair offsets of
-  // the gather items point there.  A 216-byte block of 9 x 3 doubles straddles 2.7 cache lines on
-  // average where it lies in the factor, exactly 2 in its slot.
-  int32_t packRows = 0;          // 0 = off
-  int64_t packSlotOff = 0;       // offset into HipPlanHost::elimPackSlot of lump `lumpBegin`
-  int64_t packSlots = 0;         // slots of the range
   std::vector<LevelRange> bigLevels;  // lumps wider than kElimSmallMax go through panels
   bool useGather = false;             // pair updates in gather form (atomic-free) ...
   int64_t itemBegin = 0, itemEnd = 0; // ... over these ElimGatherItems (one wave per item)
   int64_t tinyBegin = 0, tinyEnd = 0; // items with <= 16 target elements: 4 items per wave
   int64_t tiny9End = 0;               // [tinyBegin, tiny9End): target and both source blocks <= 9
                                       // elements (3x3 parameters): 7 items per wave
-  bool useRowForm = false;            // pair updates in row form instead ...
-  int64_t rowBegin = 0, rowEnd = 0;   // ... over these ElimRowItems (one workgroup per row)
-  int32_t rowLdsBytes = 0, rowLdsBytesF32 = 0;  // dynamic LDS of the launch (fp64 / fp32)
   int64_t ldsBegin = 0, ldsEnd = 0;   // items wider or taller than 16: LDS-staged kernel (K2g);
                                       // [itemBegin, itemEnd) go to the MFMA kernel (K2m)
-  // OVERLAP with the dense phase.  When every target of the range lies in the plan's single dense
-  // lump `overlapLump` (the bundle-adjustment shape: points eliminated onto one camera supernode),
-  // the MFMA items are grouped by the outer (256-column) block of their target column: group q =
-  // column blocks [groupColBlock[q], groupColBlock[q+1]) = items [groupItem[q], groupItem[q+1]).
-  // The groups run in order on a stream of their own while the dense chain already works on the
-  // column blocks whose groups are complete (LevelRange::waitGather / defWaitGather*).
-  int64_t overlapLump = -1;
-  std::vector<int32_t> groupColBlock;
-  std::vector<int64_t> groupItem;
-  std::vector<double> groupPairs;
-  int32_t groupOfColBlock(int64_t cb) const {
-    int32_t q = 0;
-    while (q + 2 < (int32_t)groupColBlock.size() && groupColBlock[q + 1] <= cb) q++;
-    return q;
-  }
 };
 
 // Every switch the plan builder honours, read ONCE (HipPlanOptions::fromEnv, called when a
@@ -278,25 +190,10 @@ struct ElimRangePlan {
 // streams cannot disagree.
 struct HipPlanOptions {
   bool dueStream = true;      // BSP_DUE_STREAM: due lookahead units on a stream of their own
-  bool earlyDue = false;      // BSP_EARLY_DUE (opt-in; needs dueStream)
-  bool dueSplit = false;      // BSP_DUE_SPLIT (opt-in; needs dueStream)
-  bool bulkRowMajor = true;   // BSP_BULK_ROW_MAJOR: lookahead tiles in row-tile-major order
-  bool elimPack = false;      // BSP_ELIM_PACK (opt-in): packed operand copy for the gather
-  bool gatherRowForm = false; // BSP_GATHER_ROW_FORM (opt-in): row form of the elimination update
-  bool elimOverlap = false;   // BSP_ELIM_OVERLAP (opt-in): gather groups beside the dense phase
   bool planTiming = false;    // BSP_TIMING: stderr laps of the gather plan
-  bool dropElimUpdate = false; // BSP_FAULT_DROP_ELIM_UPDATE=1: FAULT INJECTION for the parity tests
-                               // -- the sparse-elimination update is planned with zero pairs, so
-                               // the factor is wrong; never set outside tests
-  bool nowSplit = false;      // BSP_NOW_SPLIT=1 (opt-in; measured: no gain, below): a chain's block-wide "now" update keeps only the next
-                              // block's first two column tiles, the other two are applied by the
-                              // next block's first two steps (LevelRange::nowHeadTiles)
-  bool chainWindow = false;   // BSP_CHAIN_WINDOW: every panel of a multi-block lump updates through the
-                              // end of the NEXT outer block (rank 64) and the block-wide "now"
-                              // update disappears (SegDesc::pad bit 2, hip_plan.cpp addPanels)
-  bool gatherReverse = false; // BSP_GATHER_REVERSE: gather items from the LAST target row to the first
-                              // (the sources of the last rows are what the factor kernel wrote
-                              // last, i.e. what the memory-side cache still holds)
+  bool dropElimUpdate = false; // FAULT INJECTION for the parity tests (bsp_test_set_fault, never read
+                               // from the environment): the sparse-elimination update is not launched,
+                               // so the factor is wrong and the full-size checks must notice
   int32_t gatherMaxPairs = 128;  // BSP_GATHER_MAX_PAIRS
   double bulkAhead = 0.6;     // BSP_BULK_AHEAD
   static HipPlanOptions fromEnv();
@@ -309,16 +206,11 @@ struct HipPlanHost {
   std::vector<int32_t> elimChainLump;  // lump of every chain inside elimination ranges
   std::vector<ElimLumpDesc> elimLumpDesc;  // every lump of every elimination range
   std::vector<ElimGatherItem> elimItems;
-  std::vector<int32_t> elimPackSlot;  // per eliminated lump of a packed range: slot of its first below block
   std::vector<uint32_t> elimPairOffJ, elimPairOffI;
-  std::vector<uint16_t> elimPairSlot;  // row form: accumulator slot of every pair
-  std::vector<ElimRowItem> elimRows;
-  std::vector<ElimRowSlot> elimRowSlots;
 
   std::vector<PanelDesc> panels;
   std::vector<SrcDesc> srcs;
   std::vector<SegDesc> segs;
-  std::vector<int32_t> segColBlock;  // host only: target column block of a lookahead unit (else -1)
   std::vector<int64_t> chainOffTab;
   std::vector<int32_t> rowChain, rowLocal, rowColOff;  // per chain row of every dense lump
   std::vector<int32_t> rowGlobal;                      // ... and its row index in the full matrix
@@ -341,9 +233,6 @@ struct HipPlanHost {
   double elimPairFlops = 0;  // 2 * n * (pair elements)
   double elimColElems = 0;   // numeric elements of the sparse-eliminated columns
   int64_t numLaunches = 0;
-  // launch-bound: on average a launch carries too little work to cover its own dispatch (the
-  // criterion for running factor() as a captured graph, hip_backend.hip)
-  bool launchBound() const { return numLaunches > 8 && flops < 100e6 * double(numLaunches); }
   int64_t maxPanelsInLevel = 0;
   int64_t maxChainRows = 0;  // max rows below a panel whose level sets rawNext (staging buffer rows)
   bool hasDeferred = false;  // some level carries lookahead (deferred) tiles

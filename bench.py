@@ -182,14 +182,58 @@ def physical_cores():
     return (len(cores) or os.cpu_count() or 1), (threads or os.cpu_count() or 1), model
 
 
+def socket_cpus():
+    """{physical id: [first hardware thread of every core]} and the highest clock the host reports (MHz)"""
+    socks, seen, mhz = {}, set(), 0.0
+    try:
+        cpu = phys = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cpu = int(line.split(":", 1)[1])
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("cpu MHz"):
+                mhz = max(mhz, float(line.split(":", 1)[1]))
+            elif line.startswith("core id"):
+                key = (phys, line.split(":", 1)[1].strip())
+                if key not in seen:
+                    seen.add(key)
+                    socks.setdefault(phys, []).append(cpu)
+    except (OSError, ValueError):
+        pass
+    try:
+        mhz = max(mhz, float(open("/sys/devices/system/cpu/cpu0/cpufreq/cpuinfo_max_freq").read()) / 1e3)
+    except (OSError, ValueError):
+        pass
+    return socks, mhz
+
+
 def _cpu_baseline_once(sol, host, flops):
     """the BackendFast restatement (oracle/blas_factor.c: same call sequence and syrk/gemm rule as
-    MatOpsFast.cpp) on the host cores: 1 warm-up + median of 3 full factors of the same matrix"""
+    MatOpsFast.cpp) on the host cores: 1 warm-up + median of 5 full factors of the same matrix, the
+    BLAS team pinned to one hardware thread per core of ONE socket when it fits there (run-to-run
+    spread of the unpinned team on a two-socket host: 173-210 GF/s in round 3)"""
     from oracle import cref
     n_phys, n_threads, model = physical_cores()
+    socks, mhz = socket_cpus()
     # small problems run slower on a wide BLAS team (per-call fork/join on tiny fronts): about one
     # thread per 0.5 GF of work; the headline workload gets every physical core the BLAS accepts
     want = max(1, min(n_phys, int(flops / 0.5e9)))
+    # pin BEFORE the BLAS is loaded (it sizes its team from the affinity mask and its threads inherit
+    # it): one hardware thread per core of the largest socket -- north_star's "single-socket CPU"
+    # baseline; restored afterwards
+    pinned, old_aff = None, None
+    try:
+        best = max(socks.values(), key=len) if socks else []
+        if best and hasattr(os, "sched_setaffinity"):
+            old_aff = os.sched_getaffinity(0)
+            allowed = [c for c in best if c in old_aff][:want]
+            if allowed:
+                os.sched_setaffinity(0, allowed)
+                want = len(allowed)
+                pinned = "one socket, %d cores, one hardware thread each" % want
+    except OSError:
+        pinned = None
     _, blas_desc = cref.blas_lib(want)
     cap = want
     for tok in blas_desc.split():
@@ -199,7 +243,7 @@ def _cpu_baseline_once(sol, host, flops):
     skh = cref.SkelHandle(sol.skel())
     ranges = sol.sparseEliminationRanges()
     times, elims = [], []
-    for it in range(4):
+    for it in range(6):
         hostA = host.copy()
         t0 = time.perf_counter()
         es = cref.blas_factor(skh, hostA, ranges, want)
@@ -211,9 +255,22 @@ def _cpu_baseline_once(sol, host, flops):
             break
     if not times:
         times, elims = [dt], [es]
+    if old_aff is not None:
+        try:
+            os.sched_setaffinity(0, old_aff)
+        except OSError:
+            pass
     dt = statistics.median(times)
+    # fp64 peak of the cores used: 2 x 512-bit FMA pipes per core (Zen 4c/5, Skylake-X class) = 32
+    # flops per cycle at the highest clock the host reports -- an upper bound, stated beside the number
+    peak = used * 32.0 * mhz / 1e3 if mhz > 0 else None
     return {"value": round(flops / dt / 1e9, 2), "unit": "GF/s", "cores": used, "kind": "port",
             "seconds": round(dt, 3), "seconds_all": [round(t, 3) for t in times],
+            "spread_pct": round(100.0 * (max(times) - min(times)) / dt, 1),
+            "pinned": pinned or "no (team larger than a socket, or affinity not available)",
+            "host_peak_gflops": round(peak, 0) if peak else None,
+            "host_peak_note": "cores x 32 fp64 flops/cycle (2 x 512-bit FMA) x %.2f GHz" % (mhz / 1e3),
+            "frac_of_host_peak": round(flops / dt / 1e9 / peak, 4) if peak else None,
             "elim_seconds": round(statistics.median(elims), 3),
             "sample": "full factor() of the same matrix (same plan, same data): 1 warm-up + median of %d"
                       % len(times),
@@ -553,23 +610,34 @@ def spawn_ranks(n):
     if have < n:
         print("bench.py: --gpus %d but only %d GPU(s) visible" % (n, have), file=sys.stderr)
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    # The rendezvous port is picked by binding port 0 and closing the socket (rank 0's store has to
+    # bind it itself), so another process can take it in between: a launch whose ranks die within
+    # the rendezvous window is retried on a fresh port.
+    import time
     rc = 0
-    try:
-        for p in procs:
-            rc = p.wait() or rc
-    finally:
-        for p in procs:          # a rank that died leaves the others in a collective: end them
-            if p.poll() is None:
-                p.kill()
+    for attempt in range(3):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        t0 = time.time()
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+        rc = 0
+        try:
+            for p in procs:
+                rc = p.wait() or rc
+        finally:
+            for p in procs:          # a rank that died leaves the others in a collective: end them
+                if p.poll() is None:
+                    p.kill()
+        if rc == 0 or time.time() - t0 > 60:   # (a late failure is not a rendezvous problem)
+            break
+        print("bench.py: ranks failed within %.0f s (rc %d), retrying on a new port" % (time.time() - t0, rc),
+              file=sys.stderr)
     return rc
 
 

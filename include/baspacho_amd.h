@@ -144,6 +144,10 @@ int bsp_read_op_stats(bsp_solver* s, int32_t which, double* out, int64_t capacit
    (Solver.cpp:164-219, 270-397, 400-449) -- sparseElimSolveL/Lt, symm, solveL, gemv, assembleVec,
    solveLt, gemvT, assembleVecT, fragmentedMV/SolveL/SolveLt -- instead of the fused paths */
 int bsp_force_per_op(bsp_solver* s, int32_t on);
+/* TESTING, fault injection: kind 1 = factor() skips the sparse-elimination update (Solver.cpp:190-196
+ * doElimination's update half), so the factor is WRONG -- tests/test_full_size_gpu.py checks that the
+ * full-size parity checks then fail; 0 = off.  Not reachable through the environment. */
+int bsp_test_set_fault(bsp_solver* s, int32_t kind);
 /* TESTING hook of the reference: numCtx->doElimination(solver.internalGetElimCtx(i), ...)
    (Solver.h:139-145, tests/FactorTest.cpp:158-160) */
 int bsp_do_elimination_f64(bsp_solver* s, double* dev_data, int64_t elim_range_index);
@@ -257,7 +261,7 @@ typedef struct bsp_plan_stats {
       potrf_flops_fused;       /* ... of which inside the previous level's update launch */
   int64_t num_launches, num_levels, num_panels, num_segs, num_upd_tasks, num_trsm_tasks,
       chain_tab_entries, max_panels_in_level, num_atomic_upd_tasks,
-      num_gather_groups, /* > 0: sparse-elimination update split into groups that overlap the dense phase */
+      num_gather_groups, /* always 0 (kept for ABI stability) */
       num_fork_levels;   /* levels that hand lookahead units to the auxiliary streams */
   double deferred_flops; /* flops of those units; the lookahead schedule is used when they are worth
                             the forks (HipPlanHost::lookaheadPays) */

@@ -11,7 +11,7 @@ there (the diagonal is ~2e6, the off-diagonals are in (-1, 1)).  Now:
   * weakly damped inputs (diagonal = 1.05 x the absolute row sum: SPD by 5 % only) and REAL
     bundle-adjustment Hessians J^T J from the device pipeline (lambda = 1e-4) are factored at full
     size -- there the off-diagonal mass is as large as the diagonal and a wrong update is an O(1) error;
-  * a deliberately broken build of the plan (BSP_FAULT_DROP_ELIM_UPDATE=1: the elimination update is
+  * a deliberately broken build of the plan (bsp_test_set_fault(solver, 1): the elimination update is
     never launched) must turn the C3 check red.
 Protocol of the reference's FactorTest (tests/FactorTest.cpp:43-107) carried to sizes a dense LLT
 cannot reach; north-star tolerance 1e-10."""
@@ -142,9 +142,9 @@ def test_c3_dropped_elimination_update_is_detected(bal871, monkeypatch):
     round-2 probe could not see) must fail the very checks test_c3_bal871_full applies -- the oracle
     comparison AND the probe at its new threshold"""
     import torch
-    monkeypatch.setenv("BSP_FAULT_DROP_ELIM_UPDATE", "1")
     sizes, ss, _, _ = bal871
     sol = B.create_solver(B.Settings(), sizes, ss, [0, 527480])
+    sol._testSetFault(1)
     host = _data(sol, 37)
     dev = torch.from_numpy(host).cuda()
     sol.factor(dev)
