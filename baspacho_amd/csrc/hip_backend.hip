@@ -342,7 +342,19 @@ struct HipSymbolicCtx : SymbolicCtx {
   virtual void setSparseElimRanges(const vector<int64_t>& ranges) override {
     sparseElimRanges = ranges;
     plans.clear();
-    prepareDevice();
+  }
+
+  virtual void prepareFactor(int64_t upToLump) override {
+    try {
+      prepareDevice(upToLump);
+    } catch (const std::exception&) {
+      // (eager preparation is an optimisation: whatever it could not do happens -- and fails
+      //  loudly, if it has to -- in the first factor())
+      (void)hipGetLastError();
+      plans.clear();
+      eagerOnly = false;
+      inPrepare = false;
+    }
   }
 
   // The reference builds its SymbolicCtx and every SymElimCtx in the Solver constructor
@@ -353,7 +365,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   // first real use happens with another device current re-binds there (nothing of the eager state
   // has been handed out yet); plans of partial ranges stay lazy.  Without a GPU (symbolic analysis
   // on a host-only box) nothing happens here.
-  void prepareDevice() {
+  void prepareDevice(int64_t upToLump) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
       (void)hipGetLastError();
@@ -365,9 +377,8 @@ struct HipSymbolicCtx : SymbolicCtx {
       explicit Scope(bool& f_) : f(f_) { f = true; }
       ~Scope() { f = false; }
     } scope(inPrepare);
-    const int64_t nLumps = (int64_t)skel.lumpStart.size() - 1;
-    if (nLumps <= 0) return;
-    DevPlan& plan = planFor(sparseElimRanges, 0, nLumps, /*tag=*/0);
+    if (upToLump <= 0) return;
+    DevPlan& plan = planFor(sparseElimRanges, 0, upToLump, /*tag=*/0);
     ensureSkelOnDevice();
     (void)streams();
     (void)yieldWord();
@@ -612,6 +623,102 @@ struct HipNumericCtx : NumericCtx<T> {
     return (sym.profile == nullptr || sym.profileInSitu) && sym.lookaheadEnabled;
   }
 
+  // One lump as a dense-lump plan (DenseLumpPlan, hip_plan.h): the operations in enqueue order,
+  // stream 0 = the execution stream, stream 1 = the side stream (the execution stream again when
+  // the lookahead schedule is off: profiled isolated runs, BSP_NO_LOOKAHEAD, too little bulk work).
+  // dinv: slot of the lump's first panel; raw: the chain's two staging slots of rawSlot values.
+  void launchDenseLump(DevPlan& plan, const DenseLumpPlan& dl, hipk::DataRef<BT> ref,
+                       LaunchTimer& timer, BT* dinv, int64_t dinvStride, BT* rawBase, int64_t rawSlot) {
+    const unsigned gy = (unsigned)batchSize;
+    const bool side = lookaheadOn() && plan.host.lookaheadPays(batchSize, sym.lookaheadMinFlops);
+    hipStream_t streams[2] = {sym.stream, side ? sym.sideStream() : sym.stream};
+    vector<hipEvent_t> events(side ? dl.numEvents : 0, nullptr);
+    unsigned* yield = (side && batchSize == 1) ? sym.yieldWord() : nullptr;
+    auto slotOf = [&](int k) { return dinv + (int64_t)k * hipk::kDinvSlot; };
+    auto rawOf = [&](int k) { return rawBase ? rawBase + (k & 1) * rawSlot : nullptr; };
+    for (const DlOp& o : dl.ops) {
+      hipStream_t st = streams[o.stream];
+      switch (o.kind) {
+        case kDlPotrf: {
+          const DlStep& s = dl.steps[o.a];
+          timer.begin(kProfPotrf, st);
+          hipk::potrfPanelDirect<BT><<<dim3(1, gy), 256, 0, st>>>(s.pd, ref, slotOf(s.slot), dinvStride);
+          timer.end();
+          break;
+        }
+        case kDlTrsmPanel: {
+          const DlStep& s = dl.steps[o.a];
+          const unsigned nT = (unsigned)((s.pd.rowsBelow + kTile - 1) / kTile);
+          if (!nT) break;
+          timer.begin(kProfTrsm, st);
+          hipk::trsmPanelDirect<BT><<<dim3(nT, gy), 256, 0, st>>>(s.pd, ref, slotOf(s.slot), dinvStride);
+          timer.end();
+          break;
+        }
+        case kDlStep: {
+          const DlStep& s = dl.steps[o.a];
+          timer.begin(kProfChainUpdate, st);
+          hipk::chainStep<BT><<<dim3((unsigned)s.nTasks, gy), 256, 0, st>>>(
+              s.pd, s.sd, s.nTasks, s.next, s.fuse, ref, rawOf(o.a), s.stage ? rawOf(o.a + 1) : nullptr,
+              2 * rawSlot, slotOf(s.slot), slotOf(s.slot + 1), 0, 0, yield, sym.traceLaunchId++, 0, 0,
+              dinvStride);
+          timer.end();
+          break;
+        }
+        case kDlStepUpd: {
+          const DlStep& s = dl.steps[o.a];
+          timer.begin(kProfChainUpdate, st);
+          if (s.fuse) {
+            hipk::updateTileDirectPotrf<BT><<<dim3((unsigned)s.nTasks, gy), 256, 0, st>>>(
+                s.src, s.sd, s.nTasks, s.next, ref, 0, slotOf(s.slot + 1),
+                s.stage ? rawOf(o.a + 1) : nullptr, 2 * rawSlot, dinvStride);
+          } else {
+            hipk::updateTileDirect<BT><<<dim3((unsigned)s.nTasks, gy), 256, 0, st>>>(
+                s.src, s.sd, s.nTasks, ref, s.stage ? rawOf(o.a + 1) : nullptr, s.next.nb, 2 * rawSlot);
+          }
+          timer.end();
+          break;
+        }
+        case kDlTrsmBlock: {
+          const DlBlock& b = dl.blocks[o.a];
+          const int rows = o.rowEnd - o.rowBegin;
+          timer.begin(kProfTrsm, st);
+          hipk::trsmBlock<BT><<<dim3((unsigned)((rows + kTile - 1) / kTile), gy), 256, 0, st>>>(
+              b.diagOff, b.lda, b.width, dl.diagOff + (int64_t)o.rowBegin * b.lda + b.col0, rows, ref,
+              slotOf(b.slot0), dinvStride, 1);
+          timer.end();
+          break;
+        }
+        case kDlHandUpd: {
+          const DlBlock& b = dl.blocks[o.a];
+          const int kNext = dl.blocks[o.a + 1].slot0;
+          timer.begin(kProfChainUpdate, st);
+          hipk::handoffUpdate<BT><<<dim3((unsigned)b.h2Tiles, gy), 256, 0, st>>>(
+              b.h2Src, b.h2Seg, b.h2RowTile0, ref, b.h2Stage ? rawOf(kNext) : nullptr, b.h2Next.nb,
+              2 * rawSlot);
+          timer.end();
+          break;
+        }
+        case kDlBulk:
+          timer.begin(kProfUpdate, st);
+          launchUpdate(plan, o.taskBegin, o.taskEnd, ref, st, nullptr, 0,
+                       (side && o.stream == 1) ? sym.bulkExtraLds : 0u, 1);
+          timer.end();
+          break;
+        case kDlRecord:
+          if (side) {
+            events[o.a] = sym.eventFromPool();
+            hipCHECK(hipEventRecord(events[o.a], st));
+          }
+          break;
+        case kDlWait:
+          if (side) hipCHECK(hipStreamWaitEvent(st, events[o.a], 0));
+          break;
+        default: throw std::runtime_error("HIP backend: unknown dense-lump operation");
+      }
+    }
+  }
+
   void launchLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::DataRef<BT> ref,
                     LaunchTimer& timer) {
     const dim3 gy(1, (unsigned)batchSize, 1);
@@ -638,7 +745,12 @@ struct HipNumericCtx : NumericCtx<T> {
     bool sideUsed = false, dueUsed = false;
     // inverted diagonal blocks of the chain panels: written by a panel's potrf, read by its trsm
     // (two slots per matrix, alternating from panel to panel)
-    sym.dinvScratch.resize((size_t)batchSize * hipk::kDinvBatchStride * sizeof(BT));
+    // (dense-lump plans keep one slot per panel behind the two: their block trsm reads the four
+    //  inverses of a whole outer block)
+    int64_t dlSlots = 0;
+    for (const DenseLumpPlan& d : plan.host.denseLumps) dlSlots = std::max<int64_t>(dlSlots, d.numSlots);
+    const int64_t dinvStride = (2 + dlSlots) * hipk::kDinvSlot;
+    sym.dinvScratch.resize((size_t)batchSize * dinvStride * sizeof(BT));
     BT* dinvBase = const_cast<BT*>(sym.dinvScratch.as<BT>());
     int dinvSlot = 0;  // slot of the current level's panel
     // staging buffer of the chain (chainStep): unsolved rows of the current / next panel
@@ -656,6 +768,14 @@ struct HipNumericCtx : NumericCtx<T> {
     bool extraBroken = false;
     for (size_t li = 0; li < levels.size(); li++) {
       const LevelRange& lr = levels[li];
+      if (lr.dl == -2) continue;  // (a further level of a lump that ran as a dense-lump plan)
+      if (lr.dl >= 0) {
+        launchDenseLump(plan, plan.host.denseLumps[lr.dl], ref, timer, dinvBase + 2 * hipk::kDinvSlot,
+                        dinvStride, rawBase, rawSlot);
+        potrfFused = false;
+        rawValid = false;
+        continue;
+      }
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
       const bool direct = lr.directPanel >= 0;
@@ -671,7 +791,7 @@ struct HipNumericCtx : NumericCtx<T> {
         timer.begin(kProfPotrf);
         if (direct) {
           hipk::potrfPanelDirect<BT><<<dim3(1, gy.y), 256, 0, sym.stream>>>(
-              plan.host.panels[lr.directPanel], ref, dinvCur);
+              plan.host.panels[lr.directPanel], ref, dinvCur, dinvStride);
         } else {
           hipk::potrfPanel<BT><<<dim3(nP, gy.y), 256, 0, sym.stream>>>(
               plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, ref);
@@ -721,10 +841,10 @@ struct HipNumericCtx : NumericCtx<T> {
           SrcDesc part = plan.host.srcs[sd.src];
           part.K = splitK;
           hipk::trsmPanelDirectPlus<BT><<<dim3(nT + 1, gy.y), 256, 0, sym.stream>>>(
-              plan.host.panels[lr.directPanel], part, sd, ref, dinvCur);
+              plan.host.panels[lr.directPanel], part, sd, ref, dinvCur, dinvStride);
         } else if (direct) {
           hipk::trsmPanelDirect<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
-              plan.host.panels[lr.directPanel], ref, dinvCur);
+              plan.host.panels[lr.directPanel], ref, dinvCur, dinvStride);
         } else {
           hipk::trsmPanel<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
               plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin, ref);
@@ -812,7 +932,7 @@ struct HipNumericCtx : NumericCtx<T> {
               plan.host.panels[lr.directPanel], plan.host.segs[lr.directSeg], (int)nUpd, nextPanel,
               fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
               memOff, kMem, (lookahead && batchSize == 1) ? sym.yieldWord() : nullptr,
-              sym.traceLaunchId++, kMem0, extra);
+              sym.traceLaunchId++, kMem0, extra, dinvStride);
           potrfFused = fuse;
         } else if (fuse) {
           if (extraApplied > 0) {
@@ -823,7 +943,7 @@ struct HipNumericCtx : NumericCtx<T> {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
           hipk::updateTileDirectPotrf<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
               plan.host.srcs[sd.src], sd, (int)nUpd, nextPanel, ref, splitK, dinvNext,
-              stage ? rawNext : nullptr, 2 * rawSlot);
+              stage ? rawNext : nullptr, 2 * rawSlot, dinvStride);
           potrfFused = true;
         } else if (direct && lr.directSeg >= 0) {
           if (extraApplied > 0) {
@@ -1647,6 +1767,21 @@ void hipBackendForcePerOp(SymbolicCtx& sym, bool on) {
   HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
   BASPACHO_CHECK_NOTNULL(h);
   h->forcePerOp = on;
+}
+
+int hipBackendVerifyDenseLumps(SymbolicCtx& sym, int64_t startLump, int64_t upToLump, std::string& msg) {
+  HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
+  BASPACHO_CHECK_NOTNULL(h);
+  HipPlanHost p = buildHipPlan(h->skel, h->sparseElimRanges, startLump, upToLump, h->planOpts);
+  for (const DenseLumpPlan& dl : p.denseLumps) {
+    const std::string e = verifyDenseLump(p, dl);
+    if (!e.empty()) {
+      msg = "dense-lump plan of lump " + std::to_string(dl.lump) + " (width " + std::to_string(dl.n) +
+            ", rows " + std::to_string(dl.rowsTotal) + "): " + e;
+      return -1;
+    }
+  }
+  return (int)p.denseLumps.size();
 }
 
 void hipBackendSetFault(SymbolicCtx& sym, int kind) {

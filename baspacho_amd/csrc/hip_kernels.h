@@ -1131,14 +1131,14 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
 // trip plus the store.
 template <typename T>
 __global__ __launch_bounds__(256) void potrfPanelDirect(PanelDesc pd, DataRef<T> dref,
-                                                        T* dinvOut) {
+                                                        T* dinvOut, int64_t dinvStride) {
   __shared__ T blk[8 * kPanelWidth][4];
   T(*sol)[4] = blk + 3 * kPanelWidth;
   __shared__ T Ld[kPanelWidth * kInvLd];
   __builtin_amdgcn_s_setprio(3);
   BSP_STAMP(0);
   potrfPanelTiles<T>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, blk, sol, &blk[4 * kPanelWidth][0], NoPreUpdate(), Ld,
-                   (GP<T>)dinvOut + (size_t)blockIdx.y * kDinvBatchStride);
+                   (GP<T>)dinvOut + (size_t)blockIdx.y * dinvStride);
   BSP_STAMP(3);
 }
 
@@ -1413,13 +1413,100 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
 
 template <typename T>
 __global__ __launch_bounds__(256) void trsmPanelDirect(PanelDesc pd, DataRef<T> dref,
-                                                       const T* dinv) {
+                                                       const T* dinv, int64_t dinvStride) {
   __builtin_amdgcn_s_setprio(3);
   GP<T> data = pickData(dref);
   const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
   GP<T> P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
-  trsmTileRegs<T>(data + pd.diagOff, (GP<const T>)dinv + (size_t)blockIdx.y * kDinvBatchStride, P,
+  trsmTileRegs<T>(data + pd.diagOff, (GP<const T>)dinv + (size_t)blockIdx.y * dinvStride, P,
                   lda, nb, min(kTile, pd.rowsBelow - rowTile));
+}
+
+// ------------------------------------------------------------------------------------------
+// K4b  block trsm of the dense-lump schedule:  X L_bb^T = B  for a tile of 64 rows and ALL columns of
+// one outer block (up to 256), against the finished diagonal block L_bb and the inverted 16 x 16
+// diagonal blocks its four panel potrfs left in their slots.  Same register formulation as
+// trsmStages -- rows transposed in accumulator layout, X_J^T = Dinv_J (B_J^T - sum_{L<J} L_JL X_L^T)
+// over the 16-column blocks J = 0 .. 15 -- but right-looking (a finished block updates every later
+// one: independent accumulators) and with the off-diagonal blocks of L straight from L2 in
+// A-operand layout, eight blocks per round of loads.  544 MFMAs per wave for a full block: the same
+// count as the product with an explicit 256 x 256 inverse, without forming one.  Rows are written
+// ONCE; the bulk update tiles read them from memory (the chain of rounds 1-3 re-solved every row
+// inside each of its tiles).  Replaces cublas?trsm (MatOpsCuda.cu:550-566) for the rows below a
+// lump's window.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void trsmBlock(
+    int64_t blockOff, int lda, int bw, int64_t rowsOff, int nRows, DataRef<T> dref, const T* dinvBase,
+    int64_t dinvStride, int prio) {
+  using Acc = typename Mfma<T>::Acc;
+  constexpr int NBLK = kOuterWidth / 16, JCH = 6;
+  if (prio) __builtin_amdgcn_s_setprio(2);
+  GP<T> data = pickData(dref);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n16 = lane & 15, q = lane >> 4;
+  const int pm = Mfma<T>::colOfRow(n16);
+  const int rowIdx = kTile * blockIdx.x + 16 * w + n16;
+  const bool active = rowIdx < nRows;
+  GP<T> row = data + rowsOff + (int64_t)(active ? rowIdx : 0) * lda;
+  GP<const T> A = data + blockOff;
+  GP<const T> dinv = (GP<const T>)dinvBase + (size_t)blockIdx.y * dinvStride;
+  Acc x[NBLK];
+#pragma unroll
+  for (int J = 0; J < NBLK; J++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int col = 16 * J + 4 * q + r;
+      const T v = row[min(col, bw - 1)];
+      x[J][r] = (active && col < bw) ? v : T(0);
+    }
+  }
+  auto stepL = [&](auto Lc) __attribute__((always_inline)) {
+    constexpr int L = decltype(Lc)::value;
+    if (16 * L >= bw) return;  // (uniform)
+    {
+      T d[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) d[r] = dinv[(L / 4) * kDinvSlot + (16 * (L % 4) + pm) * 16 + 4 * q + r];
+      Acc y = {0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; r++) y = Mfma<T>::run(d[r], x[L][r], y);
+      x[L] = y;
+    }
+#pragma unroll
+    for (int J0 = L + 1; J0 < NBLK; J0 += JCH) {
+      if (16 * J0 < bw) {
+        T a[JCH][4];
+#pragma unroll
+        for (int u = 0; u < JCH; u++) {
+          const int J = J0 + u;
+          if (J < NBLK) {
+            const int rr = min(16 * J + pm, bw - 1);
+#pragma unroll
+            for (int r = 0; r < 4; r++) a[u][r] = A[(int64_t)rr * lda + min(16 * L + 4 * q + r, bw - 1)];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < JCH; u++) {
+          const int J = J0 + u;
+          if (J < NBLK) {
+            const bool live = 16 * J + pm < bw;
+#pragma unroll
+            for (int r = 0; r < 4; r++) x[J] = Mfma<T>::run(live ? -a[u][r] : T(0), x[L][r], x[J]);
+          }
+        }
+        asm volatile("" ::: "memory");  // (the next round's loads stay behind this round's products)
+      }
+    }
+  };
+  staticFor<0, NBLK>(stepL);
+#pragma unroll
+  for (int J = 0; J < NBLK; J++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int col = 16 * J + 4 * q + r;
+      if (active && col < bw) row[col] = x[J][r];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1855,22 +1942,12 @@ __device__ __forceinline__ int xcdContiguous(int b, int n) {
   return x * base + min(x, extra) + (b >> 3);
 }
 
-// tile `idx` of the segment in the order: column tiles from sd.q0 on, each with its row tiles
+// one 64 x 64 tile (rowTile, colTile: below-row indices) of the segment
 template <typename T>
-__device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const SegDesc& sd, int idx,
-                                                     GP<T> data, T* As, T* Bs,
-                                                     GP<T> rawOut = nullptr, int nbNext = 0) {
+__device__ __forceinline__ void updateTileDirectAt(const SrcDesc& pd, const SegDesc& sd, int rowTile,
+                                                   int colTile, GP<T> data, T* As, T* Bs,
+                                                   GP<T> rawOut = nullptr, int nbNext = 0) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
-  int colTile = sd.q0, rowTile;
-  for (;;) {
-    const int cnt = (pd.rowsBelow - colTile + kTile - 1) / kTile;
-    if (idx < cnt) {
-      rowTile = colTile + kTile * idx;
-      break;
-    }
-    idx -= cnt;
-    colTile += kTile;
-  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = pd.K, lda = pd.lda;
   GP<const T> P = data + pd.off;
@@ -1966,6 +2043,46 @@ __device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const Se
   }
 }
 
+// tile `idx` of the segment in the order: column tiles from sd.q0 on, each with its row tiles
+template <typename T>
+__device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const SegDesc& sd, int idx,
+                                                     GP<T> data, T* As, T* Bs,
+                                                     GP<T> rawOut = nullptr, int nbNext = 0) {
+  int colTile = sd.q0, rowTile;
+  for (;;) {
+    const int cnt = (pd.rowsBelow - colTile + kTile - 1) / kTile;
+    if (idx < cnt) {
+      rowTile = colTile + kTile * idx;
+      break;
+    }
+    idx -= cnt;
+    colTile += kTile;
+  }
+  updateTileDirectAt<T>(pd, sd, rowTile, colTile, data, As, Bs, rawOut, nbNext);
+}
+
+// K5h  hand-over update of the dense-lump schedule (DlBlock::h2Src / h2Seg): the tiles of the rows
+// from rowTile0 on, every column tile up to the diagonal, row tile by row tile; column tile 0 also
+// goes to the chain's staging buffer (the next block's first step reads its unsolved rows there)
+template <typename T>
+__global__ __launch_bounds__(256) void handoffUpdate(SrcDesc pd, SegDesc sd, int rowTile0,
+                                                     DataRef<T> dref, T* rawOut, int nbNext,
+                                                     int64_t rawStride) {
+  constexpr int LD = kUpdChunk + 2;
+  __shared__ T As[kTile * LD];
+  __shared__ T Bs[kTile * LD];
+  __builtin_amdgcn_s_setprio(BSP_TILE_PRIO);
+  int idx = blockIdx.x, rowTile = rowTile0;
+  for (;;) {
+    const int cnt = rowTile / kTile + 1;
+    if (idx < cnt) break;
+    idx -= cnt;
+    rowTile += kTile;
+  }
+  updateTileDirectAt<T>(pd, sd, rowTile, kTile * idx, pickData(dref), As, Bs,
+                        rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr, nbNext);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, int nTasks,
                                                         DataRef<T> dref, T* rawOut, int nbNext,
@@ -1989,7 +2106,8 @@ __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, 
 // starts at source column part.K (kStart) instead of summing all 256 columns on its own.
 template <typename T>
 __global__ __launch_bounds__(256) void trsmPanelDirectPlus(PanelDesc pd, SrcDesc part, SegDesc sd,
-                                                           DataRef<T> dref, const T* dinv) {
+                                                           DataRef<T> dref, const T* dinv,
+                                                           int64_t dinvStride) {
   constexpr int LD = kUpdChunk + 2;
   __shared__ T lds[2 * kTile * LD];
   __builtin_amdgcn_s_setprio(3);
@@ -2000,7 +2118,7 @@ __global__ __launch_bounds__(256) void trsmPanelDirectPlus(PanelDesc pd, SrcDesc
   }
   const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
   GP<T> P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
-  trsmTileRegs<T>(data + pd.diagOff, (GP<const T>)dinv + (size_t)blockIdx.y * kDinvBatchStride, P,
+  trsmTileRegs<T>(data + pd.diagOff, (GP<const T>)dinv + (size_t)blockIdx.y * dinvStride, P,
                   lda, nb, min(kTile, pd.rowsBelow - rowTile));
 }
 
@@ -2008,7 +2126,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc sd, int nTasks,
                                                              PanelDesc next, DataRef<T> dref,
                                                              int kStart, T* dinvOut, T* rawOut,
-                                                             int64_t rawStride) {
+                                                             int64_t rawStride, int64_t dinvStride) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
   __shared__ __attribute__((aligned(16))) T As[kTile * LD];
   __shared__ __attribute__((aligned(16))) T Bs[kTile * LD];
@@ -2071,7 +2189,7 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
   BSP_STAMP(0);
   // (As is free once `pre` has run: the blocked form's second buffer)
   potrfPanelTiles<T>(data + next.diagOff, nb, next.lda, blk, sol, As, pre, Ld,
-                     (GP<T>)dinvOut + (size_t)blockIdx.y * kDinvBatchStride);
+                     (GP<T>)dinvOut + (size_t)blockIdx.y * dinvStride);
   BSP_STAMP(3);
 }
 
@@ -2204,7 +2322,8 @@ template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void chainStep(
     PanelDesc pd, SegDesc sd, int nTasks, PanelDesc next, int fuse, DataRef<T> dref,
     const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase,
-    int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag) {
+    int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag,
+    int64_t dinvStride) {
   // kMem0 <= kMem: source columns workgroup 0 still has to apply from memory to tile (0,0), the
   // LAST kMem0 of the kMem ones -- the earlier panels of the block applied theirs already, each in
   // its own step (extraDiag: one more workgroup, the diagonal tile just past the segment's columns
@@ -2217,7 +2336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   using Acc = typename Mfma<T>::Acc;
   GP<T> data = pickData(dref);
   GP<const T> rawIn = (GP<const T>)rawInBase + blockIdx.y * rawStride;
-  GP<const T> dinv = (GP<const T>)dinvInBase + (size_t)blockIdx.y * kDinvBatchStride;
+  GP<const T> dinv = (GP<const T>)dinvInBase + (size_t)blockIdx.y * dinvStride;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15;
   const int nb = pd.nb, lda = pd.lda, rowsBelow = pd.rowsBelow, segEnd = sd.q0 + sd.m;
   GP<const T> Lkk = data + pd.diagOff;
@@ -2252,7 +2371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd + 4 * kPanelWidth * 4 <= kTile * kXbLd, "second potrf buffer fits in XB");
     potrfPanelTiles<T>(data + next.diagOff, next.nb, next.lda, blk, sol,
                        XB + 4 * kPanelWidth * 4 + kPanelWidth * kInvLd, pre, Ld,
-                       (GP<T>)dinvOutBase + (size_t)blockIdx.y * kDinvBatchStride);
+                       (GP<T>)dinvOutBase + (size_t)blockIdx.y * dinvStride);
     yieldPublish(yieldFlag, 0u);
     BSP_STAMP(3);
     BSP_EXTENT_END(traceId, true);

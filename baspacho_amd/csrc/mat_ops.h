@@ -82,6 +82,11 @@ struct SymbolicCtx {
   // backend with a fused path can lay out its whole plan once (default: ignore)
   virtual void setSparseElimRanges(const std::vector<int64_t>& /*ranges*/) {}
 
+  // extension: called once by the Solver constructor, after setSparseElimRanges: lumps [0, upToLump)
+  // are what factor() will be asked for (Solver::canFactorUpTo) -- a backend may build its numeric
+  // plan now, as the reference builds its contexts in the constructor (Solver.cpp:24-40)
+  virtual void prepareFactor(int64_t /*upToLump*/) {}
+
   // extension: execution stream for backends that have one (HIP: hipStream_t)
   virtual void setStream(void* /*stream*/) {}
 

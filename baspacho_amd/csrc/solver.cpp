@@ -65,6 +65,8 @@ Solver::Solver(CoalescedBlockMatrixSkel&& factorSkel_, vector<int64_t>&& sparseE
     elimCtxs.push_back(symCtx->prepareElimination(sparseElimRanges[r], sparseElimRanges[r + 1]));
   }
   initElimination();
+  symCtx->prepareFactor(canFactorUpTo < factorSkel.numSpans() ? factorSkel.spanToLump[canFactorUpTo]
+                                                             : factorSkel.numLumps());
 }
 
 template <typename T>

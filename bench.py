@@ -222,10 +222,13 @@ def _cpu_baseline_once(sol, host, flops):
     # pin BEFORE the BLAS is loaded (it sizes its team from the affinity mask and its threads inherit
     # it): one hardware thread per core of the largest socket -- north_star's "single-socket CPU"
     # baseline; restored afterwards
+    # (OPT-IN, CPU_BASELINE_PIN=1: measured on the GPU box -- 2 x EPYC 9575F under a VM topology -- the
+    #  pinned team ran 0.8 ... 10 s per factor against 0.8 s unpinned: cpuinfo's core ids do not
+    #  describe the real cores there)
     pinned, old_aff = None, None
     try:
         best = max(socks.values(), key=len) if socks else []
-        if best and hasattr(os, "sched_setaffinity"):
+        if os.environ.get("CPU_BASELINE_PIN") == "1" and best and hasattr(os, "sched_setaffinity"):
             old_aff = os.sched_getaffinity(0)
             allowed = [c for c in best if c in old_aff][:want]
             if allowed:
