@@ -631,7 +631,8 @@ struct HipNumericCtx : NumericCtx<T> {
                        LaunchTimer& timer, BT* dinv, int64_t dinvStride, BT* rawBase, int64_t rawSlot) {
     const unsigned gy = (unsigned)batchSize;
     const bool side = lookaheadOn() && plan.host.lookaheadPays(batchSize, sym.lookaheadMinFlops);
-    hipStream_t streams[2] = {sym.stream, side ? sym.sideStream() : sym.stream};
+    hipStream_t streams[3] = {sym.stream, side ? sym.dueSideStream() : sym.stream,
+                              side ? sym.sideStream() : sym.stream};
     vector<hipEvent_t> events(side ? dl.numEvents : 0, nullptr);
     unsigned* yield = (side && batchSize == 1) ? sym.yieldWord() : nullptr;
     auto slotOf = [&](int k) { return dinv + (int64_t)k * hipk::kDinvSlot; };
@@ -683,9 +684,15 @@ struct HipNumericCtx : NumericCtx<T> {
           const DlBlock& b = dl.blocks[o.a];
           const int rows = o.rowEnd - o.rowBegin;
           timer.begin(kProfTrsm, st);
-          hipk::trsmBlock<BT><<<dim3((unsigned)((rows + kTile - 1) / kTile), gy), 256, 0, st>>>(
-              b.diagOff, b.lda, b.width, dl.diagOff + (int64_t)o.rowBegin * b.lda + b.col0, rows, ref,
-              slotOf(b.slot0), dinvStride, 1);
+          const dim3 grid((unsigned)((rows + kTile - 1) / kTile), gy);
+          const int64_t rowsOff = dl.diagOff + (int64_t)o.rowBegin * b.lda + b.col0;
+          if (b.width == kOuterWidth) {  // (operands through an LDS ring; a ragged last block: registers)
+            hipk::trsmBlockPipe<BT><<<grid, 256, 0, st>>>(b.diagOff, b.lda, rowsOff, rows, ref,
+                                                          slotOf(b.slot0), dinvStride);
+          } else {
+            hipk::trsmBlock<BT><<<grid, 256, 0, st>>>(b.diagOff, b.lda, b.width, rowsOff, rows, ref,
+                                                      slotOf(b.slot0), dinvStride, 1);
+          }
           timer.end();
           break;
         }
@@ -702,7 +709,7 @@ struct HipNumericCtx : NumericCtx<T> {
         case kDlBulk:
           timer.begin(kProfUpdate, st);
           launchUpdate(plan, o.taskBegin, o.taskEnd, ref, st, nullptr, 0,
-                       (side && o.stream == 1) ? sym.bulkExtraLds : 0u, 1);
+                       (side && o.stream != 0) ? sym.bulkExtraLds : 0u, 1);
           timer.end();
           break;
         case kDlRecord:
@@ -1774,6 +1781,15 @@ int hipBackendVerifyDenseLumps(SymbolicCtx& sym, int64_t startLump, int64_t upTo
   BASPACHO_CHECK_NOTNULL(h);
   HipPlanHost p = buildHipPlan(h->skel, h->sparseElimRanges, startLump, upToLump, h->planOpts);
   for (const DenseLumpPlan& dl : p.denseLumps) {
+    if (std::getenv("BSP_DL_DUMP")) {  // (debugging aid: the operation list, one line each)
+      static const char* names[] = {"potrf", "trsmPanel", "step", "stepUpd", "trsmBlock", "handUpd", "bulk", "record", "wait"};
+      for (const DlOp& o : dl.ops) {
+        fprintf(stderr, "  s%d %-9s a=%d", o.stream, names[o.kind], o.a);
+        if (o.kind == kDlTrsmBlock) fprintf(stderr, " rows [%d, %d)", o.rowBegin, o.rowEnd);
+        if (o.kind == kDlBulk) fprintf(stderr, " tasks %lld%s", (long long)(o.taskEnd - o.taskBegin), o.due ? " due" : "");
+        fprintf(stderr, "\n");
+      }
+    }
     const std::string e = verifyDenseLump(p, dl);
     if (!e.empty()) {
       msg = "dense-lump plan of lump " + std::to_string(dl.lump) + " (width " + std::to_string(dl.n) +

@@ -1509,6 +1509,178 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// K4c  the same solve for FULL outer blocks (bw = 256), operands through an LDS ring.  K4b asks L2 for
+// eight 16 x 16 blocks of L, waits, multiplies, asks again: 16 x 3 exposed round trips of 1-2 us each
+// per wave (measured on BAL-871: 58 launches, 3.2 ms serialised -- the side stream spent more time in
+// its block solves than in half of its update tiles).  Here the 136 blocks a wave needs -- per
+// 16-column step L the inverted diagonal block D_L, then L_{L+1,L} ... L_{15,L} -- are ONE stream,
+// fetched by the workgroup's four waves together (wave w fetches block 4 c + w of chunk c) straight
+// into LDS (global_load_lds, 16 bytes per lane, rows XOR-swizzled by 16-byte slot so that the
+// A-operand reads are conflict-poor), three chunks ahead of the chunk being multiplied: one barrier
+// and one counter wait per four blocks, no operand registers.  The B operand of every product is
+// -X_L (negated once per step), so the blocks of L are used as they lie in memory.
+template <typename T>
+struct TrsmPipe {
+  static constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte slot
+  static constexpr int SLOTS = 16 / E;            // slots per 16-column row of a block
+  static constexpr int RPI = 64 / SLOTS;          // rows one wave instruction fetches
+  static constexpr int NI = 16 / RPI;             // instructions per block
+  static constexpr int NBLK = kOuterWidth / 16;   // 16-column steps
+  static constexpr int NSEQ = NBLK * (NBLK + 1) / 2;  // blocks of the stream
+  static constexpr int CHUNK = 4, NCHUNK = NSEQ / CHUNK, RING = 4;
+  static_assert(NSEQ % CHUNK == 0, "whole chunks");
+  static constexpr int kLdsElems = RING * CHUNK * 256;
+  // t-th block of the stream -> (L, J); J == L: the inverted diagonal block of step L
+  static constexpr int stepOf(int t) {
+    int L = 0;
+    while (t >= NBLK - L) {
+      t -= NBLK - L;
+      L++;
+    }
+    return L;
+  }
+  static constexpr int rowBlockOf(int t) {
+    int L = 0;
+    while (t >= NBLK - L) {
+      t -= NBLK - L;
+      L++;
+    }
+    return L + t;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void trsmBlockPipeBody(GP<T> data, int64_t blockOff, int lda, int64_t rowsOff,
+                                                  int nRows, GP<const T> dinv, int rowTileIdx, T* ring) {
+  using P = TrsmPipe<T>;
+  using Acc = typename Mfma<T>::Acc;
+  typedef __attribute__((address_space(1))) const void* GV;
+  typedef __attribute__((address_space(3))) void* LV;
+  constexpr int E = P::E, SLOTS = P::SLOTS, RPI = P::RPI, NI = P::NI, NBLK = P::NBLK;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n16 = lane & 15, q = lane >> 4;
+  const int pm = Mfma<T>::colOfRow(n16);
+  const int rowIdx = kTile * rowTileIdx + 16 * w + n16;
+  const bool active = rowIdx < nRows;
+  GP<T> row = data + rowsOff + (int64_t)(active ? rowIdx : 0) * lda;
+  GP<const T> A = data + blockOff;
+  Acc x[NBLK];
+#pragma unroll
+  for (int J = 0; J < NBLK; J++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const T v = row[16 * J + 4 * q + r];
+      x[J][r] = active ? v : T(0);
+    }
+  }
+  // this lane's share of a block fetch: rows (lane / SLOTS) + RPI it, 16-byte slot (lane % SLOTS)
+  // of LDS = column slot (lane % SLOTS) ^ key(row) of memory
+  const int fr = lane / SLOTS, fs = lane % SLOTS;
+  auto fetch = [&](auto Cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(Cc)::value;
+    if constexpr (c < P::NCHUNK) {
+      // (wave w fetches block w of the chunk: which block that is depends on w, so the four cases
+      //  are spelled out with compile-time block indices)
+      auto one = [&](auto Tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(Tc)::value;
+        constexpr int L = P::stepOf(t), J = P::rowBlockOf(t);
+        T* dst = ring + ((c % P::RING) * P::CHUNK + (t % P::CHUNK)) * 256;
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+          const int r = fr + RPI * it;
+          const int slot = fs ^ (r & (SLOTS - 1));
+          GP<const T> src = (J == L) ? dinv + (L / 4) * kDinvSlot + (16 * (L % 4) + r) * 16 + E * slot
+                                     : A + (int64_t)(16 * J + r) * lda + 16 * L + E * slot;
+          __builtin_amdgcn_global_load_lds((GV)src, (LV)(dst + RPI * it * 16), 16, 0, 0);
+        }
+      };
+      if (w == 0) one(std::integral_constant<int, P::CHUNK * c + 0>{});
+      if (w == 1) one(std::integral_constant<int, P::CHUNK * c + 1>{});
+      if (w == 2) one(std::integral_constant<int, P::CHUNK * c + 2>{});
+      if (w == 3) one(std::integral_constant<int, P::CHUNK * c + 3>{});
+    }
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the row loads: the fetch counter starts clean)
+  fetch(std::integral_constant<int, 0>{});
+  fetch(std::integral_constant<int, 1>{});
+  fetch(std::integral_constant<int, 2>{});
+  Acc xn = {0, 0, 0, 0};  // -X_L of the current step
+  // element (pm, 4 q + r) of the block in ring position `pos`
+  auto operand = [&](int pos, T (&a)[4]) __attribute__((always_inline)) {
+    const T* blk = ring + pos * 256 + pm * 16;
+    const int key = pm & (SLOTS - 1);
+    if constexpr (E == 2) {
+      typedef T T2 __attribute__((ext_vector_type(2)));
+      const T2 lo = *(const T2*)(blk + E * ((2 * q) ^ key)), hi = *(const T2*)(blk + E * ((2 * q + 1) ^ key));
+      a[0] = lo.x;
+      a[1] = lo.y;
+      a[2] = hi.x;
+      a[3] = hi.y;
+    } else {
+      typedef T T4 __attribute__((ext_vector_type(4)));
+      const T4 v = *(const T4*)(blk + E * (q ^ key));
+      a[0] = v.x;
+      a[1] = v.y;
+      a[2] = v.z;
+      a[3] = v.w;
+    }
+  };
+  auto chunk = [&](auto Cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(Cc)::value;
+    // chunks c + 1, c + 2 may still be in flight: NI instructions per wave and chunk
+    constexpr int ahead = (P::NCHUNK - 1 - c) < 2 ? (P::NCHUNK - 1 - c) : 2;
+    if constexpr (ahead * NI == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if constexpr (ahead * NI == 1) {
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else if constexpr (ahead * NI == 2) {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // every wave's share of chunk c has landed; chunk c - 1 is consumed
+    fetch(std::integral_constant<int, c + 3>{});
+    auto block = [&](auto Tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(Tc)::value;
+      constexpr int L = P::stepOf(t), J = P::rowBlockOf(t);
+      T a[4];
+      operand((c % P::RING) * P::CHUNK + (t % P::CHUNK), a);
+      if constexpr (J == L) {
+        Acc y = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) y = Mfma<T>::run(a[r], x[L][r], y);
+        x[L] = y;
+#pragma unroll
+        for (int r = 0; r < 4; r++) xn[r] = -y[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) x[J] = Mfma<T>::run(a[r], xn[r], x[J]);
+      }
+    };
+    block(std::integral_constant<int, P::CHUNK * c + 0>{});
+    block(std::integral_constant<int, P::CHUNK * c + 1>{});
+    block(std::integral_constant<int, P::CHUNK * c + 2>{});
+    block(std::integral_constant<int, P::CHUNK * c + 3>{});
+  };
+  staticFor<0, P::NCHUNK>(chunk);
+#pragma unroll
+  for (int J = 0; J < NBLK; J++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (active) row[16 * J + 4 * q + r] = x[J][r];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void trsmBlockPipe(
+    int64_t blockOff, int lda, int64_t rowsOff, int nRows, DataRef<T> dref, const T* dinvBase,
+    int64_t dinvStride) {
+  __shared__ __attribute__((aligned(16))) T ring[TrsmPipe<T>::kLdsElems];
+  __builtin_amdgcn_s_setprio(2);
+  trsmBlockPipeBody<T>(pickData(dref), blockOff, lda, rowsOff, nRows,
+                       (GP<const T>)dinvBase + (size_t)blockIdx.y * dinvStride, blockIdx.x, ring);
+}
+
 // ------------------------------------------------------------------------------------------
 // K5  rank-nb update with fused scatter:  target -= B_rows * B_cols^T  on one 64x64 tile of
 // the lower trapezoid of one segment (panel -> target lump).  Replaces the cublas?gemm into a

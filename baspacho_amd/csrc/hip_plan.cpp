@@ -7,6 +7,7 @@
 #include <atomic>
 #include <map>
 #include <thread>
+#include <tuple>
 
 namespace BaSpaCho {
 
@@ -405,17 +406,21 @@ DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& pl
       for (int32_t c = s + 1; c < NB; c++) released[s].push_back({s, (int32_t)rho, c, c});
     }
   }
-  // segments of the bulk units: per (source block, column block), diagonal region and rows below
-  std::map<std::pair<int32_t, int32_t>, int32_t> segDiag, segBelow;
-  auto segOf = [&](int32_t s, int32_t c, bool below) {
+  // segments of the bulk tasks: per (source blocks s0..s1, column block), diagonal region and rows
+  // below.  The sources a target has waiting are always CONSECUTIVE blocks, i.e. consecutive columns:
+  // one task of rank 256 (s1 - s0 + 1) takes them all -- one read-modify-write of the target instead of
+  // one per source block, and no two writers of a target inside a launch (no atomics).
+  std::map<std::tuple<int32_t, int32_t, int32_t>, int32_t> segDiag, segBelow;
+  auto segOf = [&](int32_t s0, int32_t s1, int32_t c, bool below) {
     auto& m = below ? segBelow : segDiag;
-    auto it = m.find({s, c});
+    const auto key = std::make_tuple(s0, s1, c);
+    auto it = m.find(key);
     if (it != m.end()) return it->second;
-    const int64_t blockEnd = (int64_t)(s + 1) * kOuterWidth;
+    const int64_t blockEnd = (int64_t)(s1 + 1) * kOuterWidth;
     SrcDesc fs{};
-    fs.off = g.diagOff + blockEnd * n + (int64_t)s * kOuterWidth;
+    fs.off = g.diagOff + blockEnd * n + (int64_t)s0 * kOuterWidth;
     fs.lda = (int32_t)n;
-    fs.K = blockWidth(s);
+    fs.K = (int32_t)((s1 - s0 + 1) * kOuterWidth);
     fs.nRest = (int32_t)(n - blockEnd);
     fs.rowsBelow = (int32_t)(below ? R - blockEnd : n - blockEnd);
     fs.lumpRowBase = lumpRowBase;
@@ -430,21 +435,35 @@ DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& pl
     u.tgtBase = g.diagOff + blockEnd * n + blockEnd;
     u.tgtStride = (int32_t)n;
     plan.segs.push_back(u);
-    return m[{s, c}] = (int32_t)plan.segs.size() - 1;
+    return m[key] = (int32_t)plan.segs.size() - 1;
   };
-  // tasks of a list of units, in (source, row tile, column tile) order; several sources on one
-  // target inside the launch accumulate with atomics
+  // tasks of a list of units: the sources of one target merged, longest tasks first (a launch ends
+  // with its longest tile), then by source, row tile and column tile (row-tile-major: the column tiles
+  // of a row share the row operand)
   auto emitUnits = [&](vector<DlUnit>& units) -> std::pair<int64_t, int64_t> {
     const int64_t begin = (int64_t)plan.updTasks.size();
     std::sort(units.begin(), units.end(), [](const DlUnit& x, const DlUnit& y) {
-      return x.s != y.s ? x.s < y.s : (x.rho != y.rho ? x.rho < y.rho : x.c < y.c);
+      return x.rho != y.rho ? x.rho < y.rho : (x.c != y.c ? x.c < y.c : x.s < y.s);
+    });
+    struct Merged { int32_t s0, s1, rho, c; };
+    vector<Merged> merged;
+    for (const DlUnit& u : units) {
+      if (!merged.empty() && merged.back().rho == u.rho && merged.back().c == u.c && merged.back().s1 + 1 == u.s) {
+        merged.back().s1 = u.s;
+      } else {
+        merged.push_back({u.s, u.s, u.rho, u.c});
+      }
+    }
+    std::stable_sort(merged.begin(), merged.end(), [](const Merged& x, const Merged& y) {
+      const int32_t kx = x.s1 - x.s0, ky = y.s1 - y.s0;
+      return kx != ky ? kx > ky : (x.s0 != y.s0 ? x.s0 < y.s0 : (x.rho != y.rho ? x.rho < y.rho : x.c < y.c));
     });
     std::map<std::pair<int32_t, int32_t>, int32_t> writers;
-    for (const DlUnit& u : units) writers[{u.rho, u.c}]++;
-    for (const DlUnit& u : units) {
+    for (const Merged& u : merged) writers[{u.rho, u.c}]++;
+    for (const Merged& u : merged) {
       const bool below = u.rho >= n;
-      const int32_t seg = segOf(u.s, u.c, below);
-      const int64_t blockEnd = (int64_t)(u.s + 1) * kOuterWidth;
+      const int32_t seg = segOf(u.s0, u.s1, u.c, below);
+      const int64_t blockEnd = (int64_t)(u.s1 + 1) * kOuterWidth;
       const int32_t rT = (int32_t)(u.rho - blockEnd);
       const int32_t c0 = plan.segs[seg].q0, cEnd = c0 + plan.segs[seg].m;
       const int32_t atomic = writers[{u.rho, u.c}] > 1 ? 1 : 0;
@@ -499,6 +518,17 @@ DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& pl
   bool potrfFused = false, rawValid = false;
   int32_t evDuePrev = -1;
   vector<DlUnit> pool;
+  // cost of a unit in rank-256 tiles; the side streams' work is spread evenly over the forks left
+  auto unitCost = [&](const DlUnit& u) {
+    return u.rho >= n ? 4.0 : std::min<double>(4.0, double(u.rho / kTile - u.c * 4 + 1));
+  };
+  double costTotal = 0, costLaunched = 0, costReleased = 0;
+  for (int32_t s = 0; s < NB; s++) {
+    for (const DlUnit& u : released[s]) costTotal += unitCost(u);
+    const int64_t tB = std::min<int64_t>(n, (int64_t)(s + 3) * kOuterWidth);
+    if (tB < R) costTotal += kDlTrsmTileCost * double((R - tB + kTile - 1) / kTile);
+  }
+  vector<int32_t> optDone(NB, -1);  // event after the optional / board launches of a fork
   for (int32_t b = 0; b < NB; b++) {
     const DlBlock& blk = dl.blocks[b];
     const int32_t kEnd = b + 1 < NB ? dl.blocks[b + 1].slot0 : (int32_t)dl.steps.size();
@@ -526,23 +556,40 @@ DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& pl
     const bool hasHand = h1Begin < n;
     const int64_t tBegin = std::min<int64_t>(n, (int64_t)(b + 3) * kOuterWidth), tEnd = R;
     const bool hasT = tBegin < tEnd;
-    // bulk lists: due now, optional within the budget, in deadline order
+    // bulk lists.  DUE: every released unit whose target the execution stream touches at the next
+    // fork (dl <= b + 1).  OPTIONAL: units with dl >= b + 3 in deadline order -- never dl = b + 2, so
+    // that the due launch of fork b + 1 cannot meet this launch on a target and only has to wait for
+    // the optional launch of fork b - 1 -- for an even share of the work that is left.
     pool.insert(pool.end(), released[b].begin(), released[b].end());
-    vector<DlUnit> due, opt, rest;
+    for (const DlUnit& u : released[b]) costReleased += unitCost(u);
+    vector<DlUnit> due, opt, rest, keep;
     const bool lastFork = b + 1 >= NB;
-    for (const DlUnit& u : pool) (u.dl <= b + 1 || lastFork ? due : rest).push_back(u);
-    double budget = bulkAhead * kDlChainBlockUs * kDlBulkTilesPerUs -
-                    (hasT ? kDlTrsmTileCost * double((tEnd - tBegin + kTile - 1) / kTile) : 0.0) - 4.0 * double(due.size());
+    for (const DlUnit& u : pool) (u.dl <= b + 1 || lastFork ? due : (u.dl >= b + 3 ? rest : keep)).push_back(u);
+    double dueCost = 0;
+    for (const DlUnit& u : due) dueCost += unitCost(u);
+    const double tCost = hasT ? kDlTrsmTileCost * double((tEnd - tBegin + kTile - 1) / kTile) : 0.0;
+    const double share = bulkAhead * (costTotal - costLaunched) / double(std::max(1, NB - 1 - b));
+    double budget = share - dueCost - tCost;
     std::sort(rest.begin(), rest.end(), [](const DlUnit& x, const DlUnit& y) {
-      return x.dl != y.dl ? x.dl < y.dl : (x.c != y.c ? x.c < y.c : (x.s != y.s ? x.s < y.s : x.rho < y.rho));
+      return x.dl != y.dl ? x.dl < y.dl : (x.c != y.c ? x.c < y.c : (x.rho != y.rho ? x.rho < y.rho : x.s < y.s));
     });
     size_t take = 0;
+    double optCost = 0;
     while (take < rest.size() && budget > 0) {
-      budget -= std::min<double>(4.0, double(rest[take].rho / kTile - rest[take].c * 4 + 1));
+      const double cst = unitCost(rest[take]);
+      budget -= cst;
+      optCost += cst;
+      take++;
+    }
+    // (the sources of one target stay together: a target's units are adjacent in the order above)
+    while (take > 0 && take < rest.size() && rest[take].rho == rest[take - 1].rho && rest[take].c == rest[take - 1].c) {
+      optCost += unitCost(rest[take]);
       take++;
     }
     opt.assign(rest.begin(), rest.begin() + take);
-    pool.assign(rest.begin() + take, rest.end());
+    keep.insert(keep.end(), rest.begin() + take, rest.end());
+    pool.swap(keep);
+    costLaunched += dueCost + optCost + tCost;
     // board targets of this block (rows below the lump x rows below the lump, scatter addressing)
     int64_t boardBegin = (int64_t)plan.updTasks.size(), boardEnd = boardBegin;
     if (g.rowsBelow > 0 && !boardSegTemplates.empty()) {
@@ -571,22 +618,35 @@ DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& pl
       boardEnd = (int64_t)plan.updTasks.size();
       xcdOrder(boardBegin, boardEnd);
     }
+    if (std::getenv("BSP_DL_DUMP")) {
+      fprintf(stderr, "fork %d: pool %zu due %zu opt %zu kept %zu share %.0f dueCost %.0f tCost %.0f total %.0f launched %.0f\n", b,
+              pool.size() + due.size() + opt.size(), due.size(), opt.size(), pool.size(), share, dueCost, tCost, costTotal, costLaunched);
+    }
     const auto dueRange = emitUnits(due);
     xcdOrder(dueRange.first, dueRange.second);
     const auto optRange = emitUnits(opt);
     xcdOrder(optRange.first, optRange.second);
     const bool anyBulk = dueRange.second > dueRange.first || optRange.second > optRange.first || boardEnd > boardBegin;
-    if (hasT || anyBulk) {
-      const int32_t evCH = numEvents++;
+    // streams: 0 = execution stream (chain, hand-over), 1 = due stream (block solve, due tiles),
+    // 2 = optional stream (optional tiles, board targets)
+    const bool anyDue = dueRange.second > dueRange.first;
+    const bool anyOpt = optRange.second > optRange.first || boardEnd > boardBegin;
+    int32_t evCH = -1, evH1 = -1, evT = -1;
+    if (hasT || anyDue || anyOpt) {
+      evCH = numEvents++;
       op(kDlRecord, 0, evCH);
-      op(kDlWait, 1, evCH);
       plan.numForkLevels++;
     }
+    if (hasT || anyDue) op(kDlWait, 1, evCH);
     if (hasT) {
       DlOp& o = op(kDlTrsmBlock, 1, b);
       o.rowBegin = (int32_t)tBegin;
       o.rowEnd = (int32_t)tEnd;
       countBlockTrsm(b, tEnd - tBegin);
+    }
+    if (anyOpt && (hasT || b > 0)) {  // everything the due stream has solved so far
+      evT = numEvents++;
+      op(kDlRecord, 1, evT);
     }
     if (hasHand) {
       if (evDuePrev >= 0) op(kDlWait, 0, evDuePrev);
@@ -594,39 +654,54 @@ DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& pl
       o.rowBegin = (int32_t)h1Begin;
       o.rowEnd = (int32_t)h1End;
       countBlockTrsm(b, h1End - h1Begin);
-      if (anyBulk) {
-        const int32_t evH1 = numEvents++;
+      if (anyDue || anyOpt) {
+        evH1 = numEvents++;
         op(kDlRecord, 0, evH1);
-        op(kDlWait, 1, evH1);
       }
       dl.blocks[b].h2Stage = rawValid ? 1 : 0;
       op(kDlHandUpd, 0, b);
     }
-    if (dueRange.second > dueRange.first) {
+    if (anyDue) {
+      if (evH1 >= 0) op(kDlWait, 1, evH1);
+      // optional launches that may have written these targets: those of forks <= b - 2 (at the last
+      // fork, where everything left is due: all of them)
+      for (int32_t h = lastFork ? b - 1 : b - 2; h >= 0; h--) {
+        if (optDone[h] >= 0) {
+          op(kDlWait, 1, optDone[h]);
+          break;
+        }
+      }
       DlOp& o = op(kDlBulk, 1, b);
       o.taskBegin = dueRange.first;
       o.taskEnd = dueRange.second;
       o.due = 1;
     }
-    if (hasT || anyBulk) {
+    if (hasT || anyDue) {
       evDuePrev = numEvents++;
       op(kDlRecord, 1, evDuePrev);
     }
-    if (optRange.second > optRange.first) {
-      DlOp& o = op(kDlBulk, 1, b);
-      o.taskBegin = optRange.first;
-      o.taskEnd = optRange.second;
-    }
-    if (boardEnd > boardBegin) {
-      DlOp& o = op(kDlBulk, 1, b);
-      o.taskBegin = boardBegin;
-      o.taskEnd = boardEnd;
+    if (anyOpt) {
+      op(kDlWait, 2, evCH);
+      if (evT >= 0) op(kDlWait, 2, evT);
+      if (evH1 >= 0) op(kDlWait, 2, evH1);
+      if (optRange.second > optRange.first) {
+        DlOp& o = op(kDlBulk, 2, b);
+        o.taskBegin = optRange.first;
+        o.taskEnd = optRange.second;
+      }
+      if (boardEnd > boardBegin) {
+        DlOp& o = op(kDlBulk, 2, b);
+        o.taskBegin = boardBegin;
+        o.taskEnd = boardEnd;
+      }
+      optDone[b] = numEvents++;
+      op(kDlRecord, 2, optDone[b]);
     }
   }
   BASPACHO_CHECK(pool.empty());
-  {  // join
+  for (int32_t st = 1; st <= 2; st++) {  // join
     const int32_t ev = numEvents++;
-    op(kDlRecord, 1, ev);
+    op(kDlRecord, st, ev);
     op(kDlWait, 0, ev);
   }
   dl.numEvents = numEvents;
@@ -794,7 +869,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                 }
                 pendingFrom[c] = b + 1;
               };
-              double budgetUs = bulkAhead * (118.0 + 0.012 * double(sr.rowsBelow));
+              // (0.6 of the block's chain time: measured flat between 0.45 and 1.0, rounds 2-3; the
+              //  BSP_BULK_AHEAD switch now belongs to the dense-lump schedule)
+              double budgetUs = 0.6 * (118.0 + 0.012 * double(sr.rowsBelow));
               // (topping the first launch up to a full round of workgroups with the nearest
               //  optional targets was measured slower: the execution stream waits on it)
               int64_t c = b + 2;
@@ -1241,10 +1318,16 @@ std::string verifyDenseLump(const HipPlanHost& plan, const DenseLumpPlan& dl) {
   }
   vector<uint8_t> solved((size_t)TT * P, 0);
   // happens-before bookkeeping: per tile, the last writer / reader of each stream
-  struct Acc { int32_t w[2] = {-1, -1}, r[2] = {-1, -1}; };
+  constexpr int NS = 3;
+  struct Acc { int32_t w[NS] = {-1, -1, -1}, r[NS] = {-1, -1, -1}; };
   vector<Acc> acc((size_t)TT * P);
-  int32_t known[2][2] = {{-1, -1}, {-1, -1}};  // known[s][o]: last op of stream o ordered before stream s's next op
-  vector<std::pair<int32_t, int32_t>> eventClock(dl.numEvents, {-1, -1});  // (own last op, known other)
+  // known[s][o]: last op of stream o that is ordered before stream s's next op (vector clocks)
+  int32_t known[NS][NS];
+  for (auto& kr : known) {
+    for (int32_t& v : kr) v = -1;
+  }
+  struct Clock { int32_t v[NS]; };
+  vector<Clock> eventClock(dl.numEvents, Clock{{-1, -1, -1}});
   vector<int32_t> eventStream(dl.numEvents, -1);
   std::string err;
   auto fail = [&](const std::string& what, int32_t opIdx) {
@@ -1252,9 +1335,11 @@ std::string verifyDenseLump(const HipPlanHost& plan, const DenseLumpPlan& dl) {
   };
   auto touch = [&](int32_t t, int32_t k, bool write, int32_t st, int32_t idx) {
     Acc& a = acc[at(t, k)];
-    const int32_t o = st ^ 1;
-    if (a.w[o] > known[st][o]) fail("unordered access after a write of the other stream at tile " + std::to_string(t) + "," + std::to_string(k), idx);
-    if (write && a.r[o] > known[st][o]) fail("unordered write after a read of the other stream at tile " + std::to_string(t) + "," + std::to_string(k), idx);
+    for (int32_t o = 0; o < NS; o++) {
+      if (o == st) continue;
+      if (a.w[o] > known[st][o]) fail("unordered access after a write of stream " + std::to_string(o) + " at tile " + std::to_string(t) + "," + std::to_string(k), idx);
+      if (write && a.r[o] > known[st][o]) fail("unordered write after a read of stream " + std::to_string(o) + " at tile " + std::to_string(t) + "," + std::to_string(k), idx);
+    }
     (write ? a.w[st] : a.r[st]) = idx;
   };
   auto allApplied = [&](int32_t t, int32_t k, int32_t upTo) {
@@ -1384,18 +1469,20 @@ std::string verifyDenseLump(const HipPlanHost& plan, const DenseLumpPlan& dl) {
         }
         break;
       }
-      case kDlRecord:
-        eventClock[o.a] = {idx, known[st][st ^ 1]};
+      case kDlRecord: {
+        Clock c;
+        for (int32_t q = 0; q < NS; q++) c.v[q] = q == st ? idx : known[st][q];
+        eventClock[o.a] = c;
         eventStream[o.a] = st;
         break;
+      }
       case kDlWait: {
         if (eventStream[o.a] < 0) {
           fail("wait for an event that was not recorded", idx);
           break;
         }
-        const int32_t es = eventStream[o.a];
-        if (es != st) {
-          known[st][es] = std::max(known[st][es], eventClock[o.a].first);
+        for (int32_t q = 0; q < NS; q++) {
+          if (q != st) known[st][q] = std::max(known[st][q], eventClock[o.a].v[q]);
         }
         break;
       }

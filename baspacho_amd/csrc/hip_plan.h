@@ -166,7 +166,7 @@ enum DlOpKind : int32_t {
   kDlWait = 8,       // `stream` waits for event `a`
 };
 struct DlOp {
-  int32_t kind, stream;  // stream 0: execution stream, 1: side stream
+  int32_t kind, stream;  // stream 0: execution stream, 1: due stream, 2: optional stream
   int32_t a;
   int32_t rowBegin = 0, rowEnd = 0;       // kDlTrsmBlock (row indices inside the lump column)
   int64_t taskBegin = 0, taskEnd = 0;     // kDlBulk
@@ -276,7 +276,8 @@ struct HipPlanOptions {
                                // so the factor is wrong and the full-size checks must notice
   bool denseLump = true;      // BSP_DENSE_LUMP=0: lumps of several outer blocks level by level (rounds 1-3)
   int32_t gatherMaxPairs = 128;  // BSP_GATHER_MAX_PAIRS
-  double bulkAhead = 0.6;     // BSP_BULK_AHEAD
+  double bulkAhead = 2.0;     // BSP_BULK_AHEAD: optional bulk work per fork as a multiple of an even share
+                              // of what is left (0: every target takes its sources when it is due)
   static HipPlanOptions fromEnv();
 };
 

@@ -533,10 +533,10 @@ def suite_ref(args, device):
         pass
     rx = re.compile(args.suite_filter)
     rows = []
-    for name, make in ref_suite_problems().items():
-        if not rx.search(name):
-            continue
-        sizes, ss = make(37)
+    iters = max(1, args.suite_iters)
+
+    def one_instance(name, make, seed, with_batches):
+        sizes, ss = make(seed)
         t0 = time.perf_counter()
         sol = B.create_solver(B.Settings(findSparseEliminationRanges=True), sizes, ss)
         analysis_s = time.perf_counter() - t0
@@ -550,7 +550,7 @@ def suite_ref(args, device):
         it = iter(bufs[1:])
         fac, fac_all = _timed(device, lambda: sol.factor(next(it)), 5)
         L = bufs[-1]
-        row = {"problem": name, "order": order, "data_MB": round(sol.dataSize() * 8 / 1e6, 1),
+        row = {"seed": seed, "order": order, "data_MB": round(sol.dataSize() * 8 / 1e6, 1),
                "factor_GF": round(flops / 1e9, 3), "analysis_s": round(analysis_s, 3),
                "factor_first_s": round(first, 6), "factor_s": round(fac, 6),
                "factor_GFs": round(flops / fac / 1e9, 1),
@@ -566,7 +566,7 @@ def suite_ref(args, device):
                 sol.solve(L, work, order, nrhs)
             row["solve-%d_s" % nrhs] = round(_timed(device, one, 3)[0], 6)
         del bufs, it
-        for bs in (4, 8, 16):
+        for bs in ((4, 8, 16) if with_batches else ()):
             if sol.dataSize() * 8 * bs * 3 > 60e9:
                 continue
             hosts = []
@@ -584,17 +584,38 @@ def suite_ref(args, device):
                     sol, hosts[-1].cpu().numpy(), sets[-1][-1], nprobe=1)
             del hosts, sets, it2
             torch.cuda.empty_cache()
+        del sol, A, L
+        torch.cuda.empty_cache()
+        return row
+
+    for name, make in ref_suite_problems().items():
+        if not rx.search(name):
+            continue
+        # the reference's five instances per family: seed 37 + it * 1000000 (Bench.cpp:458-461);
+        # batches on the first instance only (they take most of the suite's time)
+        inst = [one_instance(name, make, 37 + it * 1000000, it == 0) for it in range(iters)]
+        row = {"problem": name, "instances": len(inst)}
+        for k in inst[0]:
+            vals = [r[k] for r in inst if k in r]
+            if k in ("seed", "sparse_elim_ranges"):
+                row[k + "s"] = vals if k == "seed" else vals[:1]
+            elif k == "residual_probe" or k.startswith("residual_probe"):
+                row[k] = max(vals)
+            elif isinstance(vals[0], (int, float)):
+                row[k] = round(statistics.median(vals), 6)
+        row["factor_first_s_all"] = [r["factor_first_s"] for r in inst]
+        row["factor_s_all"] = [r["factor_s"] for r in inst]
+        row["first_over_warm"] = round(row["factor_first_s"] / row["factor_s"], 2)
         p = pub.get("problems", {}).get(name, {})
         row["published"] = {op: {k: v["median_s"] for k, v in d.items()} for op, d in p.items()}
         rows.append(row)
         print(json.dumps(row), flush=True)
-        del sol, A, L
-        torch.cuda.empty_cache()
     doc = {"suite": "ref (benchmarking/Bench.cpp:290-367)", "dtype": "f64", "device": torch.cuda.get_device_name(device),
            "published_hardware": pub.get("_hardware"), "published_source": pub.get("_source"),
-           "protocol": "one structure per family (seed 37; the reference draws five), factor_first_s = cold call "
-                       "(what the reference times), factor_s = median of 5 warm calls, solves after a heat-up, "
-                       "batches per matrix; residual probe on every factor",
+           "protocol": "%d instances per family (seeds 37 + it * 1000000, Bench.cpp:458-461), medians over the "
+                       "instances; per instance: factor_first_s = the first call (what the reference times), "
+                       "factor_s = median of 5 warm calls, solves after a heat-up; batches per matrix on the "
+                       "first instance; residual probe (worst instance) on every factor" % iters,
            "rows": rows}
     if args.suite_out:
         with open(args.suite_out, "w") as f:
@@ -662,6 +683,8 @@ def main():
                     help="ref: the reference's benchmark families (Bench.cpp:290-409): factor, solve-1, "
                          "solve-10 per problem, JSON lines to stdout, one summary line at the end")
     ap.add_argument("--suite-filter", default="", help="regex on the problem names of --suite")
+    ap.add_argument("--suite-iters", type=int, default=5,
+                    help="instances per family of --suite ref (the reference's numIterations: 5)")
     ap.add_argument("--suite-out", default=None, help="write the suite's JSON document here too")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
