@@ -659,10 +659,14 @@ struct HipNumericCtx : NumericCtx<T> {
         case kDlStep: {
           const DlStep& s = dl.steps[o.a];
           timer.begin(kProfChainUpdate, st);
-          hipk::chainStep<BT><<<dim3((unsigned)s.nTasks, gy), 256, 0, st>>>(
+          const int auxRows = o.rowEnd - o.rowBegin;
+          const unsigned auxTiles = (unsigned)((auxRows + kTile - 1) / kTile);
+          const DlBlock& blk = dl.blocks[s.block];
+          hipk::chainStep<BT><<<dim3((unsigned)s.nTasks + auxTiles, gy), 256, 0, st>>>(
               s.pd, s.sd, s.nTasks, s.next, s.fuse, ref, rawOf(o.a), s.stage ? rawOf(o.a + 1) : nullptr,
               2 * rawSlot, slotOf(s.slot), slotOf(s.slot + 1), 0, 0, yield, sym.traceLaunchId++, 0, 0,
-              dinvStride);
+              dinvStride, auxTiles ? s.nTasks : INT32_MAX, blk.diagOff,
+              dl.diagOff + (int64_t)o.rowBegin * blk.lda + blk.col0, auxRows, slotOf(blk.slot0));
           timer.end();
           break;
         }

@@ -2495,14 +2495,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     PanelDesc pd, SegDesc sd, int nTasks, PanelDesc next, int fuse, DataRef<T> dref,
     const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase,
     int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag,
-    int64_t dinvStride) {
+    int64_t dinvStride, int auxFirst = 0x7fffffff, int64_t auxBlockOff = 0, int64_t auxRowsOff = 0,
+    int auxRows = 0, const T* auxDinv = nullptr) {
+  // auxFirst .. : workgroups from this index on do not belong to the step: they solve row tiles of
+  // auxRows rows at auxRowsOff against the whole outer block at auxBlockOff (trsmBlockPipeBody, the
+  // hand-over of the dense-lump schedule riding in the block's last step)
   // kMem0 <= kMem: source columns workgroup 0 still has to apply from memory to tile (0,0), the
   // LAST kMem0 of the kMem ones -- the earlier panels of the block applied theirs already, each in
   // its own step (extraDiag: one more workgroup, the diagonal tile just past the segment's columns
   // = the next outer block's tile (0,0), rank-nb, with atomics: lookahead units of the side stream
   // may be working on that tile too).  The block-last step's potrf workgroup then starts from a
   // plain rank-nb update like every other step instead of a rank-256 one (10-25 us per block).
-  __shared__ T XB[kTile * kXbLd];
+  __shared__ __attribute__((aligned(16))) T XB[kTile * kXbLd];
+  static_assert(kTile * kXbLd >= 4 * 4 * 256, "the block solve's operand ring fits in XB");
+  if ((int)blockIdx.x >= auxFirst) {
+    __builtin_amdgcn_s_setprio(2);
+    trsmBlockPipeBody<T>(pickData(dref), auxBlockOff, pd.lda, auxRowsOff, auxRows,
+                         (GP<const T>)auxDinv + (size_t)blockIdx.y * dinvStride, (int)blockIdx.x - auxFirst, XB);
+    return;
+  }
   BSP_EXTENT_BEGIN(traceId);
   static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd <= kTile * kXbLd, "potrf LDS fits in XB");
   using Acc = typename Mfma<T>::Acc;

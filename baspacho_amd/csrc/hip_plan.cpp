@@ -292,7 +292,8 @@ struct DlUnit {
 
 DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, int64_t l,
                              const LumpCols& g, int32_t lumpRowBase,
-                             const vector<SegDesc>& boardSegTemplates, double bulkAhead) {
+                             const vector<SegDesc>& boardSegTemplates, double bulkAhead, int32_t group) {
+  group = std::max(1, group);
   DenseLumpPlan dl;
   const int64_t n = g.width, R = g.width + g.rowsBelow;
   const int32_t NB = (int32_t)((n + kOuterWidth - 1) / kOuterWidth);
@@ -532,12 +533,24 @@ DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& pl
   for (int32_t b = 0; b < NB; b++) {
     const DlBlock& blk = dl.blocks[b];
     const int32_t kEnd = b + 1 < NB ? dl.blocks[b + 1].slot0 : (int32_t)dl.steps.size();
+    bool h1Ridden = false;
     for (int32_t k = blk.slot0; k < kEnd; k++) {
       const DlStep& st = dl.steps[k];
       if (!potrfFused) op(kDlPotrf, 0, k);
       if (st.nTasks > 0) {
         if (rawValid) {
-          op(kDlStep, 0, k);
+          // the block's last step also carries the hand-over's block solve (H1: the rows of row block
+          // b + 2 against the whole block -- its last panel was factored by the previous launch) as
+          // extra workgroups: one launch less on the execution stream per outer block
+          const int64_t hb = (int64_t)(b + 2) * kOuterWidth, he = std::min<int64_t>(n, hb + kOuterWidth);
+          const bool ride = k == kEnd - 1 && hb < n && blk.width == kOuterWidth;
+          if (ride && evDuePrev >= 0) op(kDlWait, 0, evDuePrev);
+          DlOp& o = op(kDlStep, 0, k);
+          if (ride) {
+            o.rowBegin = (int32_t)hb;
+            o.rowEnd = (int32_t)he;
+            h1Ridden = true;
+          }
           plan.trsmFlopsMerged += double(st.pd.rowsBelow) * st.pd.nb * st.pd.nb;
         } else {
           op(kDlTrsmPanel, 0, k);
@@ -564,7 +577,13 @@ DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& pl
     for (const DlUnit& u : released[b]) costReleased += unitCost(u);
     vector<DlUnit> due, opt, rest, keep;
     const bool lastFork = b + 1 >= NB;
-    for (const DlUnit& u : pool) (u.dl <= b + 1 || lastFork ? due : (u.dl >= b + 3 ? rest : keep)).push_back(u);
+    // (optional launches go out every `group` forks and take targets at least group + 3 forks away:
+    //  the due launches of the forks in between never meet them on a target, so the chain runs on
+    //  while a long optional launch -- rank 256 x group, one read-modify-write per target -- is at work)
+    const bool groupFork = (b + 1) % group == 0;
+    for (const DlUnit& u : pool) {
+      (u.dl <= b + 1 || lastFork ? due : (groupFork && u.dl >= b + group + 3 ? rest : keep)).push_back(u);
+    }
     double dueCost = 0;
     for (const DlUnit& u : due) dueCost += unitCost(u);
     const double tCost = hasT ? kDlTrsmTileCost * double((tEnd - tBegin + kTile - 1) / kTile) : 0.0;
@@ -649,23 +668,27 @@ DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& pl
       op(kDlRecord, 1, evT);
     }
     if (hasHand) {
-      if (evDuePrev >= 0) op(kDlWait, 0, evDuePrev);
-      DlOp& o = op(kDlTrsmBlock, 0, b);
-      o.rowBegin = (int32_t)h1Begin;
-      o.rowEnd = (int32_t)h1End;
       countBlockTrsm(b, h1End - h1Begin);
-      if (anyDue || anyOpt) {
-        evH1 = numEvents++;
-        op(kDlRecord, 0, evH1);
+      if (h1Ridden) {
+        evH1 = evCH;  // (solved inside the block's last step)
+      } else {
+        if (evDuePrev >= 0) op(kDlWait, 0, evDuePrev);
+        DlOp& o = op(kDlTrsmBlock, 0, b);
+        o.rowBegin = (int32_t)h1Begin;
+        o.rowEnd = (int32_t)h1End;
+        if (anyDue || anyOpt) {
+          evH1 = numEvents++;
+          op(kDlRecord, 0, evH1);
+        }
       }
       dl.blocks[b].h2Stage = rawValid ? 1 : 0;
       op(kDlHandUpd, 0, b);
     }
     if (anyDue) {
-      if (evH1 >= 0) op(kDlWait, 1, evH1);
-      // optional launches that may have written these targets: those of forks <= b - 2 (at the last
-      // fork, where everything left is due: all of them)
-      for (int32_t h = lastFork ? b - 1 : b - 2; h >= 0; h--) {
+      if (evH1 >= 0 && evH1 != evCH) op(kDlWait, 1, evH1);
+      // optional launches that may have written these targets: those of forks <= b - group - 2 (at the
+      // last fork, where everything left is due: all of them)
+      for (int32_t h = lastFork ? b - 1 : b - group - 2; h >= 0; h--) {
         if (optDone[h] >= 0) {
           op(kDlWait, 1, optDone[h]);
           break;
@@ -683,7 +706,7 @@ DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& pl
     if (anyOpt) {
       op(kDlWait, 2, evCH);
       if (evT >= 0) op(kDlWait, 2, evT);
-      if (evH1 >= 0) op(kDlWait, 2, evH1);
+      if (evH1 >= 0 && evH1 != evCH) op(kDlWait, 2, evH1);
       if (optRange.second > optRange.first) {
         DlOp& o = op(kDlBulk, 2, b);
         o.taskBegin = optRange.first;
@@ -720,6 +743,7 @@ HipPlanOptions HipPlanOptions::fromEnv() {
   o.planTiming = std::getenv("BSP_TIMING") != nullptr;
   if (const char* e = std::getenv("BSP_GATHER_MAX_PAIRS")) o.gatherMaxPairs = std::max(8, atoi(e));
   if (const char* e = std::getenv("BSP_BULK_AHEAD")) o.bulkAhead = std::atof(e);
+  if (const char* e = std::getenv("BSP_DL_GROUP")) o.dlGroup = std::max(1, atoi(e));
   return o;
 }
 
@@ -1052,7 +1076,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     lastLevelOfLump[l] = level + n - 1;
     if (isDenseLump[l]) {
       const int32_t id = (int32_t)plan.denseLumps.size();
-      plan.denseLumps.push_back(buildDenseLump(sk, plan, l, g, lumpRowBase, boardSegs, bulkAhead));
+      plan.denseLumps.push_back(buildDenseLump(sk, plan, l, g, lumpRowBase, boardSegs, bulkAhead, opts.dlGroup));
       dlFirstPanel[first] = id;
       for (int32_t j = 1; j < n; j++) dlOtherPanel[first + j] = id;
     }
@@ -1384,19 +1408,8 @@ std::string verifyDenseLump(const HipPlanHost& plan, const DenseLumpPlan& dl) {
     }
     if (fused) potrf(k + 1, st, idx);
   };
-  int32_t idx = 0;
-  for (const DlOp& o : dl.ops) {
-    const int32_t st = o.stream;
-    switch (o.kind) {
-      case kDlPotrf: potrf(o.a, st, idx); break;
-      case kDlTrsmPanel: trsmPanelWindow(o.a, st, idx); break;
-      case kDlStep:
-        trsmPanelWindow(o.a, st, idx);
-        updWindow(o.a, dl.steps[o.a].fuse != 0, st, idx);
-        break;
-      case kDlStepUpd: updWindow(o.a, dl.steps[o.a].fuse != 0, st, idx); break;
-      case kDlTrsmBlock: {
-        const DlBlock& b = dl.blocks[o.a];
+  auto trsmBlockRows = [&](int32_t blockIdx, int32_t rowBegin, int32_t rowEnd, int32_t st, int32_t idx) {
+        const DlBlock& b = dl.blocks[blockIdx];
         const int32_t k0 = b.slot0, k1 = k0 + (b.width + kPanelWidth - 1) / kPanelWidth;
         for (int32_t k = k0; k < k1; k++) {
           for (int32_t c = k0; c <= k; c++) {
@@ -1405,8 +1418,8 @@ std::string verifyDenseLump(const HipPlanHost& plan, const DenseLumpPlan& dl) {
             touch(k, c, false, st, idx);
           }
         }
-        if (o.rowBegin % kTile != 0 && o.rowBegin != n) fail("trsmBlock rows not tile aligned", idx);
-        for (int64_t rho = o.rowBegin; rho < o.rowEnd; rho += kTile) {
+        if (rowBegin % kTile != 0 && rowBegin != n) fail("trsmBlock rows not tile aligned", idx);
+        for (int64_t rho = rowBegin; rho < rowEnd; rho += kTile) {
           const int32_t t = rowTileOf(rho);
           for (int32_t k = k0; k < k1; k++) {
             if (!allApplied(t, k, k0)) fail("trsmBlock of an incomplete tile " + std::to_string(t) + "," + std::to_string(k), idx);
@@ -1417,13 +1430,25 @@ std::string verifyDenseLump(const HipPlanHost& plan, const DenseLumpPlan& dl) {
             solved[at(t, k)] = 1;
             touch(t, k, true, st, idx);
           }
-          if (rho < n && rho + kTile > n && o.rowEnd > n) {
+          if (rho < n && rho + kTile > n && rowEnd > n) {
             // (the ragged last tile of the diagonal region: the rows below start a tile of their own)
             rho = n - kTile;
           }
         }
+  };
+  int32_t idx = 0;
+  for (const DlOp& o : dl.ops) {
+    const int32_t st = o.stream;
+    switch (o.kind) {
+      case kDlPotrf: potrf(o.a, st, idx); break;
+      case kDlTrsmPanel: trsmPanelWindow(o.a, st, idx); break;
+      case kDlStep:
+        if (o.rowEnd > o.rowBegin) trsmBlockRows(dl.steps[o.a].block, o.rowBegin, o.rowEnd, st, idx);
+        trsmPanelWindow(o.a, st, idx);
+        updWindow(o.a, dl.steps[o.a].fuse != 0, st, idx);
         break;
-      }
+      case kDlStepUpd: updWindow(o.a, dl.steps[o.a].fuse != 0, st, idx); break;
+      case kDlTrsmBlock: trsmBlockRows(o.a, o.rowBegin, o.rowEnd, st, idx); break;
       case kDlHandUpd: {
         const DlBlock& b = dl.blocks[o.a];
         const int32_t k0 = b.slot0, k1 = k0 + kOuterWidth / kPanelWidth;

@@ -168,7 +168,8 @@ enum DlOpKind : int32_t {
 struct DlOp {
   int32_t kind, stream;  // stream 0: execution stream, 1: due stream, 2: optional stream
   int32_t a;
-  int32_t rowBegin = 0, rowEnd = 0;       // kDlTrsmBlock (row indices inside the lump column)
+  int32_t rowBegin = 0, rowEnd = 0;       // kDlTrsmBlock (row indices inside the lump column); kDlStep: rows
+                                          // solved against the step's whole outer block by extra workgroups
   int64_t taskBegin = 0, taskEnd = 0;     // kDlBulk
   int32_t due = 0;                        // kDlBulk: 1 = a fork's due launch (profile class only)
 };
@@ -276,8 +277,9 @@ struct HipPlanOptions {
                                // so the factor is wrong and the full-size checks must notice
   bool denseLump = true;      // BSP_DENSE_LUMP=0: lumps of several outer blocks level by level (rounds 1-3)
   int32_t gatherMaxPairs = 128;  // BSP_GATHER_MAX_PAIRS
-  double bulkAhead = 2.0;     // BSP_BULK_AHEAD: optional bulk work per fork as a multiple of an even share
-                              // of what is left (0: every target takes its sources when it is due)
+  double bulkAhead = 1e9;     // BSP_BULK_AHEAD: cap of the optional bulk work of a fork, as a multiple of an
+                              // even share of what is left (0: every target takes its sources when due)
+  int32_t dlGroup = 2;        // BSP_DL_GROUP: optional launches every `group` forks (rank 256 x group)
   static HipPlanOptions fromEnv();
 };
 

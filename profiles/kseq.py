@@ -18,7 +18,7 @@ rows = cur.execute(
 first = [i for i, r in enumerate(rows) if sys.argv[2] in r[0]]
 # the last factor() starts at the last occurrence of the marker kernel that follows a long pause
 starts = [i for i in first if i == 0 or rows[i][1] - rows[i - 1][2] > 200000]
-rows = rows[starts[-1]:]
+rows = rows[(starts[-1] if starts else first[-1]):]
 t0, prev = rows[0][1], rows[0][1]
 tot = {}
 for name, st, en, x, y, w in rows:

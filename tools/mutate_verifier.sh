@@ -10,9 +10,9 @@ trap 'cp /tmp/hip_plan.cpp.orig "$SRC"; touch "$SRC"' EXIT
 muts=(
   's/          op(kDlWait, 1, optDone\[h\]);/          ;/'
   's/      if (evT >= 0) op(kDlWait, 2, evT);/      ;/'
-  's/(u.dl >= b + 3 ? rest : keep)/(u.dl >= b + 2 ? rest : keep)/'
-  's/      if (evDuePrev >= 0) op(kDlWait, 0, evDuePrev);/      ;/'
-  's/      if (evH1 >= 0) op(kDlWait, 1, evH1);/      ;/'
+  's/groupFork \&\& u.dl >= b + group + 3/groupFork \&\& u.dl >= b + group + 2/'
+  's/          if (ride \&\& evDuePrev >= 0) op(kDlWait, 0, evDuePrev);/          ;/'
+  's/    if (hasT || anyDue) op(kDlWait, 1, evCH);/    ;/'
   's/std::min(i - 2, c)});/std::min(i - 1, c)});/'
 )
 fail=0
