@@ -320,13 +320,6 @@ class Solver:
                 return False
         return _Scope()
 
-    def _testVerifyDenseLumps(self):
-        """TESTING (host only): replay the dense-lump schedules of the factor plan symbolically
-        (bsp_test_verify_dense_lumps); returns how many there are, raises on an inconsistency"""
-        n = ctypes.c_int64(0)
-        _check(self._lib.bsp_test_verify_dense_lumps(self._h, ctypes.byref(n)))
-        return int(n.value)
-
     def _testSetFault(self, kind):
         """TESTING, fault injection (bsp_test_set_fault): 1 = factor() skips the sparse-elimination
         update, 0 = off"""

@@ -270,16 +270,6 @@ int bsp_force_per_op(bsp_solver* s, int32_t on) {
   BSP_CATCH
 }
 
-int bsp_test_verify_dense_lumps(bsp_solver* s, int64_t* numPlans) {
-  BSP_TRY
-  std::string msg;
-  const int n = hipBackendVerifyDenseLumps(s->solver->internalSymbolicContext(), 0,
-                                           s->solver->skel().numLumps(), msg);
-  if (n < 0) throw std::runtime_error(msg);
-  if (numPlans) *numPlans = n;
-  BSP_CATCH
-}
-
 int bsp_test_set_fault(bsp_solver* s, int32_t kind) {
   BSP_TRY
   hipBackendSetFault(s->solver->internalSymbolicContext(), kind);

@@ -3,7 +3,6 @@
 #pragma once
 
 #include <cstdint>
-#include <string>
 
 #include "mat_ops.h"
 
@@ -62,11 +61,6 @@ void hipBackendForcePerOp(SymbolicCtx& sym, bool on);
 // sparse-elimination update (the factor is then wrong and the checks must say so), 0 = off.
 // Never read from the environment: a leaked variable cannot corrupt a caller's factor.
 void hipBackendSetFault(SymbolicCtx& sym, int kind);
-
-// TESTING (host only): builds the plan of lumps [startLump, upToLump) and replays every dense-lump
-// schedule symbolically (verifyDenseLump, hip_plan.h).  Returns the number of dense-lump plans, or
-// -1 with `msg` saying what is wrong.
-int hipBackendVerifyDenseLumps(SymbolicCtx& sym, int64_t startLump, int64_t upToLump, std::string& msg);
 
 HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t upToLump);
 

@@ -623,113 +623,6 @@ struct HipNumericCtx : NumericCtx<T> {
     return (sym.profile == nullptr || sym.profileInSitu) && sym.lookaheadEnabled;
   }
 
-  // One lump as a dense-lump plan (DenseLumpPlan, hip_plan.h): the operations in enqueue order,
-  // stream 0 = the execution stream, stream 1 = the side stream (the execution stream again when
-  // the lookahead schedule is off: profiled isolated runs, BSP_NO_LOOKAHEAD, too little bulk work).
-  // dinv: slot of the lump's first panel; raw: the chain's two staging slots of rawSlot values.
-  void launchDenseLump(DevPlan& plan, const DenseLumpPlan& dl, hipk::DataRef<BT> ref,
-                       LaunchTimer& timer, BT* dinv, int64_t dinvStride, BT* rawBase, int64_t rawSlot) {
-    const unsigned gy = (unsigned)batchSize;
-    const bool side = lookaheadOn() && plan.host.lookaheadPays(batchSize, sym.lookaheadMinFlops);
-    hipStream_t streams[3] = {sym.stream, side ? sym.dueSideStream() : sym.stream,
-                              side ? sym.sideStream() : sym.stream};
-    vector<hipEvent_t> events(side ? dl.numEvents : 0, nullptr);
-    unsigned* yield = (side && batchSize == 1) ? sym.yieldWord() : nullptr;
-    auto slotOf = [&](int k) { return dinv + (int64_t)k * hipk::kDinvSlot; };
-    auto rawOf = [&](int k) { return rawBase ? rawBase + (k & 1) * rawSlot : nullptr; };
-    for (const DlOp& o : dl.ops) {
-      hipStream_t st = streams[o.stream];
-      switch (o.kind) {
-        case kDlPotrf: {
-          const DlStep& s = dl.steps[o.a];
-          timer.begin(kProfPotrf, st);
-          hipk::potrfPanelDirect<BT><<<dim3(1, gy), 256, 0, st>>>(s.pd, ref, slotOf(s.slot), dinvStride);
-          timer.end();
-          break;
-        }
-        case kDlTrsmPanel: {
-          const DlStep& s = dl.steps[o.a];
-          const unsigned nT = (unsigned)((s.pd.rowsBelow + kTile - 1) / kTile);
-          if (!nT) break;
-          timer.begin(kProfTrsm, st);
-          hipk::trsmPanelDirect<BT><<<dim3(nT, gy), 256, 0, st>>>(s.pd, ref, slotOf(s.slot), dinvStride);
-          timer.end();
-          break;
-        }
-        case kDlStep: {
-          const DlStep& s = dl.steps[o.a];
-          timer.begin(kProfChainUpdate, st);
-          const int auxRows = o.rowEnd - o.rowBegin;
-          const unsigned auxTiles = (unsigned)((auxRows + kTile - 1) / kTile);
-          const DlBlock& blk = dl.blocks[s.block];
-          hipk::chainStep<BT><<<dim3((unsigned)s.nTasks + auxTiles, gy), 256, 0, st>>>(
-              s.pd, s.sd, s.nTasks, s.next, s.fuse, ref, rawOf(o.a), s.stage ? rawOf(o.a + 1) : nullptr,
-              2 * rawSlot, slotOf(s.slot), slotOf(s.slot + 1), 0, 0, yield, sym.traceLaunchId++, 0, 0,
-              dinvStride, auxTiles ? s.nTasks : INT32_MAX, blk.diagOff,
-              dl.diagOff + (int64_t)o.rowBegin * blk.lda + blk.col0, auxRows, slotOf(blk.slot0));
-          timer.end();
-          break;
-        }
-        case kDlStepUpd: {
-          const DlStep& s = dl.steps[o.a];
-          timer.begin(kProfChainUpdate, st);
-          if (s.fuse) {
-            hipk::updateTileDirectPotrf<BT><<<dim3((unsigned)s.nTasks, gy), 256, 0, st>>>(
-                s.src, s.sd, s.nTasks, s.next, ref, 0, slotOf(s.slot + 1),
-                s.stage ? rawOf(o.a + 1) : nullptr, 2 * rawSlot, dinvStride);
-          } else {
-            hipk::updateTileDirect<BT><<<dim3((unsigned)s.nTasks, gy), 256, 0, st>>>(
-                s.src, s.sd, s.nTasks, ref, s.stage ? rawOf(o.a + 1) : nullptr, s.next.nb, 2 * rawSlot);
-          }
-          timer.end();
-          break;
-        }
-        case kDlTrsmBlock: {
-          const DlBlock& b = dl.blocks[o.a];
-          const int rows = o.rowEnd - o.rowBegin;
-          timer.begin(kProfTrsm, st);
-          const dim3 grid((unsigned)((rows + kTile - 1) / kTile), gy);
-          const int64_t rowsOff = dl.diagOff + (int64_t)o.rowBegin * b.lda + b.col0;
-          if (b.width == kOuterWidth) {  // (operands through an LDS ring; a ragged last block: registers)
-            hipk::trsmBlockPipe<BT><<<grid, 256, 0, st>>>(b.diagOff, b.lda, rowsOff, rows, ref,
-                                                          slotOf(b.slot0), dinvStride);
-          } else {
-            hipk::trsmBlock<BT><<<grid, 256, 0, st>>>(b.diagOff, b.lda, b.width, rowsOff, rows, ref,
-                                                      slotOf(b.slot0), dinvStride, 1);
-          }
-          timer.end();
-          break;
-        }
-        case kDlHandUpd: {
-          const DlBlock& b = dl.blocks[o.a];
-          const int kNext = dl.blocks[o.a + 1].slot0;
-          timer.begin(kProfChainUpdate, st);
-          hipk::handoffUpdate<BT><<<dim3((unsigned)b.h2Tiles, gy), 256, 0, st>>>(
-              b.h2Src, b.h2Seg, b.h2RowTile0, ref, b.h2Stage ? rawOf(kNext) : nullptr, b.h2Next.nb,
-              2 * rawSlot);
-          timer.end();
-          break;
-        }
-        case kDlBulk:
-          timer.begin(kProfUpdate, st);
-          launchUpdate(plan, o.taskBegin, o.taskEnd, ref, st, nullptr, 0,
-                       (side && o.stream != 0) ? sym.bulkExtraLds : 0u, 1);
-          timer.end();
-          break;
-        case kDlRecord:
-          if (side) {
-            events[o.a] = sym.eventFromPool();
-            hipCHECK(hipEventRecord(events[o.a], st));
-          }
-          break;
-        case kDlWait:
-          if (side) hipCHECK(hipStreamWaitEvent(st, events[o.a], 0));
-          break;
-        default: throw std::runtime_error("HIP backend: unknown dense-lump operation");
-      }
-    }
-  }
-
   void launchLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::DataRef<BT> ref,
                     LaunchTimer& timer) {
     const dim3 gy(1, (unsigned)batchSize, 1);
@@ -756,12 +649,7 @@ struct HipNumericCtx : NumericCtx<T> {
     bool sideUsed = false, dueUsed = false;
     // inverted diagonal blocks of the chain panels: written by a panel's potrf, read by its trsm
     // (two slots per matrix, alternating from panel to panel)
-    // (dense-lump plans keep one slot per panel behind the two: their block trsm reads the four
-    //  inverses of a whole outer block)
-    int64_t dlSlots = 0;
-    for (const DenseLumpPlan& d : plan.host.denseLumps) dlSlots = std::max<int64_t>(dlSlots, d.numSlots);
-    const int64_t dinvStride = (2 + dlSlots) * hipk::kDinvSlot;
-    sym.dinvScratch.resize((size_t)batchSize * dinvStride * sizeof(BT));
+    sym.dinvScratch.resize((size_t)batchSize * hipk::kDinvBatchStride * sizeof(BT));
     BT* dinvBase = const_cast<BT*>(sym.dinvScratch.as<BT>());
     int dinvSlot = 0;  // slot of the current level's panel
     // staging buffer of the chain (chainStep): unsolved rows of the current / next panel
@@ -779,14 +667,6 @@ struct HipNumericCtx : NumericCtx<T> {
     bool extraBroken = false;
     for (size_t li = 0; li < levels.size(); li++) {
       const LevelRange& lr = levels[li];
-      if (lr.dl == -2) continue;  // (a further level of a lump that ran as a dense-lump plan)
-      if (lr.dl >= 0) {
-        launchDenseLump(plan, plan.host.denseLumps[lr.dl], ref, timer, dinvBase + 2 * hipk::kDinvSlot,
-                        dinvStride, rawBase, rawSlot);
-        potrfFused = false;
-        rawValid = false;
-        continue;
-      }
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
       const bool direct = lr.directPanel >= 0;
@@ -802,7 +682,7 @@ struct HipNumericCtx : NumericCtx<T> {
         timer.begin(kProfPotrf);
         if (direct) {
           hipk::potrfPanelDirect<BT><<<dim3(1, gy.y), 256, 0, sym.stream>>>(
-              plan.host.panels[lr.directPanel], ref, dinvCur, dinvStride);
+              plan.host.panels[lr.directPanel], ref, dinvCur);
         } else {
           hipk::potrfPanel<BT><<<dim3(nP, gy.y), 256, 0, sym.stream>>>(
               plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, ref);
@@ -852,10 +732,10 @@ struct HipNumericCtx : NumericCtx<T> {
           SrcDesc part = plan.host.srcs[sd.src];
           part.K = splitK;
           hipk::trsmPanelDirectPlus<BT><<<dim3(nT + 1, gy.y), 256, 0, sym.stream>>>(
-              plan.host.panels[lr.directPanel], part, sd, ref, dinvCur, dinvStride);
+              plan.host.panels[lr.directPanel], part, sd, ref, dinvCur);
         } else if (direct) {
           hipk::trsmPanelDirect<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
-              plan.host.panels[lr.directPanel], ref, dinvCur, dinvStride);
+              plan.host.panels[lr.directPanel], ref, dinvCur);
         } else {
           hipk::trsmPanel<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
               plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin, ref);
@@ -943,7 +823,7 @@ struct HipNumericCtx : NumericCtx<T> {
               plan.host.panels[lr.directPanel], plan.host.segs[lr.directSeg], (int)nUpd, nextPanel,
               fuse ? 1 : 0, ref, rawCur, stage ? rawNext : nullptr, 2 * rawSlot, dinvCur, dinvNext,
               memOff, kMem, (lookahead && batchSize == 1) ? sym.yieldWord() : nullptr,
-              sym.traceLaunchId++, kMem0, extra, dinvStride);
+              sym.traceLaunchId++, kMem0, extra);
           potrfFused = fuse;
         } else if (fuse) {
           if (extraApplied > 0) {
@@ -954,7 +834,7 @@ struct HipNumericCtx : NumericCtx<T> {
           const SegDesc& sd = plan.host.segs[lr.directSeg];
           hipk::updateTileDirectPotrf<BT><<<dim3(nUpd, gy.y), 256, 0, sym.stream>>>(
               plan.host.srcs[sd.src], sd, (int)nUpd, nextPanel, ref, splitK, dinvNext,
-              stage ? rawNext : nullptr, 2 * rawSlot, dinvStride);
+              stage ? rawNext : nullptr, 2 * rawSlot);
           potrfFused = true;
         } else if (direct && lr.directSeg >= 0) {
           if (extraApplied > 0) {
@@ -1778,30 +1658,6 @@ void hipBackendForcePerOp(SymbolicCtx& sym, bool on) {
   HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
   BASPACHO_CHECK_NOTNULL(h);
   h->forcePerOp = on;
-}
-
-int hipBackendVerifyDenseLumps(SymbolicCtx& sym, int64_t startLump, int64_t upToLump, std::string& msg) {
-  HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
-  BASPACHO_CHECK_NOTNULL(h);
-  HipPlanHost p = buildHipPlan(h->skel, h->sparseElimRanges, startLump, upToLump, h->planOpts);
-  for (const DenseLumpPlan& dl : p.denseLumps) {
-    if (std::getenv("BSP_DL_DUMP")) {  // (debugging aid: the operation list, one line each)
-      static const char* names[] = {"potrf", "trsmPanel", "step", "stepUpd", "trsmBlock", "handUpd", "bulk", "record", "wait"};
-      for (const DlOp& o : dl.ops) {
-        fprintf(stderr, "  s%d %-9s a=%d", o.stream, names[o.kind], o.a);
-        if (o.kind == kDlTrsmBlock) fprintf(stderr, " rows [%d, %d)", o.rowBegin, o.rowEnd);
-        if (o.kind == kDlBulk) fprintf(stderr, " tasks %lld%s", (long long)(o.taskEnd - o.taskBegin), o.due ? " due" : "");
-        fprintf(stderr, "\n");
-      }
-    }
-    const std::string e = verifyDenseLump(p, dl);
-    if (!e.empty()) {
-      msg = "dense-lump plan of lump " + std::to_string(dl.lump) + " (width " + std::to_string(dl.n) +
-            ", rows " + std::to_string(dl.rowsTotal) + "): " + e;
-      return -1;
-    }
-  }
-  return (int)p.denseLumps.size();
 }
 
 void hipBackendSetFault(SymbolicCtx& sym, int kind) {

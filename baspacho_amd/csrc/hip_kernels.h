@@ -1131,14 +1131,14 @@ __global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
 // trip plus the store.
 template <typename T>
 __global__ __launch_bounds__(256) void potrfPanelDirect(PanelDesc pd, DataRef<T> dref,
-                                                        T* dinvOut, int64_t dinvStride) {
+                                                        T* dinvOut) {
   __shared__ T blk[8 * kPanelWidth][4];
   T(*sol)[4] = blk + 3 * kPanelWidth;
   __shared__ T Ld[kPanelWidth * kInvLd];
   __builtin_amdgcn_s_setprio(3);
   BSP_STAMP(0);
   potrfPanelTiles<T>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, blk, sol, &blk[4 * kPanelWidth][0], NoPreUpdate(), Ld,
-                   (GP<T>)dinvOut + (size_t)blockIdx.y * dinvStride);
+                   (GP<T>)dinvOut + (size_t)blockIdx.y * kDinvBatchStride);
   BSP_STAMP(3);
 }
 
@@ -1413,272 +1413,13 @@ __global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const 
 
 template <typename T>
 __global__ __launch_bounds__(256) void trsmPanelDirect(PanelDesc pd, DataRef<T> dref,
-                                                       const T* dinv, int64_t dinvStride) {
+                                                       const T* dinv) {
   __builtin_amdgcn_s_setprio(3);
   GP<T> data = pickData(dref);
   const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
   GP<T> P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
-  trsmTileRegs<T>(data + pd.diagOff, (GP<const T>)dinv + (size_t)blockIdx.y * dinvStride, P,
+  trsmTileRegs<T>(data + pd.diagOff, (GP<const T>)dinv + (size_t)blockIdx.y * kDinvBatchStride, P,
                   lda, nb, min(kTile, pd.rowsBelow - rowTile));
-}
-
-// ------------------------------------------------------------------------------------------
-// K4b  block trsm of the dense-lump schedule:  X L_bb^T = B  for a tile of 64 rows and ALL columns of
-// one outer block (up to 256), against the finished diagonal block L_bb and the inverted 16 x 16
-// diagonal blocks its four panel potrfs left in their slots.  Same register formulation as
-// trsmStages -- rows transposed in accumulator layout, X_J^T = Dinv_J (B_J^T - sum_{L<J} L_JL X_L^T)
-// over the 16-column blocks J = 0 .. 15 -- but right-looking (a finished block updates every later
-// one: independent accumulators) and with the off-diagonal blocks of L straight from L2 in
-// A-operand layout, eight blocks per round of loads.  544 MFMAs per wave for a full block: the same
-// count as the product with an explicit 256 x 256 inverse, without forming one.  Rows are written
-// ONCE; the bulk update tiles read them from memory (the chain of rounds 1-3 re-solved every row
-// inside each of its tiles).  Replaces cublas?trsm (MatOpsCuda.cu:550-566) for the rows below a
-// lump's window.
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void trsmBlock(
-    int64_t blockOff, int lda, int bw, int64_t rowsOff, int nRows, DataRef<T> dref, const T* dinvBase,
-    int64_t dinvStride, int prio) {
-  using Acc = typename Mfma<T>::Acc;
-  constexpr int NBLK = kOuterWidth / 16, JCH = 6;
-  if (prio) __builtin_amdgcn_s_setprio(2);
-  GP<T> data = pickData(dref);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n16 = lane & 15, q = lane >> 4;
-  const int pm = Mfma<T>::colOfRow(n16);
-  const int rowIdx = kTile * blockIdx.x + 16 * w + n16;
-  const bool active = rowIdx < nRows;
-  GP<T> row = data + rowsOff + (int64_t)(active ? rowIdx : 0) * lda;
-  GP<const T> A = data + blockOff;
-  GP<const T> dinv = (GP<const T>)dinvBase + (size_t)blockIdx.y * dinvStride;
-  Acc x[NBLK];
-#pragma unroll
-  for (int J = 0; J < NBLK; J++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int col = 16 * J + 4 * q + r;
-      const T v = row[min(col, bw - 1)];
-      x[J][r] = (active && col < bw) ? v : T(0);
-    }
-  }
-  auto stepL = [&](auto Lc) __attribute__((always_inline)) {
-    constexpr int L = decltype(Lc)::value;
-    if (16 * L >= bw) return;  // (uniform)
-    {
-      T d[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) d[r] = dinv[(L / 4) * kDinvSlot + (16 * (L % 4) + pm) * 16 + 4 * q + r];
-      Acc y = {0, 0, 0, 0};
-#pragma unroll
-      for (int r = 0; r < 4; r++) y = Mfma<T>::run(d[r], x[L][r], y);
-      x[L] = y;
-    }
-#pragma unroll
-    for (int J0 = L + 1; J0 < NBLK; J0 += JCH) {
-      if (16 * J0 < bw) {
-        T a[JCH][4];
-#pragma unroll
-        for (int u = 0; u < JCH; u++) {
-          const int J = J0 + u;
-          if (J < NBLK) {
-            const int rr = min(16 * J + pm, bw - 1);
-#pragma unroll
-            for (int r = 0; r < 4; r++) a[u][r] = A[(int64_t)rr * lda + min(16 * L + 4 * q + r, bw - 1)];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < JCH; u++) {
-          const int J = J0 + u;
-          if (J < NBLK) {
-            const bool live = 16 * J + pm < bw;
-#pragma unroll
-            for (int r = 0; r < 4; r++) x[J] = Mfma<T>::run(live ? -a[u][r] : T(0), x[L][r], x[J]);
-          }
-        }
-        asm volatile("" ::: "memory");  // (the next round's loads stay behind this round's products)
-      }
-    }
-  };
-  staticFor<0, NBLK>(stepL);
-#pragma unroll
-  for (int J = 0; J < NBLK; J++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int col = 16 * J + 4 * q + r;
-      if (active && col < bw) row[col] = x[J][r];
-    }
-  }
-}
-
-// K4c  the same solve for FULL outer blocks (bw = 256), operands through an LDS ring.  K4b asks L2 for
-// eight 16 x 16 blocks of L, waits, multiplies, asks again: 16 x 3 exposed round trips of 1-2 us each
-// per wave (measured on BAL-871: 58 launches, 3.2 ms serialised -- the side stream spent more time in
-// its block solves than in half of its update tiles).  Here the 136 blocks a wave needs -- per
-// 16-column step L the inverted diagonal block D_L, then L_{L+1,L} ... L_{15,L} -- are ONE stream,
-// fetched by the workgroup's four waves together (wave w fetches block 4 c + w of chunk c) straight
-// into LDS (global_load_lds, 16 bytes per lane, rows XOR-swizzled by 16-byte slot so that the
-// A-operand reads are conflict-poor), three chunks ahead of the chunk being multiplied: one barrier
-// and one counter wait per four blocks, no operand registers.  The B operand of every product is
-// -X_L (negated once per step), so the blocks of L are used as they lie in memory.
-template <typename T>
-struct TrsmPipe {
-  static constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte slot
-  static constexpr int SLOTS = 16 / E;            // slots per 16-column row of a block
-  static constexpr int RPI = 64 / SLOTS;          // rows one wave instruction fetches
-  static constexpr int NI = 16 / RPI;             // instructions per block
-  static constexpr int NBLK = kOuterWidth / 16;   // 16-column steps
-  static constexpr int NSEQ = NBLK * (NBLK + 1) / 2;  // blocks of the stream
-  static constexpr int CHUNK = 4, NCHUNK = NSEQ / CHUNK, RING = 4;
-  static_assert(NSEQ % CHUNK == 0, "whole chunks");
-  static constexpr int kLdsElems = RING * CHUNK * 256;
-  // t-th block of the stream -> (L, J); J == L: the inverted diagonal block of step L
-  static constexpr int stepOf(int t) {
-    int L = 0;
-    while (t >= NBLK - L) {
-      t -= NBLK - L;
-      L++;
-    }
-    return L;
-  }
-  static constexpr int rowBlockOf(int t) {
-    int L = 0;
-    while (t >= NBLK - L) {
-      t -= NBLK - L;
-      L++;
-    }
-    return L + t;
-  }
-};
-
-template <typename T>
-__device__ __forceinline__ void trsmBlockPipeBody(GP<T> data, int64_t blockOff, int lda, int64_t rowsOff,
-                                                  int nRows, GP<const T> dinv, int rowTileIdx, T* ring) {
-  using P = TrsmPipe<T>;
-  using Acc = typename Mfma<T>::Acc;
-  typedef __attribute__((address_space(1))) const void* GV;
-  typedef __attribute__((address_space(3))) void* LV;
-  constexpr int E = P::E, SLOTS = P::SLOTS, RPI = P::RPI, NI = P::NI, NBLK = P::NBLK;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n16 = lane & 15, q = lane >> 4;
-  const int pm = Mfma<T>::colOfRow(n16);
-  const int rowIdx = kTile * rowTileIdx + 16 * w + n16;
-  const bool active = rowIdx < nRows;
-  GP<T> row = data + rowsOff + (int64_t)(active ? rowIdx : 0) * lda;
-  GP<const T> A = data + blockOff;
-  Acc x[NBLK];
-#pragma unroll
-  for (int J = 0; J < NBLK; J++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const T v = row[16 * J + 4 * q + r];
-      x[J][r] = active ? v : T(0);
-    }
-  }
-  // this lane's share of a block fetch: rows (lane / SLOTS) + RPI it, 16-byte slot (lane % SLOTS)
-  // of LDS = column slot (lane % SLOTS) ^ key(row) of memory
-  const int fr = lane / SLOTS, fs = lane % SLOTS;
-  auto fetch = [&](auto Cc) __attribute__((always_inline)) {
-    constexpr int c = decltype(Cc)::value;
-    if constexpr (c < P::NCHUNK) {
-      // (wave w fetches block w of the chunk: which block that is depends on w, so the four cases
-      //  are spelled out with compile-time block indices)
-      auto one = [&](auto Tc) __attribute__((always_inline)) {
-        constexpr int t = decltype(Tc)::value;
-        constexpr int L = P::stepOf(t), J = P::rowBlockOf(t);
-        T* dst = ring + ((c % P::RING) * P::CHUNK + (t % P::CHUNK)) * 256;
-#pragma unroll
-        for (int it = 0; it < NI; it++) {
-          const int r = fr + RPI * it;
-          const int slot = fs ^ (r & (SLOTS - 1));
-          GP<const T> src = (J == L) ? dinv + (L / 4) * kDinvSlot + (16 * (L % 4) + r) * 16 + E * slot
-                                     : A + (int64_t)(16 * J + r) * lda + 16 * L + E * slot;
-          __builtin_amdgcn_global_load_lds((GV)src, (LV)(dst + RPI * it * 16), 16, 0, 0);
-        }
-      };
-      if (w == 0) one(std::integral_constant<int, P::CHUNK * c + 0>{});
-      if (w == 1) one(std::integral_constant<int, P::CHUNK * c + 1>{});
-      if (w == 2) one(std::integral_constant<int, P::CHUNK * c + 2>{});
-      if (w == 3) one(std::integral_constant<int, P::CHUNK * c + 3>{});
-    }
-  };
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the row loads: the fetch counter starts clean)
-  fetch(std::integral_constant<int, 0>{});
-  fetch(std::integral_constant<int, 1>{});
-  fetch(std::integral_constant<int, 2>{});
-  Acc xn = {0, 0, 0, 0};  // -X_L of the current step
-  // element (pm, 4 q + r) of the block in ring position `pos`
-  auto operand = [&](int pos, T (&a)[4]) __attribute__((always_inline)) {
-    const T* blk = ring + pos * 256 + pm * 16;
-    const int key = pm & (SLOTS - 1);
-    if constexpr (E == 2) {
-      typedef T T2 __attribute__((ext_vector_type(2)));
-      const T2 lo = *(const T2*)(blk + E * ((2 * q) ^ key)), hi = *(const T2*)(blk + E * ((2 * q + 1) ^ key));
-      a[0] = lo.x;
-      a[1] = lo.y;
-      a[2] = hi.x;
-      a[3] = hi.y;
-    } else {
-      typedef T T4 __attribute__((ext_vector_type(4)));
-      const T4 v = *(const T4*)(blk + E * (q ^ key));
-      a[0] = v.x;
-      a[1] = v.y;
-      a[2] = v.z;
-      a[3] = v.w;
-    }
-  };
-  auto chunk = [&](auto Cc) __attribute__((always_inline)) {
-    constexpr int c = decltype(Cc)::value;
-    // chunks c + 1, c + 2 may still be in flight: NI instructions per wave and chunk
-    constexpr int ahead = (P::NCHUNK - 1 - c) < 2 ? (P::NCHUNK - 1 - c) : 2;
-    if constexpr (ahead * NI == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if constexpr (ahead * NI == 1) {
-      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    } else if constexpr (ahead * NI == 2) {
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();  // every wave's share of chunk c has landed; chunk c - 1 is consumed
-    fetch(std::integral_constant<int, c + 3>{});
-    auto block = [&](auto Tc) __attribute__((always_inline)) {
-      constexpr int t = decltype(Tc)::value;
-      constexpr int L = P::stepOf(t), J = P::rowBlockOf(t);
-      T a[4];
-      operand((c % P::RING) * P::CHUNK + (t % P::CHUNK), a);
-      if constexpr (J == L) {
-        Acc y = {0, 0, 0, 0};
-#pragma unroll
-        for (int r = 0; r < 4; r++) y = Mfma<T>::run(a[r], x[L][r], y);
-        x[L] = y;
-#pragma unroll
-        for (int r = 0; r < 4; r++) xn[r] = -y[r];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; r++) x[J] = Mfma<T>::run(a[r], xn[r], x[J]);
-      }
-    };
-    block(std::integral_constant<int, P::CHUNK * c + 0>{});
-    block(std::integral_constant<int, P::CHUNK * c + 1>{});
-    block(std::integral_constant<int, P::CHUNK * c + 2>{});
-    block(std::integral_constant<int, P::CHUNK * c + 3>{});
-  };
-  staticFor<0, P::NCHUNK>(chunk);
-#pragma unroll
-  for (int J = 0; J < NBLK; J++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      if (active) row[16 * J + 4 * q + r] = x[J][r];
-    }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void trsmBlockPipe(
-    int64_t blockOff, int lda, int64_t rowsOff, int nRows, DataRef<T> dref, const T* dinvBase,
-    int64_t dinvStride) {
-  __shared__ __attribute__((aligned(16))) T ring[TrsmPipe<T>::kLdsElems];
-  __builtin_amdgcn_s_setprio(2);
-  trsmBlockPipeBody<T>(pickData(dref), blockOff, lda, rowsOff, nRows,
-                       (GP<const T>)dinvBase + (size_t)blockIdx.y * dinvStride, blockIdx.x, ring);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2114,12 +1855,22 @@ __device__ __forceinline__ int xcdContiguous(int b, int n) {
   return x * base + min(x, extra) + (b >> 3);
 }
 
-// one 64 x 64 tile (rowTile, colTile: below-row indices) of the segment
+// tile `idx` of the segment in the order: column tiles from sd.q0 on, each with its row tiles
 template <typename T>
-__device__ __forceinline__ void updateTileDirectAt(const SrcDesc& pd, const SegDesc& sd, int rowTile,
-                                                   int colTile, GP<T> data, T* As, T* Bs,
-                                                   GP<T> rawOut = nullptr, int nbNext = 0) {
+__device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const SegDesc& sd, int idx,
+                                                     GP<T> data, T* As, T* Bs,
+                                                     GP<T> rawOut = nullptr, int nbNext = 0) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
+  int colTile = sd.q0, rowTile;
+  for (;;) {
+    const int cnt = (pd.rowsBelow - colTile + kTile - 1) / kTile;
+    if (idx < cnt) {
+      rowTile = colTile + kTile * idx;
+      break;
+    }
+    idx -= cnt;
+    colTile += kTile;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = pd.K, lda = pd.lda;
   GP<const T> P = data + pd.off;
@@ -2215,46 +1966,6 @@ __device__ __forceinline__ void updateTileDirectAt(const SrcDesc& pd, const SegD
   }
 }
 
-// tile `idx` of the segment in the order: column tiles from sd.q0 on, each with its row tiles
-template <typename T>
-__device__ __forceinline__ void updateTileDirectBody(const SrcDesc& pd, const SegDesc& sd, int idx,
-                                                     GP<T> data, T* As, T* Bs,
-                                                     GP<T> rawOut = nullptr, int nbNext = 0) {
-  int colTile = sd.q0, rowTile;
-  for (;;) {
-    const int cnt = (pd.rowsBelow - colTile + kTile - 1) / kTile;
-    if (idx < cnt) {
-      rowTile = colTile + kTile * idx;
-      break;
-    }
-    idx -= cnt;
-    colTile += kTile;
-  }
-  updateTileDirectAt<T>(pd, sd, rowTile, colTile, data, As, Bs, rawOut, nbNext);
-}
-
-// K5h  hand-over update of the dense-lump schedule (DlBlock::h2Src / h2Seg): the tiles of the rows
-// from rowTile0 on, every column tile up to the diagonal, row tile by row tile; column tile 0 also
-// goes to the chain's staging buffer (the next block's first step reads its unsolved rows there)
-template <typename T>
-__global__ __launch_bounds__(256) void handoffUpdate(SrcDesc pd, SegDesc sd, int rowTile0,
-                                                     DataRef<T> dref, T* rawOut, int nbNext,
-                                                     int64_t rawStride) {
-  constexpr int LD = kUpdChunk + 2;
-  __shared__ T As[kTile * LD];
-  __shared__ T Bs[kTile * LD];
-  __builtin_amdgcn_s_setprio(BSP_TILE_PRIO);
-  int idx = blockIdx.x, rowTile = rowTile0;
-  for (;;) {
-    const int cnt = rowTile / kTile + 1;
-    if (idx < cnt) break;
-    idx -= cnt;
-    rowTile += kTile;
-  }
-  updateTileDirectAt<T>(pd, sd, rowTile, kTile * idx, pickData(dref), As, Bs,
-                        rawOut ? (GP<T>)rawOut + blockIdx.y * rawStride : nullptr, nbNext);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, int nTasks,
                                                         DataRef<T> dref, T* rawOut, int nbNext,
@@ -2278,8 +1989,7 @@ __global__ __launch_bounds__(256) void updateTileDirect(SrcDesc pd, SegDesc sd, 
 // starts at source column part.K (kStart) instead of summing all 256 columns on its own.
 template <typename T>
 __global__ __launch_bounds__(256) void trsmPanelDirectPlus(PanelDesc pd, SrcDesc part, SegDesc sd,
-                                                           DataRef<T> dref, const T* dinv,
-                                                           int64_t dinvStride) {
+                                                           DataRef<T> dref, const T* dinv) {
   constexpr int LD = kUpdChunk + 2;
   __shared__ T lds[2 * kTile * LD];
   __builtin_amdgcn_s_setprio(3);
@@ -2290,7 +2000,7 @@ __global__ __launch_bounds__(256) void trsmPanelDirectPlus(PanelDesc pd, SrcDesc
   }
   const int nb = pd.nb, lda = pd.lda, rowTile = blockIdx.x * kTile;
   GP<T> P = data + pd.diagOff + (int64_t)(nb + rowTile) * lda;
-  trsmTileRegs<T>(data + pd.diagOff, (GP<const T>)dinv + (size_t)blockIdx.y * dinvStride, P,
+  trsmTileRegs<T>(data + pd.diagOff, (GP<const T>)dinv + (size_t)blockIdx.y * kDinvBatchStride, P,
                   lda, nb, min(kTile, pd.rowsBelow - rowTile));
 }
 
@@ -2298,7 +2008,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc sd, int nTasks,
                                                              PanelDesc next, DataRef<T> dref,
                                                              int kStart, T* dinvOut, T* rawOut,
-                                                             int64_t rawStride, int64_t dinvStride) {
+                                                             int64_t rawStride) {
   constexpr int KC = kUpdChunk, LD = KC + 2;
   __shared__ __attribute__((aligned(16))) T As[kTile * LD];
   __shared__ __attribute__((aligned(16))) T Bs[kTile * LD];
@@ -2361,7 +2071,7 @@ __global__ __launch_bounds__(256) void updateTileDirectPotrf(SrcDesc pd, SegDesc
   BSP_STAMP(0);
   // (As is free once `pre` has run: the blocked form's second buffer)
   potrfPanelTiles<T>(data + next.diagOff, nb, next.lda, blk, sol, As, pre, Ld,
-                     (GP<T>)dinvOut + (size_t)blockIdx.y * dinvStride);
+                     (GP<T>)dinvOut + (size_t)blockIdx.y * kDinvBatchStride);
   BSP_STAMP(3);
 }
 
@@ -2494,32 +2204,20 @@ template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void chainStep(
     PanelDesc pd, SegDesc sd, int nTasks, PanelDesc next, int fuse, DataRef<T> dref,
     const T* rawInBase, T* rawOutBase, int64_t rawStride, const T* dinvInBase, T* dinvOutBase,
-    int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag,
-    int64_t dinvStride, int auxFirst = 0x7fffffff, int64_t auxBlockOff = 0, int64_t auxRowsOff = 0,
-    int auxRows = 0, const T* auxDinv = nullptr) {
-  // auxFirst .. : workgroups from this index on do not belong to the step: they solve row tiles of
-  // auxRows rows at auxRowsOff against the whole outer block at auxBlockOff (trsmBlockPipeBody, the
-  // hand-over of the dense-lump schedule riding in the block's last step)
+    int64_t memOff, int kMem, unsigned* yieldFlag, int traceId, int kMem0, int extraDiag) {
   // kMem0 <= kMem: source columns workgroup 0 still has to apply from memory to tile (0,0), the
   // LAST kMem0 of the kMem ones -- the earlier panels of the block applied theirs already, each in
   // its own step (extraDiag: one more workgroup, the diagonal tile just past the segment's columns
   // = the next outer block's tile (0,0), rank-nb, with atomics: lookahead units of the side stream
   // may be working on that tile too).  The block-last step's potrf workgroup then starts from a
   // plain rank-nb update like every other step instead of a rank-256 one (10-25 us per block).
-  __shared__ __attribute__((aligned(16))) T XB[kTile * kXbLd];
-  static_assert(kTile * kXbLd >= 4 * 4 * 256, "the block solve's operand ring fits in XB");
-  if ((int)blockIdx.x >= auxFirst) {
-    __builtin_amdgcn_s_setprio(2);
-    trsmBlockPipeBody<T>(pickData(dref), auxBlockOff, pd.lda, auxRowsOff, auxRows,
-                         (GP<const T>)auxDinv + (size_t)blockIdx.y * dinvStride, (int)blockIdx.x - auxFirst, XB);
-    return;
-  }
+  __shared__ T XB[kTile * kXbLd];
   BSP_EXTENT_BEGIN(traceId);
   static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd <= kTile * kXbLd, "potrf LDS fits in XB");
   using Acc = typename Mfma<T>::Acc;
   GP<T> data = pickData(dref);
   GP<const T> rawIn = (GP<const T>)rawInBase + blockIdx.y * rawStride;
-  GP<const T> dinv = (GP<const T>)dinvInBase + (size_t)blockIdx.y * dinvStride;
+  GP<const T> dinv = (GP<const T>)dinvInBase + (size_t)blockIdx.y * kDinvBatchStride;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15;
   const int nb = pd.nb, lda = pd.lda, rowsBelow = pd.rowsBelow, segEnd = sd.q0 + sd.m;
   GP<const T> Lkk = data + pd.diagOff;
@@ -2554,7 +2252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd + 4 * kPanelWidth * 4 <= kTile * kXbLd, "second potrf buffer fits in XB");
     potrfPanelTiles<T>(data + next.diagOff, next.nb, next.lda, blk, sol,
                        XB + 4 * kPanelWidth * 4 + kPanelWidth * kInvLd, pre, Ld,
-                       (GP<T>)dinvOutBase + (size_t)blockIdx.y * dinvStride);
+                       (GP<T>)dinvOutBase + (size_t)blockIdx.y * kDinvBatchStride);
     yieldPublish(yieldFlag, 0u);
     BSP_STAMP(3);
     BSP_EXTENT_END(traceId, true);

@@ -7,7 +7,6 @@
 #include <atomic>
 #include <map>
 #include <thread>
-#include <tuple>
 
 namespace BaSpaCho {
 
@@ -271,479 +270,14 @@ struct PanelBuild {
   int32_t level;
 };
 
-// ---- dense-lump plan (DenseLumpPlan, hip_plan.h) ---------------------------------------------
-// Rows of the lump column: [0, n) the diagonal region, [n, n + r) the rows below (boards).  Column
-// blocks b = 0 .. NB-1 of kOuterWidth columns.  Who applies source block s to a 64-row tile starting
-// at row rho (block i = rho / 256 while rho < n) of column block c > s:
-//   rho < 256 (s + 2)            the chain of block s (window);
-//   256 (s + 2) <= rho < 256 (s + 3), rho < n   the hand-over of block s (H2);
-//   everything else              a bulk tile, released by T(s) / H1(s), with deadline
-//                                dl = min(i - 2, c) for rho < n (the fork whose hand-over or T(c)
-//                                touches the tile first), dl = c for the rows below the lump.
-// At fork f (after the chain of block f) every released bulk tile with dl <= f + 1 is launched as the
-// DUE list; further ones follow in deadline order as long as the fork's time budget lasts.
-constexpr double kDlBulkTilesPerUs = 15.7;   // rank-256 fp64 tiles per microsecond beside the chain
-constexpr double kDlChainBlockUs = 110.0;    // one outer block of the chain, hand-over included
-constexpr double kDlTrsmTileCost = 2.2;      // a trsmBlock row tile in units of one update tile
-
-struct DlUnit {
-  int32_t s, rho, c, dl;  // source block, first row of the 64-row tile, column block, deadline
-};
-
-DenseLumpPlan buildDenseLump(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, int64_t l,
-                             const LumpCols& g, int32_t lumpRowBase,
-                             const vector<SegDesc>& boardSegTemplates, double bulkAhead, int32_t group) {
-  group = std::max(1, group);
-  DenseLumpPlan dl;
-  const int64_t n = g.width, R = g.width + g.rowsBelow;
-  const int32_t NB = (int32_t)((n + kOuterWidth - 1) / kOuterWidth);
-  dl.lump = (int32_t)l;
-  dl.diagOff = g.diagOff;
-  dl.n = (int32_t)n;
-  dl.rowsTotal = (int32_t)R;
-  auto blockWidth = [&](int64_t b) { return (int32_t)std::min<int64_t>(kOuterWidth, n - b * kOuterWidth); };
-
-  // ---- chain steps
-  for (int32_t b = 0; b < NB; b++) {
-    const int64_t col0 = (int64_t)b * kOuterWidth, bw = blockWidth(b);
-    const int64_t windowEnd = std::min<int64_t>(n, col0 + 2 * kOuterWidth);
-    DlBlock blk{};
-    blk.diagOff = g.diagOff + col0 * n + col0;
-    blk.lda = (int32_t)n;
-    blk.width = (int32_t)bw;
-    blk.slot0 = (int32_t)dl.steps.size();
-    blk.col0 = (int32_t)col0;
-    for (int64_t c0 = col0; c0 < col0 + bw; c0 += kPanelWidth) {
-      const int32_t nb = (int32_t)std::min<int64_t>(kPanelWidth, col0 + bw - c0);
-      DlStep st{};
-      st.pd.diagOff = g.diagOff + c0 * n + c0;
-      st.pd.lda = (int32_t)n;
-      st.pd.nb = nb;
-      st.pd.rowsBelow = (int32_t)(windowEnd - c0 - nb);
-      st.pd.nRest = st.pd.rowsBelow;
-      st.pd.lumpRowBase = lumpRowBase;
-      st.pd.lump = (int32_t)l;
-      st.pd.vecOff = (int32_t)(sk.lumpStart[l] + c0);
-      st.src.off = st.pd.diagOff + (int64_t)nb * n;
-      st.src.lda = (int32_t)n;
-      st.src.K = nb;
-      st.src.rowsBelow = st.pd.rowsBelow;
-      st.src.nRest = st.pd.rowsBelow;
-      st.src.lumpRowBase = lumpRowBase;
-      st.sd.src = -1;
-      st.sd.kind = kSegIntra;
-      st.sd.q0 = 0;
-      st.sd.m = st.pd.rowsBelow;
-      st.sd.tgtBase = g.diagOff + (c0 + nb) * n + (c0 + nb);
-      st.sd.tgtStride = (int32_t)n;
-      st.sd.lump = (int32_t)l;
-      st.nTasks = 0;
-      for (int32_t cT = 0; cT < st.sd.m; cT += kTile) st.nTasks += (st.pd.rowsBelow - cT + kTile - 1) / kTile;
-      st.block = b;
-      st.slot = (int32_t)dl.steps.size();
-      dl.maxWindowRows = std::max(dl.maxWindowRows, st.pd.rowsBelow);
-      // algorithmic work of the window tiles (plan statistics)
-      {
-        const double m = st.sd.m, rows = st.pd.rowsBelow;
-        const double elems = m * rows - m * (m - 1) / 2;
-        plan.updElems += elems;
-        plan.updFlops += 2.0 * nb * elems;
-        plan.updFlopsDirect += 2.0 * nb * elems;
-      }
-      dl.steps.push_back(st);
-    }
-    dl.blocks.push_back(blk);
-  }
-  dl.numSlots = (int32_t)dl.steps.size();
-  for (size_t k = 0; k < dl.steps.size(); k++) {
-    DlStep& st = dl.steps[k];
-    if (k + 1 < dl.steps.size() && st.nTasks > 0) {
-      st.next = dl.steps[k + 1].pd;
-      st.stage = 1;
-      // (a narrower next panel does not fill tile 0: the rows below it inside that tile would not be
-      //  staged by the potrf workgroup; one tile: nothing to run beside the potrf)
-      st.fuse = st.next.nb == kTile && st.nTasks >= 2;
-    }
-  }
-
-  // ---- hand-over descriptors
-  for (int32_t b = 0; b + 2 < NB; b++) {
-    DlBlock& blk = dl.blocks[b];
-    const int64_t rho0 = (int64_t)(b + 1) * kOuterWidth;  // first row of the next block
-    const int64_t end = std::min<int64_t>(n, rho0 + 2 * kOuterWidth);
-    blk.h2Src.off = g.diagOff + rho0 * n + blk.col0;
-    blk.h2Src.lda = (int32_t)n;
-    blk.h2Src.K = blk.width;
-    blk.h2Src.rowsBelow = (int32_t)(end - rho0);
-    blk.h2Src.nRest = blk.h2Src.rowsBelow;
-    blk.h2Src.lumpRowBase = lumpRowBase;
-    blk.h2Seg.src = -1;
-    blk.h2Seg.kind = kSegIntra;
-    blk.h2Seg.q0 = 0;
-    blk.h2Seg.m = blk.h2Src.rowsBelow;
-    blk.h2Seg.tgtBase = g.diagOff + rho0 * n + rho0;
-    blk.h2Seg.tgtStride = (int32_t)n;
-    blk.h2Seg.rowMin = kOuterWidth;
-    blk.h2Seg.lump = (int32_t)l;
-    blk.h2RowTile0 = kOuterWidth;
-    blk.h2Tiles = 0;
-    for (int32_t q = kOuterWidth; q < blk.h2Src.rowsBelow; q += kTile) blk.h2Tiles += q / kTile + 1;
-    blk.h2Next = dl.steps[dl.blocks[b + 1].slot0].pd;
-    const double m = blk.h2Seg.m, rows = blk.h2Src.rowsBelow, top = kOuterWidth;
-    const double elems = (m * rows - m * (m - 1) / 2) - (top * top - top * (top - 1) / 2);
-    plan.updElems += elems;
-    plan.updFlops += 2.0 * blk.width * elems;
-    plan.updFlopsDirect += 2.0 * blk.width * elems;
-  }
-
-  // ---- bulk units (s, row tile, c)
-  vector<vector<DlUnit>> released(NB);  // by source block
-  for (int32_t s = 0; s + 1 < NB; s++) {
-    for (int64_t rho = (int64_t)(s + 3) * kOuterWidth; rho < n; rho += kTile) {
-      const int32_t i = (int32_t)(rho / kOuterWidth);
-      for (int32_t c = s + 1; c <= i; c++) released[s].push_back({s, (int32_t)rho, c, std::min(i - 2, c)});
-    }
-    for (int64_t rho = n; rho < R; rho += kTile) {
-      for (int32_t c = s + 1; c < NB; c++) released[s].push_back({s, (int32_t)rho, c, c});
-    }
-  }
-  // segments of the bulk tasks: per (source blocks s0..s1, column block), diagonal region and rows
-  // below.  The sources a target has waiting are always CONSECUTIVE blocks, i.e. consecutive columns:
-  // one task of rank 256 (s1 - s0 + 1) takes them all -- one read-modify-write of the target instead of
-  // one per source block, and no two writers of a target inside a launch (no atomics).
-  std::map<std::tuple<int32_t, int32_t, int32_t>, int32_t> segDiag, segBelow;
-  auto segOf = [&](int32_t s0, int32_t s1, int32_t c, bool below) {
-    auto& m = below ? segBelow : segDiag;
-    const auto key = std::make_tuple(s0, s1, c);
-    auto it = m.find(key);
-    if (it != m.end()) return it->second;
-    const int64_t blockEnd = (int64_t)(s1 + 1) * kOuterWidth;
-    SrcDesc fs{};
-    fs.off = g.diagOff + blockEnd * n + (int64_t)s0 * kOuterWidth;
-    fs.lda = (int32_t)n;
-    fs.K = (int32_t)((s1 - s0 + 1) * kOuterWidth);
-    fs.nRest = (int32_t)(n - blockEnd);
-    fs.rowsBelow = (int32_t)(below ? R - blockEnd : n - blockEnd);
-    fs.lumpRowBase = lumpRowBase;
-    plan.srcs.push_back(fs);
-    SegDesc u{};
-    u.src = (int32_t)plan.srcs.size() - 1;
-    u.kind = kSegIntra;
-    u.outer = 2;
-    u.lump = (int32_t)l;
-    u.q0 = (int32_t)((int64_t)c * kOuterWidth - blockEnd);
-    u.m = blockWidth(c);
-    u.tgtBase = g.diagOff + blockEnd * n + blockEnd;
-    u.tgtStride = (int32_t)n;
-    plan.segs.push_back(u);
-    return m[key] = (int32_t)plan.segs.size() - 1;
-  };
-  // tasks of a list of units: the sources of one target merged, longest tasks first (a launch ends
-  // with its longest tile), then by source, row tile and column tile (row-tile-major: the column tiles
-  // of a row share the row operand)
-  auto emitUnits = [&](vector<DlUnit>& units) -> std::pair<int64_t, int64_t> {
-    const int64_t begin = (int64_t)plan.updTasks.size();
-    std::sort(units.begin(), units.end(), [](const DlUnit& x, const DlUnit& y) {
-      return x.rho != y.rho ? x.rho < y.rho : (x.c != y.c ? x.c < y.c : x.s < y.s);
-    });
-    struct Merged { int32_t s0, s1, rho, c; };
-    vector<Merged> merged;
-    for (const DlUnit& u : units) {
-      if (!merged.empty() && merged.back().rho == u.rho && merged.back().c == u.c && merged.back().s1 + 1 == u.s) {
-        merged.back().s1 = u.s;
-      } else {
-        merged.push_back({u.s, u.s, u.rho, u.c});
-      }
-    }
-    std::stable_sort(merged.begin(), merged.end(), [](const Merged& x, const Merged& y) {
-      const int32_t kx = x.s1 - x.s0, ky = y.s1 - y.s0;
-      return kx != ky ? kx > ky : (x.s0 != y.s0 ? x.s0 < y.s0 : (x.rho != y.rho ? x.rho < y.rho : x.c < y.c));
-    });
-    std::map<std::pair<int32_t, int32_t>, int32_t> writers;
-    for (const Merged& u : merged) writers[{u.rho, u.c}]++;
-    for (const Merged& u : merged) {
-      const bool below = u.rho >= n;
-      const int32_t seg = segOf(u.s0, u.s1, u.c, below);
-      const int64_t blockEnd = (int64_t)(u.s1 + 1) * kOuterWidth;
-      const int32_t rT = (int32_t)(u.rho - blockEnd);
-      const int32_t c0 = plan.segs[seg].q0, cEnd = c0 + plan.segs[seg].m;
-      const int32_t atomic = writers[{u.rho, u.c}] > 1 ? 1 : 0;
-      for (int32_t cT = c0; cT < cEnd && cT <= rT; cT += kTile) {
-        plan.updTasks.push_back(UpdTask{seg, rT, cT, atomic});
-        const double rows = std::min<double>(kTile, (below ? R : n) - u.rho);
-        const double cols = std::min<int32_t>(kTile, cEnd - cT);
-        const double elems = cT == rT ? cols * (cols + 1) / 2 + std::max(0.0, rows - cols) * cols : rows * cols;
-        const double K = plan.srcs[plan.segs[seg].src].K;
-        plan.updElems += elems;
-        plan.updFlops += 2.0 * K * elems;
-        plan.deferredFlops += 2.0 * K * elems;
-      }
-    }
-    return {begin, (int64_t)plan.updTasks.size()};
-  };
-  // XCD-contiguous permutation of a task range (as emitLevels' xcdOrder)
-  auto xcdOrder = [&](int64_t begin, int64_t end) {
-    const int64_t cnt = end - begin;
-    if (cnt < 64) return;
-    vector<UpdTask> tmp(plan.updTasks.begin() + begin, plan.updTasks.begin() + end);
-    const int64_t base = cnt / 8, extra = cnt % 8;
-    int64_t chunkStart[9];
-    chunkStart[0] = 0;
-    for (int x = 0; x < 8; x++) chunkStart[x + 1] = chunkStart[x] + base + (x < extra ? 1 : 0);
-    for (int64_t q = 0; q < cnt; q++) plan.updTasks[begin + q] = tmp[chunkStart[q % 8] + q / 8];
-  };
-
-  // ---- operations in enqueue order
-  int32_t numEvents = 0;
-  auto op = [&](int32_t kind, int32_t stream, int32_t a) -> DlOp& {
-    DlOp o{};
-    o.kind = kind;
-    o.stream = stream;
-    o.a = a;
-    dl.ops.push_back(o);
-    return dl.ops.back();
-  };
-  // the panels of a block left of a column act on the rows of a trsmBlock launch inside the kernel:
-  // update work in the plan's accounting (2 w_l w_p per row and panel pair l < p)
-  auto countBlockTrsm = [&](int32_t b, int64_t rows) {
-    const DlBlock& blk = dl.blocks[b];
-    double pairs = 0, left = 0;
-    for (int32_t c0 = 0; c0 < blk.width; c0 += kPanelWidth) {
-      const double w = std::min<int32_t>(kPanelWidth, blk.width - c0);
-      pairs += left * w;
-      left += w;
-    }
-    plan.updFlops += 2.0 * double(rows) * pairs;
-    plan.updElems += double(rows) * std::max(0, blk.width - kPanelWidth);
-  };
-  bool potrfFused = false, rawValid = false;
-  int32_t evDuePrev = -1;
-  vector<DlUnit> pool;
-  // cost of a unit in rank-256 tiles; the side streams' work is spread evenly over the forks left
-  auto unitCost = [&](const DlUnit& u) {
-    return u.rho >= n ? 4.0 : std::min<double>(4.0, double(u.rho / kTile - u.c * 4 + 1));
-  };
-  double costTotal = 0, costLaunched = 0, costReleased = 0;
-  for (int32_t s = 0; s < NB; s++) {
-    for (const DlUnit& u : released[s]) costTotal += unitCost(u);
-    const int64_t tB = std::min<int64_t>(n, (int64_t)(s + 3) * kOuterWidth);
-    if (tB < R) costTotal += kDlTrsmTileCost * double((R - tB + kTile - 1) / kTile);
-  }
-  vector<int32_t> optDone(NB, -1);  // event after the optional / board launches of a fork
-  for (int32_t b = 0; b < NB; b++) {
-    const DlBlock& blk = dl.blocks[b];
-    const int32_t kEnd = b + 1 < NB ? dl.blocks[b + 1].slot0 : (int32_t)dl.steps.size();
-    bool h1Ridden = false;
-    for (int32_t k = blk.slot0; k < kEnd; k++) {
-      const DlStep& st = dl.steps[k];
-      if (!potrfFused) op(kDlPotrf, 0, k);
-      if (st.nTasks > 0) {
-        if (rawValid) {
-          // the block's last step also carries the hand-over's block solve (H1: the rows of row block
-          // b + 2 against the whole block -- its last panel was factored by the previous launch) as
-          // extra workgroups: one launch less on the execution stream per outer block
-          const int64_t hb = (int64_t)(b + 2) * kOuterWidth, he = std::min<int64_t>(n, hb + kOuterWidth);
-          const bool ride = k == kEnd - 1 && hb < n && blk.width == kOuterWidth;
-          if (ride && evDuePrev >= 0) op(kDlWait, 0, evDuePrev);
-          DlOp& o = op(kDlStep, 0, k);
-          if (ride) {
-            o.rowBegin = (int32_t)hb;
-            o.rowEnd = (int32_t)he;
-            h1Ridden = true;
-          }
-          plan.trsmFlopsMerged += double(st.pd.rowsBelow) * st.pd.nb * st.pd.nb;
-        } else {
-          op(kDlTrsmPanel, 0, k);
-          op(kDlStepUpd, 0, k);
-        }
-        if (st.fuse) plan.potrfFlopsFused += double(st.next.nb) * st.next.nb * st.next.nb / 3.0;
-        potrfFused = st.fuse;
-        rawValid = st.stage;
-      } else {
-        potrfFused = false;
-        rawValid = false;
-      }
-    }
-    // fork of block b
-    const int64_t h1Begin = (int64_t)(b + 2) * kOuterWidth, h1End = std::min<int64_t>(n, h1Begin + kOuterWidth);
-    const bool hasHand = h1Begin < n;
-    const int64_t tBegin = std::min<int64_t>(n, (int64_t)(b + 3) * kOuterWidth), tEnd = R;
-    const bool hasT = tBegin < tEnd;
-    // bulk lists.  DUE: every released unit whose target the execution stream touches at the next
-    // fork (dl <= b + 1).  OPTIONAL: units with dl >= b + 3 in deadline order -- never dl = b + 2, so
-    // that the due launch of fork b + 1 cannot meet this launch on a target and only has to wait for
-    // the optional launch of fork b - 1 -- for an even share of the work that is left.
-    pool.insert(pool.end(), released[b].begin(), released[b].end());
-    for (const DlUnit& u : released[b]) costReleased += unitCost(u);
-    vector<DlUnit> due, opt, rest, keep;
-    const bool lastFork = b + 1 >= NB;
-    // (optional launches go out every `group` forks and take targets at least group + 3 forks away:
-    //  the due launches of the forks in between never meet them on a target, so the chain runs on
-    //  while a long optional launch -- rank 256 x group, one read-modify-write per target -- is at work)
-    const bool groupFork = (b + 1) % group == 0;
-    for (const DlUnit& u : pool) {
-      (u.dl <= b + 1 || lastFork ? due : (groupFork && u.dl >= b + group + 3 ? rest : keep)).push_back(u);
-    }
-    double dueCost = 0;
-    for (const DlUnit& u : due) dueCost += unitCost(u);
-    const double tCost = hasT ? kDlTrsmTileCost * double((tEnd - tBegin + kTile - 1) / kTile) : 0.0;
-    const double share = bulkAhead * (costTotal - costLaunched) / double(std::max(1, NB - 1 - b));
-    double budget = share - dueCost - tCost;
-    std::sort(rest.begin(), rest.end(), [](const DlUnit& x, const DlUnit& y) {
-      return x.dl != y.dl ? x.dl < y.dl : (x.c != y.c ? x.c < y.c : (x.rho != y.rho ? x.rho < y.rho : x.s < y.s));
-    });
-    size_t take = 0;
-    double optCost = 0;
-    while (take < rest.size() && budget > 0) {
-      const double cst = unitCost(rest[take]);
-      budget -= cst;
-      optCost += cst;
-      take++;
-    }
-    // (the sources of one target stay together: a target's units are adjacent in the order above)
-    while (take > 0 && take < rest.size() && rest[take].rho == rest[take - 1].rho && rest[take].c == rest[take - 1].c) {
-      optCost += unitCost(rest[take]);
-      take++;
-    }
-    opt.assign(rest.begin(), rest.begin() + take);
-    keep.insert(keep.end(), rest.begin() + take, rest.end());
-    pool.swap(keep);
-    costLaunched += dueCost + optCost + tCost;
-    // board targets of this block (rows below the lump x rows below the lump, scatter addressing)
-    int64_t boardBegin = (int64_t)plan.updTasks.size(), boardEnd = boardBegin;
-    if (g.rowsBelow > 0 && !boardSegTemplates.empty()) {
-      const int64_t blockEnd = std::min<int64_t>(n, (int64_t)(b + 1) * kOuterWidth);
-      SrcDesc sr{};
-      sr.off = g.diagOff + blockEnd * n + blk.col0;
-      sr.lda = (int32_t)n;
-      sr.K = blk.width;
-      sr.nRest = (int32_t)(n - blockEnd);
-      sr.rowsBelow = (int32_t)(sr.nRest + g.rowsBelow);
-      sr.lumpRowBase = lumpRowBase;
-      plan.srcs.push_back(sr);
-      const int32_t srcIdx = (int32_t)plan.srcs.size() - 1;
-      for (SegDesc sg : boardSegTemplates) {
-        sg.src = srcIdx;
-        sg.q0 += sr.nRest;
-        plan.segs.push_back(sg);
-        const int32_t seg = (int32_t)plan.segs.size() - 1;
-        for (int32_t cT = sg.q0; cT < sg.q0 + sg.m; cT += kTile) {
-          for (int32_t rT = cT; rT < sr.rowsBelow; rT += kTile) plan.updTasks.push_back(UpdTask{seg, rT, cT, 0});
-        }
-        const double R2 = double(sr.rowsBelow - sg.q0), m = double(sg.m);
-        plan.updElems += m * R2 - m * (m - 1) / 2;
-        plan.updFlops += 2.0 * sr.K * (m * R2 - m * (m - 1) / 2);
-      }
-      boardEnd = (int64_t)plan.updTasks.size();
-      xcdOrder(boardBegin, boardEnd);
-    }
-    if (std::getenv("BSP_DL_DUMP")) {
-      fprintf(stderr, "fork %d: pool %zu due %zu opt %zu kept %zu share %.0f dueCost %.0f tCost %.0f total %.0f launched %.0f\n", b,
-              pool.size() + due.size() + opt.size(), due.size(), opt.size(), pool.size(), share, dueCost, tCost, costTotal, costLaunched);
-    }
-    const auto dueRange = emitUnits(due);
-    xcdOrder(dueRange.first, dueRange.second);
-    const auto optRange = emitUnits(opt);
-    xcdOrder(optRange.first, optRange.second);
-    const bool anyBulk = dueRange.second > dueRange.first || optRange.second > optRange.first || boardEnd > boardBegin;
-    // streams: 0 = execution stream (chain, hand-over), 1 = due stream (block solve, due tiles),
-    // 2 = optional stream (optional tiles, board targets)
-    const bool anyDue = dueRange.second > dueRange.first;
-    const bool anyOpt = optRange.second > optRange.first || boardEnd > boardBegin;
-    int32_t evCH = -1, evH1 = -1, evT = -1;
-    if (hasT || anyDue || anyOpt) {
-      evCH = numEvents++;
-      op(kDlRecord, 0, evCH);
-      plan.numForkLevels++;
-    }
-    if (hasT || anyDue) op(kDlWait, 1, evCH);
-    if (hasT) {
-      DlOp& o = op(kDlTrsmBlock, 1, b);
-      o.rowBegin = (int32_t)tBegin;
-      o.rowEnd = (int32_t)tEnd;
-      countBlockTrsm(b, tEnd - tBegin);
-    }
-    if (anyOpt && (hasT || b > 0)) {  // everything the due stream has solved so far
-      evT = numEvents++;
-      op(kDlRecord, 1, evT);
-    }
-    if (hasHand) {
-      countBlockTrsm(b, h1End - h1Begin);
-      if (h1Ridden) {
-        evH1 = evCH;  // (solved inside the block's last step)
-      } else {
-        if (evDuePrev >= 0) op(kDlWait, 0, evDuePrev);
-        DlOp& o = op(kDlTrsmBlock, 0, b);
-        o.rowBegin = (int32_t)h1Begin;
-        o.rowEnd = (int32_t)h1End;
-        if (anyDue || anyOpt) {
-          evH1 = numEvents++;
-          op(kDlRecord, 0, evH1);
-        }
-      }
-      dl.blocks[b].h2Stage = rawValid ? 1 : 0;
-      op(kDlHandUpd, 0, b);
-    }
-    if (anyDue) {
-      if (evH1 >= 0 && evH1 != evCH) op(kDlWait, 1, evH1);
-      // optional launches that may have written these targets: those of forks <= b - group - 2 (at the
-      // last fork, where everything left is due: all of them)
-      for (int32_t h = lastFork ? b - 1 : b - group - 2; h >= 0; h--) {
-        if (optDone[h] >= 0) {
-          op(kDlWait, 1, optDone[h]);
-          break;
-        }
-      }
-      DlOp& o = op(kDlBulk, 1, b);
-      o.taskBegin = dueRange.first;
-      o.taskEnd = dueRange.second;
-      o.due = 1;
-    }
-    if (hasT || anyDue) {
-      evDuePrev = numEvents++;
-      op(kDlRecord, 1, evDuePrev);
-    }
-    if (anyOpt) {
-      op(kDlWait, 2, evCH);
-      if (evT >= 0) op(kDlWait, 2, evT);
-      if (evH1 >= 0 && evH1 != evCH) op(kDlWait, 2, evH1);
-      if (optRange.second > optRange.first) {
-        DlOp& o = op(kDlBulk, 2, b);
-        o.taskBegin = optRange.first;
-        o.taskEnd = optRange.second;
-      }
-      if (boardEnd > boardBegin) {
-        DlOp& o = op(kDlBulk, 2, b);
-        o.taskBegin = boardBegin;
-        o.taskEnd = boardEnd;
-      }
-      optDone[b] = numEvents++;
-      op(kDlRecord, 2, optDone[b]);
-    }
-  }
-  BASPACHO_CHECK(pool.empty());
-  for (int32_t st = 1; st <= 2; st++) {  // join
-    const int32_t ev = numEvents++;
-    op(kDlRecord, st, ev);
-    op(kDlWait, 0, ev);
-  }
-  dl.numEvents = numEvents;
-  plan.maxChainRows = std::max<int64_t>(plan.maxChainRows, dl.maxWindowRows);
-  plan.hasDeferred = plan.hasDeferred || plan.deferredFlops > 0;
-  return dl;
-}
-
-
 }  // namespace
 
 HipPlanOptions HipPlanOptions::fromEnv() {
   HipPlanOptions o;
   if (const char* e = std::getenv("BSP_DUE_STREAM")) o.dueStream = e[0] != '0';
-  if (const char* e = std::getenv("BSP_DENSE_LUMP")) o.denseLump = e[0] != '0';
   o.planTiming = std::getenv("BSP_TIMING") != nullptr;
   if (const char* e = std::getenv("BSP_GATHER_MAX_PAIRS")) o.gatherMaxPairs = std::max(8, atoi(e));
   if (const char* e = std::getenv("BSP_BULK_AHEAD")) o.bulkAhead = std::atof(e);
-  if (const char* e = std::getenv("BSP_DL_GROUP")) o.dlGroup = std::max(1, atoi(e));
   return o;
 }
 
@@ -775,7 +309,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
   // the last panel of an outer block also carries the segments of the block-wide source
   // (K = block width): rest of the lump and, if requested, every board of the lump column.
   auto addPanels = [&](int64_t l, const LumpCols& g, int32_t lumpRowBase, bool withBoards,
-                       const vector<SegDesc>& boardSegTemplates, bool noSegs = false) {
+                       const vector<SegDesc>& boardSegTemplates) {
     int32_t count = 0;
     const int64_t n = g.width;
     vector<int64_t> pendingFrom;  // per column block of this lump (lookahead schedule, see below)
@@ -797,10 +331,6 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         plan.potrfFlops += double(nb) * nb * nb / 3.0;
         plan.trsmFlops += double(pd.rowsBelow) * nb * nb;
         panelSegBegin.push_back((int64_t)plan.segs.size());
-        if (noSegs) {  // (a dense-lump plan carries the lump's updates: addDenseLump)
-          panelSegEnd.push_back((int64_t)plan.segs.size());
-          continue;
-        }
         const int64_t innerCols = blockEnd - c0 - nb;
         if (innerCols > 0) {
           SrcDesc sr{};
@@ -893,9 +423,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                 }
                 pendingFrom[c] = b + 1;
               };
-              // (0.6 of the block's chain time: measured flat between 0.45 and 1.0, rounds 2-3; the
-              //  BSP_BULK_AHEAD switch now belongs to the dense-lump schedule)
-              double budgetUs = 0.6 * (118.0 + 0.012 * double(sr.rowsBelow));
+              double budgetUs = bulkAhead * (118.0 + 0.012 * double(sr.rowsBelow));
               // (topping the first launch up to a full round of workgroups with the nearest
               //  optional targets was measured slower: the execution stream waits on it)
               int64_t c = b + 2;
@@ -995,36 +523,6 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
   // ---- dense lumps
   const int64_t denseBegin = std::max(startLump, denseFrom);
   vector<int32_t> lastLevelOfLump(nLumps, -1);
-  // pre-pass: levels and panel counts of every dense lump; a lump of several outer blocks whose
-  // panels are alone in their levels runs as a DenseLumpPlan
-  vector<char> isDenseLump(nLumps, 0);
-  if (opts.denseLump) {
-    vector<int32_t> lastLvl(nLumps, -1), firstLvl(nLumps, 0), nPan(nLumps, 0), perLevel;
-    for (int64_t l = denseBegin; l < upToLump; l++) {
-      const int64_t n = sk.lumpStart[l + 1] - sk.lumpStart[l];
-      int32_t np = 0;
-      for (int64_t bs = 0; bs < n; bs += kOuterWidth) {
-        np += (int32_t)((std::min<int64_t>(kOuterWidth, n - bs) + kPanelWidth - 1) / kPanelWidth);
-      }
-      int32_t level = 0;
-      for (int64_t q = sk.boardRowPtr[l]; q < sk.boardRowPtr[l + 1] - 1; q++) {
-        const int64_t s = sk.boardColLump[q];
-        if (s >= denseBegin && s < l) level = std::max(level, lastLvl[s] + 1);
-      }
-      firstLvl[l] = level;
-      nPan[l] = np;
-      lastLvl[l] = level + np - 1;
-      if ((int64_t)perLevel.size() < level + np) perLevel.resize(level + np, 0);
-      for (int32_t j = 0; j < np; j++) perLevel[level + j]++;
-    }
-    for (int64_t l = denseBegin; l < upToLump; l++) {
-      const int64_t n = sk.lumpStart[l + 1] - sk.lumpStart[l];
-      bool alone = n > kOuterWidth;
-      for (int32_t j = 0; alone && j < nPan[l]; j++) alone = perLevel[firstLvl[l] + j] == 1;
-      isDenseLump[l] = alone;
-    }
-  }
-  std::map<int32_t, int32_t> dlFirstPanel, dlOtherPanel;
   for (int64_t l = denseBegin; l < upToLump; l++) {
     LumpCols g = lumpCols(sk, l);
     plan.flops += double(g.width) * g.width * g.width / 3.0 +
@@ -1071,15 +569,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       if (s >= denseBegin && s < l) level = std::max(level, lastLevelOfLump[s] + 1);
     }
     const int32_t first = (int32_t)plan.panels.size();
-    const int32_t n = addPanels(l, g, lumpRowBase, /*withBoards=*/true, boardSegs, isDenseLump[l]);
+    const int32_t n = addPanels(l, g, lumpRowBase, /*withBoards=*/true, boardSegs);
     for (int32_t j = 0; j < n; j++) bucketAt(levelBuckets, level + j).push_back({first + j, level + j});
     lastLevelOfLump[l] = level + n - 1;
-    if (isDenseLump[l]) {
-      const int32_t id = (int32_t)plan.denseLumps.size();
-      plan.denseLumps.push_back(buildDenseLump(sk, plan, l, g, lumpRowBase, boardSegs, bulkAhead, opts.dlGroup));
-      dlFirstPanel[first] = id;
-      for (int32_t j = 1; j < n; j++) dlOtherPanel[first + j] = id;
-    }
   }
 
   // ---- emit task lists level by level
@@ -1200,15 +692,6 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         plan.numForkLevels++;
       }
       if (bucket.size() == 1) {
-        auto itF = dlFirstPanel.find(bucket[0].panel);
-        if (itF != dlFirstPanel.end()) {
-          lr.dl = itF->second;
-          plan.numLaunches += (int64_t)plan.denseLumps[itF->second].ops.size();
-        } else if (dlOtherPanel.count(bucket[0].panel)) {
-          lr.dl = -2;
-        }
-      }
-      if (bucket.size() == 1) {
         lr.directPanel = bucket[0].panel;
         if (nowSegs == 1 && nowPlain) {
           lr.directSeg = nowSeg;
@@ -1322,207 +805,6 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
             plan.updTasks.size(), run, need, 100 * need / run, 100 * needWave / run, 100 * elems / (run * 256 / 1.0) * 1.0);
   }
   return plan;
-}
-
-// Symbolic replay of a dense-lump schedule: see hip_plan.h.
-std::string verifyDenseLump(const HipPlanHost& plan, const DenseLumpPlan& dl) {
-  const int64_t n = dl.n, R = dl.rowsTotal;
-  const int32_t P = (int32_t)dl.steps.size();                 // 64-column panels
-  const int32_t Td = (int32_t)((n + kTile - 1) / kTile);      // row tiles of the diagonal region
-  const int32_t Tb = (int32_t)((R - n + kTile - 1) / kTile);  // row tiles below it
-  const int32_t TT = Td + Tb;
-  if (P != Td) return "panels and diagonal row tiles differ";
-  auto rowTileOf = [&](int64_t rho) -> int32_t {
-    return rho < n ? (int32_t)(rho / kTile) : Td + (int32_t)((rho - n) / kTile);
-  };
-  auto at = [&](int32_t t, int32_t k) { return (size_t)t * P + k; };
-  vector<vector<uint8_t>> applied((size_t)TT * P);  // per (row tile, panel): count per source panel
-  for (int32_t t = 0; t < TT; t++) {
-    for (int32_t k = 0; k < P && (t >= Td || k <= t); k++) applied[at(t, k)].assign(k, 0);
-  }
-  vector<uint8_t> solved((size_t)TT * P, 0);
-  // happens-before bookkeeping: per tile, the last writer / reader of each stream
-  constexpr int NS = 3;
-  struct Acc { int32_t w[NS] = {-1, -1, -1}, r[NS] = {-1, -1, -1}; };
-  vector<Acc> acc((size_t)TT * P);
-  // known[s][o]: last op of stream o that is ordered before stream s's next op (vector clocks)
-  int32_t known[NS][NS];
-  for (auto& kr : known) {
-    for (int32_t& v : kr) v = -1;
-  }
-  struct Clock { int32_t v[NS]; };
-  vector<Clock> eventClock(dl.numEvents, Clock{{-1, -1, -1}});
-  vector<int32_t> eventStream(dl.numEvents, -1);
-  std::string err;
-  auto fail = [&](const std::string& what, int32_t opIdx) {
-    if (err.empty()) err = what + " (op " + std::to_string(opIdx) + ")";
-  };
-  auto touch = [&](int32_t t, int32_t k, bool write, int32_t st, int32_t idx) {
-    Acc& a = acc[at(t, k)];
-    for (int32_t o = 0; o < NS; o++) {
-      if (o == st) continue;
-      if (a.w[o] > known[st][o]) fail("unordered access after a write of stream " + std::to_string(o) + " at tile " + std::to_string(t) + "," + std::to_string(k), idx);
-      if (write && a.r[o] > known[st][o]) fail("unordered write after a read of stream " + std::to_string(o) + " at tile " + std::to_string(t) + "," + std::to_string(k), idx);
-    }
-    (write ? a.w[st] : a.r[st]) = idx;
-  };
-  auto allApplied = [&](int32_t t, int32_t k, int32_t upTo) {
-    const auto& v = applied[at(t, k)];
-    for (int32_t p = 0; p < upTo; p++) {
-      if (v[p] != 1) return false;
-    }
-    return true;
-  };
-  auto apply = [&](int32_t t, int32_t k, int32_t p0, int32_t p1, int32_t idx) {
-    if (solved[at(t, k)]) fail("update of a solved tile " + std::to_string(t) + "," + std::to_string(k), idx);
-    for (int32_t p = p0; p < p1; p++) {
-      if (!solved[at(t, p)] || !solved[at(k, p)]) fail("update from unsolved rows, tile " + std::to_string(t) + "," + std::to_string(k) + " source " + std::to_string(p), idx);
-      if (++applied[at(t, k)][p] != 1) fail("source applied twice, tile " + std::to_string(t) + "," + std::to_string(k) + " source " + std::to_string(p), idx);
-    }
-  };
-  auto potrf = [&](int32_t k, int32_t st, int32_t idx) {
-    if (!allApplied(k, k, k)) fail("potrf of an incomplete diagonal tile " + std::to_string(k), idx);
-    if (solved[at(k, k)]) fail("second potrf of panel " + std::to_string(k), idx);
-    solved[at(k, k)] = 1;
-    touch(k, k, true, st, idx);
-  };
-  auto windowEndTile = [&](const DlStep& s, int32_t k) { return k + 1 + (s.pd.rowsBelow + kTile - 1) / kTile; };
-  auto trsmPanelWindow = [&](int32_t k, int32_t st, int32_t idx) {
-    const DlStep& s = dl.steps[k];
-    if (!solved[at(k, k)]) fail("trsm before the potrf of panel " + std::to_string(k), idx);
-    for (int32_t t = k + 1; t < windowEndTile(s, k); t++) {
-      if (!allApplied(t, k, k)) fail("trsm of an incomplete tile " + std::to_string(t) + "," + std::to_string(k), idx);
-      if (solved[at(t, k)]) fail("tile solved twice " + std::to_string(t) + "," + std::to_string(k), idx);
-      solved[at(t, k)] = 1;
-      touch(t, k, true, st, idx);
-    }
-  };
-  auto updWindow = [&](int32_t k, bool fused, int32_t st, int32_t idx) {
-    const DlStep& s = dl.steps[k];
-    const int32_t tEnd = windowEndTile(s, k);
-    for (int32_t t = k + 1; t < tEnd; t++) {
-      for (int32_t c = k + 1; c <= t; c++) {
-        apply(t, c, k, k + 1, idx);
-        touch(t, c, true, st, idx);
-      }
-    }
-    if (fused) potrf(k + 1, st, idx);
-  };
-  auto trsmBlockRows = [&](int32_t blockIdx, int32_t rowBegin, int32_t rowEnd, int32_t st, int32_t idx) {
-        const DlBlock& b = dl.blocks[blockIdx];
-        const int32_t k0 = b.slot0, k1 = k0 + (b.width + kPanelWidth - 1) / kPanelWidth;
-        for (int32_t k = k0; k < k1; k++) {
-          for (int32_t c = k0; c <= k; c++) {
-            if (c == k && !solved[at(k, k)]) fail("trsmBlock before the block's potrf", idx);
-            if (c < k && !solved[at(k, c)]) fail("trsmBlock before the block is solved", idx);
-            touch(k, c, false, st, idx);
-          }
-        }
-        if (rowBegin % kTile != 0 && rowBegin != n) fail("trsmBlock rows not tile aligned", idx);
-        for (int64_t rho = rowBegin; rho < rowEnd; rho += kTile) {
-          const int32_t t = rowTileOf(rho);
-          for (int32_t k = k0; k < k1; k++) {
-            if (!allApplied(t, k, k0)) fail("trsmBlock of an incomplete tile " + std::to_string(t) + "," + std::to_string(k), idx);
-            for (int32_t p = k0; p < k; p++) {  // (applied inside the kernel)
-              if (++applied[at(t, k)][p] != 1) fail("source applied twice inside trsmBlock", idx);
-            }
-            if (solved[at(t, k)]) fail("tile solved twice " + std::to_string(t) + "," + std::to_string(k), idx);
-            solved[at(t, k)] = 1;
-            touch(t, k, true, st, idx);
-          }
-          if (rho < n && rho + kTile > n && rowEnd > n) {
-            // (the ragged last tile of the diagonal region: the rows below start a tile of their own)
-            rho = n - kTile;
-          }
-        }
-  };
-  int32_t idx = 0;
-  for (const DlOp& o : dl.ops) {
-    const int32_t st = o.stream;
-    switch (o.kind) {
-      case kDlPotrf: potrf(o.a, st, idx); break;
-      case kDlTrsmPanel: trsmPanelWindow(o.a, st, idx); break;
-      case kDlStep:
-        if (o.rowEnd > o.rowBegin) trsmBlockRows(dl.steps[o.a].block, o.rowBegin, o.rowEnd, st, idx);
-        trsmPanelWindow(o.a, st, idx);
-        updWindow(o.a, dl.steps[o.a].fuse != 0, st, idx);
-        break;
-      case kDlStepUpd: updWindow(o.a, dl.steps[o.a].fuse != 0, st, idx); break;
-      case kDlTrsmBlock: trsmBlockRows(o.a, o.rowBegin, o.rowEnd, st, idx); break;
-      case kDlHandUpd: {
-        const DlBlock& b = dl.blocks[o.a];
-        const int32_t k0 = b.slot0, k1 = k0 + kOuterWidth / kPanelWidth;
-        const int32_t t0 = (b.col0 + kOuterWidth) / kTile;  // first row tile of the next block
-        int32_t tiles = 0;
-        for (int32_t q = b.h2RowTile0; q < b.h2Src.rowsBelow; q += kTile) {
-          const int32_t t = t0 + q / kTile;
-          for (int32_t c = t0; c <= t; c++) {
-            for (int32_t p = k0; p < k1; p++) touch(t, p, false, st, idx), touch(c, p, false, st, idx);
-            apply(t, c, k0, k1, idx);
-            touch(t, c, true, st, idx);
-            tiles++;
-          }
-        }
-        if (tiles != b.h2Tiles) fail("hand-over tile count", idx);
-        break;
-      }
-      case kDlBulk: {
-        for (int64_t q = o.taskBegin; q < o.taskEnd; q++) {
-          const UpdTask& ut = plan.updTasks[q];
-          const SegDesc& sd = plan.segs[ut.seg];
-          const SrcDesc& sr = plan.srcs[sd.src];
-          const int64_t rel = sr.off - dl.diagOff;
-          const int64_t row0 = rel / n, colS = rel % n;  // first row below the source / its first column
-          const int32_t k0 = (int32_t)(colS / kPanelWidth), k1 = k0 + (sr.K + kPanelWidth - 1) / kPanelWidth;
-          const int64_t rho = row0 + ut.rowTile;
-          const int32_t t = rowTileOf(rho);
-          if (sd.kind == kSegBoard) {  // rows below the lump x rows below the lump: sources must be solved
-            const int32_t t2 = rowTileOf(row0 + ut.colTile);
-            for (int32_t p = k0; p < k1; p++) {
-              if (!solved[at(t, p)] || !solved[at(t2, p)]) fail("board update from unsolved rows", idx);
-              touch(t, p, false, st, idx);
-              touch(t2, p, false, st, idx);
-            }
-            continue;
-          }
-          const int32_t c = (int32_t)((row0 + ut.colTile) / kTile);
-          if (rho < n && rho % kTile != 0) fail("bulk tile not aligned", idx);
-          if (rho >= n && (rho - n) % kTile != 0) fail("bulk tile below the lump not aligned", idx);
-          for (int32_t p = k0; p < k1; p++) touch(t, p, false, st, idx), touch(c, p, false, st, idx);
-          apply(t, c, k0, k1, idx);
-          touch(t, c, true, st, idx);
-        }
-        break;
-      }
-      case kDlRecord: {
-        Clock c;
-        for (int32_t q = 0; q < NS; q++) c.v[q] = q == st ? idx : known[st][q];
-        eventClock[o.a] = c;
-        eventStream[o.a] = st;
-        break;
-      }
-      case kDlWait: {
-        if (eventStream[o.a] < 0) {
-          fail("wait for an event that was not recorded", idx);
-          break;
-        }
-        for (int32_t q = 0; q < NS; q++) {
-          if (q != st) known[st][q] = std::max(known[st][q], eventClock[o.a].v[q]);
-        }
-        break;
-      }
-      default: fail("unknown op", idx);
-    }
-    if (!err.empty()) return err;
-    idx++;
-  }
-  for (int32_t t = 0; t < TT; t++) {
-    for (int32_t k = 0; k < P && (t >= Td || k <= t); k++) {
-      if (!solved[at(t, k)]) return "tile never solved " + std::to_string(t) + "," + std::to_string(k);
-      if (!allApplied(t, k, k)) return "tile misses a source " + std::to_string(t) + "," + std::to_string(k);
-    }
-  }
-  return "";
 }
 
 HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly, int64_t vecOff,

@@ -14,7 +14,6 @@
 #pragma once
 
 #include <cstdint>
-#include <string>
 #include <vector>
 
 #include "skeleton.h"
@@ -93,9 +92,6 @@ struct TrsmTask {
 };
 
 struct LevelRange {
-  // >= 0: first level of a lump that runs as DenseLumpPlan `dl` (launched as a whole from this level;
-  // -2: a further level of such a lump -- its panels / trsm tasks serve the triangular solves only)
-  int32_t dl = -1;
   int64_t panelBegin, panelEnd;  // into levelPanels
   int64_t trsmBegin, trsmEnd;    // into trsmTasks
   int64_t updBegin, updEnd;      // into updTasks: tiles that must run before the next level
@@ -132,83 +128,6 @@ struct LevelRange {
   // due-stream mode: level whose OPTIONAL lookahead units (forked two outer blocks earlier: plain
   // read-modify-write on far columns) must be complete before this level's due units start; -1
   int64_t optWaitLevel = -1;
-};
-
-// ------------------------------------------------------------------------------------------
-// DENSE-LUMP schedule (round 4).  A lump of two or more outer blocks whose panels are alone in
-// their levels (the camera block of a bundle-adjustment Schur complement, the top separators of a
-// nested structure) is not driven level by level but by its own list of operations on two streams:
-//   * CHAIN (execution stream), per outer block b: four chainStep launches over the WINDOW rows and
-//     columns [256 b, 256 (b + 2)) only -- the block's own potrf / trsm / rank-64 updates and those of
-//     the next block's 256 rows: at most 28 light tiles per launch, every tile with its source
-//     columns in registers;
-//   * HAND-OVER H1 / H2 (execution stream): row block b + 2 enters the window of block b + 1; its rows
-//     are solved against the finished block b (trsmBlock, 4 workgroups) and its tiles in column blocks
-//     b + 1, b + 2 take block b's rank-256 update (26 tiles);
-//   * BULK (side stream): T(b) = trsmBlock of every row below row block b + 2, written once; then
-//     rank-256 update tiles (source block s -> target tile in rows >= 256 (s + 3)) in DEADLINE order:
-//     a target tile of row block i / column block c is first touched from the execution stream when
-//     the chain is at block min(i - 2, c) (hand-over or T(c)); tiles due before the next hand-over form
-//     the fork's DUE launch (event), later ones follow as OPTIONAL work within a time budget.
-// The chain no longer solves every row below each 64-column panel inside its own tiles (a 7839-wide
-// lump: 122 launches of 25-80 us, 0.07 of the matrix pipe's peak, the critical path of rounds 1-3).
-// The plan holds the operations in enqueue order; the launcher (hip_backend.hip) interprets them and
-// verifyDenseLump() (tests) replays the same list symbolically.
-enum DlOpKind : int32_t {
-  kDlPotrf = 0,      // potrfPanelDirect of step `a`
-  kDlTrsmPanel = 1,  // trsmPanelDirect of step `a` (step whose rows were not staged)
-  kDlStep = 2,       // chainStep of step `a` (rows staged by the previous step / hand-over)
-  kDlStepUpd = 3,    // updateTileDirect[Potrf] of step `a` (after kDlTrsmPanel)
-  kDlTrsmBlock = 4,  // trsmBlock: block `a`, rows [rowBegin, rowEnd) of the lump column
-  kDlHandUpd = 5,    // hand-over update H2 of fork `a`
-  kDlBulk = 6,       // update tiles [taskBegin, taskEnd) of plan.updTasks
-  kDlRecord = 7,     // record event `a` on `stream`
-  kDlWait = 8,       // `stream` waits for event `a`
-};
-struct DlOp {
-  int32_t kind, stream;  // stream 0: execution stream, 1: due stream, 2: optional stream
-  int32_t a;
-  int32_t rowBegin = 0, rowEnd = 0;       // kDlTrsmBlock (row indices inside the lump column); kDlStep: rows
-                                          // solved against the step's whole outer block by extra workgroups
-  int64_t taskBegin = 0, taskEnd = 0;     // kDlBulk
-  int32_t due = 0;                        // kDlBulk: 1 = a fork's due launch (profile class only)
-};
-// one chain step = one 64-column panel with its window
-struct DlStep {
-  PanelDesc pd;    // rowsBelow cut to the window
-  SrcDesc src;     // the panel as update source (K = nb), rows of the window
-  SegDesc sd;      // window columns right of the panel
-  PanelDesc next;  // next panel of the lump (nb = 0: none)
-  int32_t nTasks;  // lower-trapezoid tiles of the window
-  int32_t fuse;    // workgroup 0 factors `next`
-  int32_t stage;   // column tile 0 goes to the staging buffer as well
-  int32_t block;   // outer block of the panel
-  int32_t slot;    // inverse-diagonal-block slot of the panel (panel ordinal inside the lump)
-};
-struct DlBlock {
-  int64_t diagOff;     // data offset of the block's first diagonal entry
-  int32_t lda, width;  // row stride, columns of the block (<= kOuterWidth)
-  int32_t slot0;       // slot of its first panel
-  int32_t col0;        // first column inside the lump
-  // hand-over update (fork of this block): source = this block's columns, rows from the next
-  // block's first row; targets: row block b + 2 in column blocks b + 1, b + 2
-  SrcDesc h2Src;
-  SegDesc h2Seg;
-  int32_t h2Tiles = 0;   // 0: no hand-over
-  int32_t h2RowTile0 = 0;  // first below-row index of the entering rows (= 256)
-  PanelDesc h2Next;      // first panel of the next block (staging target of H2's column tile 0)
-  int32_t h2Stage = 0;   // 1: that step reads its unsolved rows from the staging buffer
-};
-struct DenseLumpPlan {
-  int32_t lump = -1;
-  int64_t diagOff = 0;         // data offset of the lump's first entry
-  int32_t n = 0, rowsTotal = 0;  // width, rows of the lump column (n + rows below)
-  int32_t numSlots = 0;        // panels
-  int32_t numEvents = 0;
-  int32_t maxWindowRows = 0;   // staging rows
-  std::vector<DlStep> steps;
-  std::vector<DlBlock> blocks;
-  std::vector<DlOp> ops;
 };
 
 // One work item of the gather-form sparse-elimination update: a target block (sj,si) of the
@@ -275,11 +194,8 @@ struct HipPlanOptions {
   bool dropElimUpdate = false; // FAULT INJECTION for the parity tests (bsp_test_set_fault, never read
                                // from the environment): the sparse-elimination update is not launched,
                                // so the factor is wrong and the full-size checks must notice
-  bool denseLump = true;      // BSP_DENSE_LUMP=0: lumps of several outer blocks level by level (rounds 1-3)
   int32_t gatherMaxPairs = 128;  // BSP_GATHER_MAX_PAIRS
-  double bulkAhead = 1e9;     // BSP_BULK_AHEAD: cap of the optional bulk work of a fork, as a multiple of an
-                              // even share of what is left (0: every target takes its sources when due)
-  int32_t dlGroup = 2;        // BSP_DL_GROUP: optional launches every `group` forks (rank 256 x group)
+  double bulkAhead = 0.6;     // BSP_BULK_AHEAD
   static HipPlanOptions fromEnv();
 };
 
@@ -292,7 +208,6 @@ struct HipPlanHost {
   std::vector<ElimGatherItem> elimItems;
   std::vector<uint32_t> elimPairOffJ, elimPairOffI;
 
-  std::vector<DenseLumpPlan> denseLumps;
   std::vector<PanelDesc> panels;
   std::vector<SrcDesc> srcs;
   std::vector<SegDesc> segs;
@@ -349,12 +264,6 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& skel,
 // SolveCtx::solveL / solveLt reuse the potrfOnly plan: its panels and row tiles).
 // lda: row stride of the block and of the rows below it (0: the block is contiguous, lda = n);
 // a span inside a wider lump has lda = lump width (NumericCtx::pseudoFactorSpans).
-// Symbolic replay of a dense-lump schedule (tests): every operation's preconditions at 64 x 64 tile
-// granularity (rows solved / sources applied exactly once / diagonal blocks complete before their
-// potrf) in enqueue order, and an event-ordered happens-before check of every pair of operations on
-// different streams that touch a common tile.  Returns an empty string, or what is wrong.
-std::string verifyDenseLump(const HipPlanHost& plan, const DenseLumpPlan& dl);
-
 HipPlanHost buildDenseOpPlan(int64_t n, int64_t k, int64_t offA, bool potrfOnly,
                              int64_t vecOff = 0, int64_t lda = 0);
 

@@ -148,11 +148,6 @@ int bsp_force_per_op(bsp_solver* s, int32_t on);
  * doElimination's update half), so the factor is WRONG -- tests/test_full_size_gpu.py checks that the
  * full-size parity checks then fail; 0 = off.  Not reachable through the environment. */
 int bsp_test_set_fault(bsp_solver* s, int32_t kind);
-/* TESTING (host only, no GPU): symbolic replay of the dense-lump schedules of the full-range factor
- * plan -- every tile solved once, every source applied exactly once, diagonal blocks complete before
- * their potrf, cross-stream accesses ordered by events.  *numPlans = number of dense-lump plans.
- * (the plan replaces the host-serial loop of Solver.cpp:198-218 for wide lumps) */
-int bsp_test_verify_dense_lumps(bsp_solver* s, int64_t* numPlans);
 /* TESTING hook of the reference: numCtx->doElimination(solver.internalGetElimCtx(i), ...)
    (Solver.h:139-145, tests/FactorTest.cpp:158-160) */
 int bsp_do_elimination_f64(bsp_solver* s, double* dev_data, int64_t elim_range_index);
