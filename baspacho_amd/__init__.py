@@ -452,6 +452,16 @@ class Solver:
     def factorFlops(self):
         return float(self._lib.bsp_factor_flops(self._h))
 
+    def planLevels(self):
+        """level table of the factor plan (bsp_plan_levels): int64 array [levels, 8]"""
+        self._lib.bsp_plan_levels.restype = ctypes.c_int64
+        n = self._lib.bsp_plan_levels(self._h, None, ctypes.c_int64(0))
+        if n < 0:
+            raise RuntimeError(_lib.load().bsp_last_error().decode("utf-8", "replace"))
+        out = np.zeros(n, dtype=np.int64)
+        self._lib.bsp_plan_levels(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_int64(n))
+        return out.reshape(-1, 8)
+
     def planStats(self):
         st = _CPlanStats()
         _check(self._lib.bsp_plan_stats_full(self._h, ctypes.byref(st)))

@@ -548,6 +548,19 @@ int bsp_bal_fill_hessian_se3_f32(bsp_solver* s, int64_t numPts, int64_t numCams,
 
 double bsp_factor_flops(const bsp_solver* s) { return s->solver->factorFlops(); }
 
+int64_t bsp_plan_levels(bsp_solver* s, int64_t* out, int64_t capacity) {
+  try {
+    std::vector<int64_t> v = hipBackendPlanLevels(s->solver->internalSymbolicContext(), 0,
+                                                  s->solver->skel().numLumps());
+    const int64_t n = (int64_t)v.size();
+    if (out) std::copy(v.begin(), v.begin() + std::min(n, capacity), out);
+    return n;
+  } catch (const std::exception& e) {
+    g_lastError = e.what();
+    return -1;
+  }
+}
+
 int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out) {
   BSP_TRY
   HipPlanStats p = hipBackendPlanStats(s->solver->internalSymbolicContext(), 0,

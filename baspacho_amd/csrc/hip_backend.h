@@ -3,6 +3,7 @@
 #pragma once
 
 #include <cstdint>
+#include <vector>
 
 #include "mat_ops.h"
 
@@ -61,6 +62,10 @@ void hipBackendForcePerOp(SymbolicCtx& sym, bool on);
 // sparse-elimination update (the factor is then wrong and the checks must say so), 0 = off.
 // Never read from the environment: a leaked variable cannot corrupt a caller's factor.
 void hipBackendSetFault(SymbolicCtx& sym, int kind);
+
+// per level of the plan (host only): {elimination range or -1, panels, widest panel, most rows below a
+// panel, trsm tasks, update tiles, lookahead tiles, rows below summed over the panels}
+std::vector<int64_t> hipBackendPlanLevels(SymbolicCtx& sym, int64_t startLump, int64_t upToLump);
 
 HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t upToLump);
 

@@ -1660,6 +1660,30 @@ void hipBackendForcePerOp(SymbolicCtx& sym, bool on) {
   h->forcePerOp = on;
 }
 
+std::vector<int64_t> hipBackendPlanLevels(SymbolicCtx& sym, int64_t startLump, int64_t upToLump) {
+  HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
+  BASPACHO_CHECK_NOTNULL(h);
+  HipPlanHost p = buildHipPlan(h->skel, h->sparseElimRanges, startLump, upToLump, h->planOpts);
+  std::vector<int64_t> out;
+  auto emit = [&](const vector<LevelRange>& levels, int64_t range) {
+    for (const LevelRange& lr : levels) {
+      int64_t maxNb = 0, maxRows = 0, sumRows = 0;
+      for (int64_t q = lr.panelBegin; q < lr.panelEnd; q++) {
+        const PanelDesc& pd = p.panels[p.levelPanels[q]];
+        maxNb = std::max<int64_t>(maxNb, pd.nb);
+        maxRows = std::max<int64_t>(maxRows, pd.rowsBelow);
+        sumRows += pd.rowsBelow;
+      }
+      const int64_t row[8] = {range, lr.panelEnd - lr.panelBegin, maxNb, maxRows, lr.trsmEnd - lr.trsmBegin,
+                              lr.updEnd - lr.updBegin, lr.defEnd - lr.defBegin, sumRows};
+      out.insert(out.end(), row, row + 8);
+    }
+  };
+  for (size_t r = 0; r < p.elimRanges.size(); r++) emit(p.elimRanges[r].bigLevels, (int64_t)r);
+  emit(p.levels, -1);
+  return out;
+}
+
 void hipBackendSetFault(SymbolicCtx& sym, int kind) {
   HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
   BASPACHO_CHECK_NOTNULL(h);

@@ -148,6 +148,11 @@ int bsp_force_per_op(bsp_solver* s, int32_t on);
  * doElimination's update half), so the factor is WRONG -- tests/test_full_size_gpu.py checks that the
  * full-size parity checks then fail; 0 = off.  Not reachable through the environment. */
 int bsp_test_set_fault(bsp_solver* s, int32_t kind);
+/* Level table of the full-range factor plan (host only; the level schedule replaces the host-serial
+ * per-lump loop of Solver.cpp:198-218): 8 values per level -- {sparse-elimination range or -1, panels,
+ * widest panel, most rows below a panel, trsm row tiles, update tiles, lookahead tiles, rows below
+ * summed over the panels}.  Returns the number of values (call with out = NULL to size), -1 on error. */
+int64_t bsp_plan_levels(bsp_solver* s, int64_t* out, int64_t capacity);
 /* TESTING hook of the reference: numCtx->doElimination(solver.internalGetElimCtx(i), ...)
    (Solver.h:139-145, tests/FactorTest.cpp:158-160) */
 int bsp_do_elimination_f64(bsp_solver* s, double* dev_data, int64_t elim_range_index);

@@ -356,3 +356,45 @@ def test_partial_solve_boundary_inside_an_elimination_range_is_an_error():
     edge = int(sk["lumpToSpan"][int(ranges[-1])])
     sol.solveLUpTo(d, edge, v, n, 1)
     sol.solveLFrom(d, edge, v, n, 1)
+
+
+@pytest.mark.parametrize("cond", [1e4, 1e8])
+def test_block_solve_by_inverses_on_ill_conditioned_lump(monkeypatch, cond):
+    """the wide-lump solves multiply by explicitly inverted 64 x 64 diagonal blocks
+    (BSP_SOLVE_INV, default on) where the reference substitutes (trsm / trsv, MatOpsCuda.cu:550-566):
+    the error of that form grows with the condition of a diagonal block of L.  One dense lump of 700
+    columns with a GRADED spectrum (A = Q diag(1 .. 1/cond) Q^T): both forms against numpy and the
+    oracle's substitution, with the bound each is held to -- backward error 1e-14 for substitution,
+    1e-16 x sqrt(cond) x 100 for the inverses (a diagonal block of L is at worst as ill conditioned as
+    sqrt(cond(A)))."""
+    import torch
+    n = 700
+    rng = np.random.default_rng(5)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A = (Q * np.logspace(0, -np.log10(cond), n)) @ Q.T
+    A = 0.5 * (A + A.T)
+    b = rng.standard_normal(n)
+    want = np.linalg.solve(A, b)
+    res = {}
+    for inv in ("1", "0"):
+        monkeypatch.setenv("BSP_SOLVE_INV", inv)
+        ss = T.columns_to_structure([set(range(i, n)) for i in range(n)])
+        sol = B.create_solver(B.Settings(), np.ones(n, dtype=np.int64), ss)
+        assert sol.numLumps() == 1
+        # one lump: the data vector IS the (permuted) n x n matrix, row-major; undo the ordering
+        perm = np.asarray(sol.paramToSpan())
+        Ap = np.empty_like(A)
+        Ap[np.ix_(perm, perm)] = A
+        d = to_dev(Ap.reshape(-1).copy())
+        sol.factor(d)
+        v = to_dev(b.copy())
+        sol.solve(d, v, n, 1)
+        torch.cuda.synchronize()
+        x = v.cpu().numpy()
+        eta = np.linalg.norm(A @ x - b, np.inf) / (np.linalg.norm(A, np.inf) * np.linalg.norm(x, np.inf)
+                                                  + np.linalg.norm(b, np.inf))
+        res[inv] = (eta, np.linalg.norm(x - want) / np.linalg.norm(want))
+    assert res["0"][0] < 1e-14, res
+    assert res["1"][0] < 1e-14 * np.sqrt(cond), res
+    # forward error: both within cond x eps of numpy's solution
+    assert res["0"][1] < 1e-13 * cond and res["1"][1] < 1e-13 * cond, res

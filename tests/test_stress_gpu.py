@@ -1,5 +1,6 @@
-"""GPU: a seeded 40-case slice of the randomised parity sweep (tools/stress.py runs the long
-version: round 2 ran 320 cases clean, outside pytest, where the driver never saw it)."""
+"""GPU: the randomised parity sweeps as part of the driver-run suite (round 4: 240 random cases, every
+lump width 1 .. 1100 with and without a lump below; tools/stress.py and tools/sweep_widths.py run the
+same cases by hand -- round 3 found a wrong factor with them that no pytest had seen)."""
 import pytest
 
 from stress_cases import run_case
@@ -16,6 +17,40 @@ def test_random_case(seed):
 def test_random_case_wide_lumps(seed):
     """300-900 parameters, denser: wide lumps, chain steps and lookahead units"""
     run_case(seed, big=True)
+
+
+@pytest.mark.parametrize("seed", range(3000, 3160))
+def test_random_case_more(seed):
+    """round 4: 160 further seeds of the same generator (random structure / sizes / elimination set /
+    dtype / batch; factor, solves, partial factor + solves, addMvFrom, per-op loops in one of five)"""
+    run_case(seed)
+
+
+@pytest.mark.parametrize("seed", range(4000, 4040))
+def test_random_case_wide_lumps_more(seed):
+    run_case(seed, big=True)
+
+
+@pytest.mark.parametrize("first", range(1, 1101, 10))
+def test_every_lump_width(first):
+    """tools/sweep_widths.py inside the suite: ten consecutive widths of a dense last lump per test,
+    alone and followed by a second lump (70 columns), device factor against numpy, fp64"""
+    from stress_cases import run_width_case
+    for W in range(first, min(first + 10, 1101)):
+        for tail in (0, 70):
+            err = run_width_case(W, tail)
+            assert err < 1e-12, (W, tail, err)
+
+
+@pytest.mark.parametrize("first", range(1, 1101, 44))
+def test_lump_widths_fp32(first):
+    """the same sweep in single precision, every fourth width"""
+    import numpy as np
+    from stress_cases import run_width_case
+    for W in range(first, min(first + 44, 1101), 4):
+        for tail in (0, 70):
+            err = run_width_case(W, tail, dtype=np.float32)
+            assert err < 2e-5, (W, tail, err)
 
 
 def test_seed_that_found_the_single_tile_block_last_step():
