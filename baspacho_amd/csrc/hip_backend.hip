@@ -1283,81 +1283,31 @@ struct HipSolveCtx : SolveCtx<T> {
         invSlot = &ent.slotOfGroup;
       }
     }
-    // block groups solved through inverses chain up when they are consecutive outer blocks of one
-    // lump: one launch per block (hip_solve_kernels.h, K-B3) instead of triangle + product
-    struct BlockOf {
-      PanelDesc first, last;
-      int w = 0, c0 = 0;
-      unsigned nT = 0;
-      const BT* inv = nullptr;
-      bool ok = false;
-    };
-    auto blockOf = [&](int64_t gIdx) {
-      BlockOf b;
-      if (gIdx < 0 || gIdx >= nG) return b;
-      const auto& grp = groups[gIdx];
-      if (grp.second - grp.first < 2 || !invBase || (*invSlot)[gIdx] < 0) return b;
-      b.first = plan.host.panels[levels[grp.first].directPanel];
-      b.last = plan.host.panels[levels[grp.second - 1].directPanel];
-      b.w = (int)(grp.second - 1 - grp.first) * kPanelWidth + b.last.nb;
-      b.c0 = b.first.lda - b.first.nRest - b.first.nb;
-      b.nT = (unsigned)((b.last.rowsBelow + kTile - 1) / kTile);
-      b.inv = invBase + (int64_t)(*invSlot)[gIdx] * kPanelWidth * kPanelWidth;
-      b.ok = true;
-      return b;
-    };
-    // `lo` is the block right before `hi` in the same lump
-    auto adjacent = [](const BlockOf& lo, const BlockOf& hi) {
-      return lo.ok && hi.ok && lo.first.lump == hi.first.lump && lo.c0 + lo.w == hi.c0;
-    };
-    auto tilesBeyond = [](const BlockOf& lo, const BlockOf& hi) {  // row tiles below `lo` past `hi`'s rows
-      return (unsigned)std::max<int64_t>(0, ((int64_t)lo.last.rowsBelow - hi.w + kTile - 1) / kTile);
-    };
-    BlockOf owed;          // forward: block whose product with the rows below it is still to be applied
-    bool chained = false;  // backward: the previous step applied the rows beyond it to this block
     for (int64_t gi = 0; gi < nG; gi++) {
       const int64_t gIdx = BACKWARD ? nG - 1 - gi : gi;
       const auto& grp = groups[gIdx];
-      const BlockOf cur = blockOf(gIdx);
-      if (!BACKWARD && owed.ok && !adjacent(owed, cur)) {
-        if (owed.nT) {
-          hipk::solveGemvBlockL<BT><<<grid(owed.nT), 256, 0, sym.stream>>>(
-              owed.first, owed.last, owed.w, plan.rowGlobal.as<int32_t>(), ref, 0);
-        }
-        owed = BlockOf();
-      }
-      if (cur.ok) {
-        if (!BACKWARD) {
-          if (owed.ok) {  // (adjacent: checked above)
-            hipk::solveBlockStepL<BT><<<grid(1 + tilesBeyond(owed, cur)), 256, 0, sym.stream>>>(
-                cur.first, cur.w, cur.inv, invBatchStride, owed.first, owed.last, owed.w,
-                plan.rowGlobal.as<int32_t>(), ref);
-          } else {
-            hipk::solveTriBlockInv<BT, false><<<grid(1), 256, 0, sym.stream>>>(cur.first, cur.w, cur.inv,
-                                                                               invBatchStride, ref);
-          }
-          owed = cur;
-        } else {
-          const BlockOf upper = chained ? blockOf(gIdx + 1) : BlockOf();
-          if (!chained && cur.nT) {
-            hipk::solveGemvBlockLt<BT><<<grid(cur.nT), 256, 0, sym.stream>>>(
-                cur.first, cur.last, cur.w, plan.rowGlobal.as<int32_t>(), ref, 0);
-          }
-          const BlockOf lower = blockOf(gIdx - 1);
-          const bool link = adjacent(lower, cur);
-          hipk::solveBlockStepLt<BT><<<grid(1 + (link ? tilesBeyond(lower, cur) : 0u)), 256, 0, sym.stream>>>(
-              cur.first, cur.w, cur.inv, invBatchStride, chained ? upper.w : 0, link ? lower.first : cur.first,
-              link ? lower.last : cur.last, link ? lower.w : 0, plan.rowGlobal.as<int32_t>(), ref);
-          chained = link;
-        }
-        continue;
-      }
-      chained = false;
       if (grp.second - grp.first >= 2) {
         const PanelDesc& first = plan.host.panels[levels[grp.first].directPanel];
         const PanelDesc& last = plan.host.panels[levels[grp.second - 1].directPanel];
         const int w = (int)(grp.second - 1 - grp.first) * kPanelWidth + last.nb;
         const unsigned nT = (unsigned)((last.rowsBelow + kTile - 1) / kTile);
+        if (invBase && (*invSlot)[gIdx] >= 0) {
+          const BT* inv = invBase + (int64_t)(*invSlot)[gIdx] * kPanelWidth * kPanelWidth;
+          if (!BACKWARD) {
+            hipk::solveTriBlockInv<BT, false><<<grid(1), 256, 0, sym.stream>>>(first, w, inv, invBatchStride, ref);
+            if (nT) {
+              hipk::solveGemvBlockL<BT><<<grid(nT), 256, 0, sym.stream>>>(
+                  first, last, w, plan.rowGlobal.as<int32_t>(), ref);
+            }
+          } else {
+            if (nT) {
+              hipk::solveGemvBlockLt<BT><<<grid(nT), 256, 0, sym.stream>>>(
+                  first, last, w, plan.rowGlobal.as<int32_t>(), ref);
+            }
+            hipk::solveTriBlockInv<BT, true><<<grid(1), 256, 0, sym.stream>>>(first, w, inv, invBatchStride, ref);
+          }
+          continue;
+        }
         if (!BACKWARD) {
           hipk::solveTriBlock<BT, false><<<grid(1), 256, 0, sym.stream>>>(first, w, ref);
           if (nT) {
@@ -1395,10 +1345,6 @@ struct HipSolveCtx : SolveCtx<T> {
         hipk::solveTriPanel<BT, true><<<gP, 256, 0, sym.stream>>>(
             plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, ref);
       }
-    }
-    if (!BACKWARD && owed.ok && owed.nT) {
-      hipk::solveGemvBlockL<BT><<<grid(owed.nT), 256, 0, sym.stream>>>(
-          owed.first, owed.last, owed.w, plan.rowGlobal.as<int32_t>(), ref, 0);
     }
   }
 

@@ -646,21 +646,13 @@ __global__ __launch_bounds__(64) void solveInvertPanels(const PanelDesc* list, T
   for (int i = 0; i < NB; i++) out[i * NB + t] = y[i];  // Inv[i][t]
 }
 
-struct SolveLoadRhs {
-  // default right-hand side of a block: what the vector holds
-  template <typename T>
-  __device__ __forceinline__ void operator()(T* xs, GP<T> x, int w) const {
-    const int tid = threadIdx.x;
-    if (tid < kSolveBlock) xs[tid] = tid < w ? x[tid] : T(0);
-  }
-};
-// `fill(xs, x, w)` puts the block's right-hand side into xs (it runs after the block's operands
-// have been requested: whatever it loads is in flight together with them)
-template <typename T, bool BACKWARD, typename Fill = SolveLoadRhs>
-__device__ __forceinline__ void triBlockInvBody(const PanelDesc& first, int w, const T* invBase,
-                                                int64_t batchStride, const SolveRef<T>& ref, T* xs, T* ts,
-                                                T (*part)[kPanelWidth], Fill fill = Fill()) {
+template <typename T, bool BACKWARD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void solveTriBlockInv(
+    PanelDesc first, int w, const T* invBase, int64_t batchStride, SolveRef<T> ref) {
   constexpr int NB = kPanelWidth, NQ = kSolveBlock / NB;
+  __shared__ T xs[kSolveBlock];
+  __shared__ T ts[NB];
+  __shared__ T part[4][NB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lda = first.lda;
   GP<const T> A = solveMat(ref) + first.diagOff;  // (c0, c0) of the block
   GP<const T> inv = (GP<const T>)invBase + (int64_t)blockIdx.z * batchStride;
@@ -684,7 +676,7 @@ __device__ __forceinline__ void triBlockInvBody(const PanelDesc& first, int w, c
       }
     }
   }
-  fill(xs, x, w);
+  if (tid < kSolveBlock) xs[tid] = tid < w ? x[tid] : T(0);
   __syncthreads();
   const int ur = (lane >> 2) & 15;
   if (!BACKWARD) {
@@ -740,29 +732,19 @@ __device__ __forceinline__ void triBlockInvBody(const PanelDesc& first, int w, c
   if (tid < w) x[tid] = xs[tid];
 }
 
-template <typename T, bool BACKWARD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void solveTriBlockInv(
-    PanelDesc first, int w, const T* invBase, int64_t batchStride, SolveRef<T> ref) {
-  __shared__ T xs[kSolveBlock];
-  __shared__ T ts[kPanelWidth];
-  __shared__ T part[4][kPanelWidth];
-  triBlockInvBody<T, BACKWARD>(first, w, invBase, batchStride, ref, xs, ts, part);
-}
-
 // K-B2 forward: rows below the block, 64 rows per workgroup: x[target(q)] -= L[row q, block] . x_B
 // (`last` = descriptor of the block's last panel: its below-rows are the block's below-rows)
 template <typename T>
-__device__ __forceinline__ void gemvBlockLBody(const PanelDesc& first, const PanelDesc& last, int w,
-                                               const int32_t* rowGlobal, const SolveRef<T>& ref,
-                                               int rowTile) {
+__global__ __launch_bounds__(256) void solveGemvBlockL(PanelDesc first, PanelDesc last, int w,
+                                                       const int32_t* rowGlobal, SolveRef<T> ref) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lda = first.lda;
   GP<const T> A = solveMat(ref) + first.diagOff + (int64_t)w * lda;  // first row below, col c0
   GP<T> vec = solveVec(ref);
   T xk[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) xk[i] = lane + 64 * i < w ? vec[first.vecOff + lane + 64 * i] : T(0);
+  const int rowTile = blockIdx.x * kTile;
   const int rows = min(kTile, last.rowsBelow - rowTile);
-  if (rows <= 0) return;
   for (int r0 = wave * 16; r0 < wave * 16 + 16; r0 += 8) {
     T p[8][4];
 #pragma unroll
@@ -783,23 +765,17 @@ __device__ __forceinline__ void gemvBlockLBody(const PanelDesc& first, const Pan
     }
   }
 }
-template <typename T>
-__global__ __launch_bounds__(256) void solveGemvBlockL(PanelDesc first, PanelDesc last, int w,
-                                                       const int32_t* rowGlobal, SolveRef<T> ref,
-                                                       int rowTile0 = 0) {
-  gemvBlockLBody<T>(first, last, w, rowGlobal, ref, rowTile0 + (int)blockIdx.x * kTile);
-}
 
 // K-B2 backward: x_B[k] -= sum over a 64-row tile of L[row q, c0 + k] * x[target(q)]; thread = k
 template <typename T>
-__device__ __forceinline__ void gemvBlockLtBody(const PanelDesc& first, const PanelDesc& last, int w,
-                                                const int32_t* rowGlobal, const SolveRef<T>& ref,
-                                                int rowTile, T* xq) {
+__global__ __launch_bounds__(256) void solveGemvBlockLt(PanelDesc first, PanelDesc last, int w,
+                                                        const int32_t* rowGlobal, SolveRef<T> ref) {
+  __shared__ T xq[kTile];
   const int tid = threadIdx.x, lda = first.lda;
   GP<const T> A = solveMat(ref) + first.diagOff + (int64_t)w * lda;
   GP<T> vec = solveVec(ref);
+  const int rowTile = blockIdx.x * kTile;
   const int rows = min(kTile, last.rowsBelow - rowTile);
-  if (rows <= 0) return;  // (uniform)
   if (tid < kTile) xq[tid] = tid < rows ? vec[solveTargetRow(last, rowGlobal, rowTile + tid)] : T(0);
   __syncthreads();
   T acc = T(0);
@@ -812,95 +788,6 @@ __device__ __forceinline__ void gemvBlockLtBody(const PanelDesc& first, const Pa
     for (int u = 0; u < 16; u++) acc += (r0 + u < rows) ? p[u] * xq[min(r0 + u, kTile - 1)] : T(0);
   }
   if (tid < w) atomicSub(vec + first.vecOff + tid, acc);
-}
-template <typename T>
-__global__ __launch_bounds__(256) void solveGemvBlockLt(PanelDesc first, PanelDesc last, int w,
-                                                        const int32_t* rowGlobal, SolveRef<T> ref,
-                                                        int rowTile0 = 0) {
-  __shared__ T xq[kTile];
-  gemvBlockLtBody<T>(first, last, w, rowGlobal, ref, rowTile0 + (int)blockIdx.x * kTile, xq);
-}
-
-// K-B3 (round 4): ONE launch per outer block of a wide lump and direction.  Rounds 2-3 ran, per block,
-// the triangle (one workgroup) and then the product of the block with every row below it (a launch
-// of its own): 2 x 31 x 2 dependent launches for the camera block of BAL-871.  The triangle of the NEXT
-// block only needs the product's first rows -- its own 256 -- so workgroup 0 of the step computes
-// those itself (forward: x_cur -= L[cur rows, prev columns] x_prev, lane = column, eight rows per
-// reduction; backward: x_cur -= L[next rows, cur columns]^T x_next, thread = column) and goes straight
-// on into the triangle, while the other workgroups of the same launch apply the neighbouring block
-// to the rows beyond (forward: block `prev` to the rows below `cur`; backward: the rows below `cur`
-// to block `prev`'s entries, which the next step's triangle needs complete).
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void solveBlockStepL(
-    PanelDesc cur, int wCur, const T* invCur, int64_t invBatchStride, PanelDesc prevFirst,
-    PanelDesc prevLast, int wPrev, const int32_t* rowGlobal, SolveRef<T> ref) {
-  __shared__ T xs[kSolveBlock];
-  __shared__ T ts[kPanelWidth];
-  __shared__ T part[4][kPanelWidth];
-  if (blockIdx.x != 0) {  // block `prev` applied to the rows below block `cur`
-    gemvBlockLBody<T>(prevFirst, prevLast, wPrev, rowGlobal, ref, wCur + ((int)blockIdx.x - 1) * kTile);
-    return;
-  }
-  auto fill = [&](T* xsh, GP<T> x, int w) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lda = prevFirst.lda;
-    // rows of `cur` = the first rows below block `prev`
-    GP<const T> A = solveMat(ref) + prevFirst.diagOff + (int64_t)wPrev * lda;
-    GP<const T> xp = solveVec(ref) + prevFirst.vecOff;
-    T xk[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) xk[i] = lane + 64 * i < wPrev ? xp[lane + 64 * i] : T(0);
-    for (int r0 = wave * 64; r0 < wave * 64 + 64; r0 += 8) {
-      T p[8][4];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        GP<const T> row = A + (int64_t)min(r0 + u, w - 1) * lda;
-#pragma unroll
-        for (int i = 0; i < 4; i++) p[u][i] = lane + 64 * i < wPrev ? row[lane + 64 * i] : T(0);
-      }
-      T d[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) d[u] = p[u][0] * xk[0] + p[u][1] * xk[1] + p[u][2] * xk[2] + p[u][3] * xk[3];
-      const T sres = waveSum8(d, lane);
-      const int ur = (lane >> 3) & 7;
-      if ((lane & 7) == 0) xsh[r0 + ur] = r0 + ur < w ? x[r0 + ur] - sres : T(0);
-    }
-  };
-  triBlockInvBody<T, false>(cur, wCur, invCur, invBatchStride, ref, xs, ts, part, fill);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void solveBlockStepLt(
-    PanelDesc cur, int wCur, const T* invCur, int64_t invBatchStride, int wNext, PanelDesc prevFirst,
-    PanelDesc prevLast, int wPrev, const int32_t* rowGlobal, SolveRef<T> ref) {
-  __shared__ T xs[kSolveBlock];
-  __shared__ T ts[kPanelWidth];
-  __shared__ T part[4][kPanelWidth];
-  if (blockIdx.x != 0) {  // rows below block `cur` applied to block `prev` (the block before `cur`)
-    gemvBlockLtBody<T>(prevFirst, prevLast, wPrev, rowGlobal, ref, wCur + ((int)blockIdx.x - 1) * kTile, ts);
-    return;
-  }
-  auto fill = [&](T* xsh, GP<T> x, int w) {
-    const int tid = threadIdx.x, lda = cur.lda;
-    // rows of block `next` = the first wNext rows below block `cur`; their solution sits behind
-    // `cur`'s in the vector (same lump)
-    GP<const T> A = solveMat(ref) + cur.diagOff + (int64_t)w * lda;
-    GP<const T> xn = x + w;
-    T acc = T(0);
-    const int k = min(tid, w - 1);
-    for (int r0 = 0; r0 < wNext; r0 += 16) {
-      T p[16], xv[16];
-#pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int r = min(r0 + u, wNext - 1);
-        p[u] = A[(int64_t)r * lda + k];
-        xv[u] = xn[r];
-      }
-#pragma unroll
-      for (int u = 0; u < 16; u++) acc += (r0 + u < wNext) ? p[u] * xv[u] : T(0);
-    }
-    if (tid < kSolveBlock) xsh[tid] = tid < w ? x[tid] - acc : T(0);
-  };
-  triBlockInvBody<T, true>(cur, wCur, invCur, invBatchStride, ref, xs, ts, part, fill);
 }
 
 // ---- Solver::addMvFrom (Solver.cpp:400-449): out += alpha * A * in on the trailing block from a
