@@ -773,37 +773,6 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     if (s.kind == kSegBoard) s.tgtBase = 0;
   }
   BASPACHO_CHECK_LT((int64_t)plan.segs.size(), (int64_t)INT32_MAX);
-  if (std::getenv("BSP_PLAN_TILE_STATS")) {
-    // 16x16x4 MFMA steps the update tiles execute (whole 64 x 64 tiles, the strictly upper wave of
-    // a diagonal tile skipped) against those that touch a wanted entry
-    double run = 0, need = 0, needWave = 0, elems = 0;
-    for (const UpdTask& t : plan.updTasks) {
-      const SegDesc& sd = plan.segs[t.seg];
-      const SrcDesc& sr = plan.srcs[sd.src];
-      const int kSteps = (sr.K + 3) / 4, segEnd = sd.q0 + sd.m;
-      const bool diag = t.rowTile == t.colTile;
-      run += (diag ? 12.0 : 16.0) * kSteps;
-      bool live[4][4];
-      for (int i = 0; i < 4; i++) {
-        for (int j = 0; j < 4; j++) {
-          const int r0 = std::max<int>(t.rowTile + 16 * i, sd.rowMin), r1 = std::min(t.rowTile + 16 * i + 16, sr.rowsBelow);
-          const int c0 = t.colTile + 16 * j, c1 = std::min(t.colTile + 16 * j + 16, segEnd);
-          live[i][j] = r0 < r1 && c0 < c1 && r1 - 1 >= c0;
-          if (live[i][j]) need += kSteps;
-          for (int r = r0; r < r1; r++) {
-            for (int c = c0; c < c1; c++) elems += r >= c;
-          }
-        }
-      }
-      for (int wi = 0; wi < 2; wi++) {
-        for (int wj = 0; wj < 2; wj++) {
-          if (live[2 * wi][2 * wj] || live[2 * wi][2 * wj + 1] || live[2 * wi + 1][2 * wj] || live[2 * wi + 1][2 * wj + 1]) needWave += 4.0 * kSteps;
-        }
-      }
-    }
-    fprintf(stderr, "update tiles: %zu, MFMA steps run %.3g, needed (16x16 granular) %.3g = %.1f %%, (32x32 wave granular) %.1f %%, fill of the run steps %.1f %%\n",
-            plan.updTasks.size(), run, need, 100 * need / run, 100 * needWave / run, 100 * elems / (run * 256 / 1.0) * 1.0);
-  }
   return plan;
 }
 
