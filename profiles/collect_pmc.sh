@@ -11,3 +11,5 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_e -o e -
 #  then hung for 15 minutes -- those counters are not collected)
 timeout 300 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TA_FLAT_READ_WAVEFRONTS_sum -d gpurun_out/pmc_f -o f -- $CMD > gpurun_out/pmc_f.log 2>&1
 ls gpurun_out/pmc_*/ 
+# round 4: MFMA instruction counts per kernel (the dense phase's matrix-pipe work against the algorithmic count)
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA -d gpurun_out/pmc_g -o g -- $CMD > gpurun_out/pmc_g.log 2>&1
