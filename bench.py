@@ -222,9 +222,9 @@ def _cpu_baseline_once(sol, host, flops):
     # pin BEFORE the BLAS is loaded (it sizes its team from the affinity mask and its threads inherit
     # it): one hardware thread per core of the largest socket -- north_star's "single-socket CPU"
     # baseline; restored afterwards
-    # (OPT-IN, CPU_BASELINE_PIN=1: measured on the GPU box -- 2 x EPYC 9575F under a VM topology -- the
-    #  pinned team ran 0.8 ... 10 s per factor against 0.8 s unpinned: cpuinfo's core ids do not
-    #  describe the real cores there)
+    # (OPT-IN, CPU_BASELINE_PIN=1: measured on the GPU box -- 2 x EPYC 9575F, socket 0 = CPUs 0-63 -- the
+    #  pinned team ran 0.8 ... 10 s per factor against 0.8-1.0 s unpinned: the box is shared, other
+    #  tenants' processes run on those cores, and only the free scheduler finds the idle ones)
     pinned, old_aff = None, None
     try:
         best = max(socks.values(), key=len) if socks else []
