@@ -1512,7 +1512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 
   // Round 3: which of the wave's four 16 x 16 sub-tiles hold a wanted entry at all (wave-uniform).
   // On block-sparse structures a quarter of the MFMA steps of whole 64 x 64 tiles only ever reach
   // masked-off entries (ragged segment ends, rows under rowMin, the upper halves of diagonal tiles):
-  // GRID 82 x 82 runs 1.69 M steps per factor of which 1.28 M are wanted (BSP_PLAN_TILE_STATS=1).
+  // GRID 82 x 82 runs 1.69 M steps per factor of which 1.28 M are wanted (a plan statistic of round 3).
   // (Measured neutral on the batched GRID workload, 11.20 against 11.19 ms: its tiles live ~11 us
   //  of which the matrix pipe accounts for 1-3 -- the rest is dependent memory round trips.)
   bool live[4];
