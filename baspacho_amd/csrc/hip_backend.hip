@@ -73,8 +73,8 @@ struct DevPlan {
   // keyed by the address of a level list that lives inside `host` (host.levels, an elimination
   // range's bigLevels): the entries die with the plan, an address is never reused under them
   std::map<const void*, SolveInvList> solveInvLists;
-  DevBuf panels, srcs, segs, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
-      updTasks, updTasksFat, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc;
+  DevBuf panels, levelPanelDescs, trsmTasksFat, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
+      updTasksFat, updTasksWide, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc;
   int64_t numUpdTasks = 0;
   vector<int64_t> slowPrefix;  // tasks [0, i) that updateTileBulk cannot take
   // forward-solve gather lists, built on the first solve that needs them
@@ -95,8 +95,6 @@ struct DevPlan {
   }
   void upload() {
     panels.upload(host.panels);
-    srcs.upload(host.srcs);
-    segs.upload(host.segs);
     chainOffTab.upload(host.chainOffTab);
     rowChain.upload(host.rowChain);
     rowLocal.upload(host.rowLocal);
@@ -104,9 +102,22 @@ struct DevPlan {
     rowGlobal.upload(host.rowGlobal);
     levelPanels.upload(host.levelPanels);
     trsmTasks.upload(host.trsmTasks);
-    updTasks.upload(host.updTasks);
+    {
+      // the factor kernels of multi-panel levels read self-contained records (one uniform load
+      // instead of index -> descriptor); the solve kernels keep the index lists
+      vector<PanelDesc> lp(host.levelPanels.size());
+      for (size_t i = 0; i < lp.size(); i++) lp[i] = host.panels[host.levelPanels[i]];
+      levelPanelDescs.upload(lp);
+      vector<TrsmTaskFat> tf(host.trsmTasks.size());
+      for (size_t i = 0; i < tf.size(); i++) {
+        const PanelDesc& pd = host.panels[host.trsmTasks[i].panel];
+        tf[i] = TrsmTaskFat{pd.diagOff, pd.lda, pd.nb, pd.rowsBelow, host.trsmTasks[i].rowTile, 0, 0};
+      }
+      trsmTasksFat.upload(tf);
+    }
     {
       vector<UpdTaskFat> fat(host.updTasks.size());
+      vector<UpdTaskWide> wide(host.updTasks.size());
       slowPrefix.assign(host.updTasks.size() + 1, 0);
       for (size_t i = 0; i < host.updTasks.size(); i++) {
         const UpdTask& t = host.updTasks[i];
@@ -127,8 +138,27 @@ struct DevPlan {
         f.fast = sd.kind == kSegIntra && sr.K > 0 && sr.K % hipk::kUpdChunk == 0;
         f.pad0 = f.pad1 = 0;
         slowPrefix[i + 1] = slowPrefix[i] + (f.fast ? 0 : 1);
+        UpdTaskWide& w = wide[i];
+        w.srcOff = sr.off;
+        w.tgtBase = sd.tgtBase;
+        w.chainTabPtr = sd.chainTabPtr;
+        w.lda = sr.lda;
+        w.K = sr.K;
+        w.rowsBelow = sr.rowsBelow;
+        w.nRest = sr.nRest;
+        w.lumpRowBase = sr.lumpRowBase;
+        w.kind = sd.kind;
+        w.segEnd = sd.q0 + sd.m;
+        w.tgtStride = sd.tgtStride;
+        w.firstChainOrd = sd.firstChainOrd;
+        w.rowMin = sd.rowMin;
+        w.rowTile = t.rowTile;
+        w.colTile = t.colTile;
+        w.atomic = t.atomic;
+        w.pad0 = w.pad1 = w.pad2 = w.pad3 = w.pad4 = 0;
       }
       updTasksFat.upload(fat);
+      updTasksWide.upload(wide);
     }
     elimChainLump.upload(host.elimChainLump);
     elimLumpDesc.upload(host.elimLumpDesc);
@@ -563,7 +593,10 @@ struct HipSymbolicCtx : SymbolicCtx {
   // per level list the panels whose diagonal blocks are inverted (uploaded once)
   DevBuf solveInvScratch;
   bool solveInv = true;  // BSP_SOLVE_INV=0: the substitution kernels of rounds 1-2
-  static constexpr int64_t updPrefetchMaxWgs = 2048;  // updateTile<PREFETCH> for launches of up to this many workgroups
+#ifndef BSP_UPD_PREFETCH_MAX_WGS
+#define BSP_UPD_PREFETCH_MAX_WGS 2048
+#endif
+  static constexpr int64_t updPrefetchMaxWgs = BSP_UPD_PREFETCH_MAX_WGS;  // updateTile<PREFETCH> for launches of up to this many workgroups
   PtrRing ptrRing;
   std::map<std::pair<int64_t, int64_t>, std::pair<std::unique_ptr<DevBuf>, size_t>> addMvTileLists;
 
@@ -610,7 +643,7 @@ struct HipNumericCtx : NumericCtx<T> {
     // (Asking for enough dynamic LDS that only ceil(workgroups / CUs) of a small launch fit on a CU,
     //  in case the dispatcher packs them four to a CU: no effect at batch 1 / 8 / 64 -- it does not.)
     kern<<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, extraLds, stream>>>(
-        plan.srcs.as<SrcDesc>(), plan.segs.as<SegDesc>(), plan.updTasks.as<UpdTask>() + begin,
+        plan.updTasksWide.as<UpdTaskWide>() + begin,
         plan.chainOffTab.as<int64_t>(), plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(),
         plan.rowColOff.as<int32_t>(), ref, altTarget, altStride, atomicMask);
   }
@@ -685,7 +718,7 @@ struct HipNumericCtx : NumericCtx<T> {
               plan.host.panels[lr.directPanel], ref, dinvCur);
         } else {
           hipk::potrfPanel<BT><<<dim3(nP, gy.y), 256, 0, sym.stream>>>(
-              plan.panels.as<PanelDesc>(), plan.levelPanels.as<int32_t>() + lr.panelBegin, ref);
+              plan.levelPanelDescs.as<PanelDesc>() + lr.panelBegin, ref);
         }
         timer.end();
       }
@@ -738,7 +771,7 @@ struct HipNumericCtx : NumericCtx<T> {
               plan.host.panels[lr.directPanel], ref, dinvCur);
         } else {
           hipk::trsmPanel<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
-              plan.panels.as<PanelDesc>(), plan.trsmTasks.as<TrsmTask>() + lr.trsmBegin, ref);
+              plan.trsmTasksFat.as<TrsmTaskFat>() + lr.trsmBegin, ref);
         }
         timer.end();
       }

@@ -277,7 +277,6 @@ template <typename T>
 __global__ __launch_bounds__(256) void elimFactorTinyStaged(const ElimLumpDesc* descs,
                                                             DataRef<T> dref, int numLumps) {
   __shared__ T scratch[4][kStagedCap];
-  constexpr int IT = kStagedCap / 64;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, sub = lane & 15, q = lane >> 4;
   const int first = (blockIdx.x * 4 + wave) * kTinyPerWave;
@@ -295,6 +294,9 @@ __global__ __launch_bounds__(256) void elimFactorTinyStaged(const ElimLumpDesc* 
     if (live) tinyLumpBody<T>(data + ld.diagOff, ld.n, ld.rowsBelow, sub);
     return;
   }
+  // (Round 4: 16 bytes per lane in and out -- half the wave loads and stores; the stretch starts at
+  //  an 8-byte boundary, which global accesses tolerate -- measured SLOWER: 0.364 against 0.335 ms.)
+  constexpr int IT = kStagedCap / 64;
   const int E = (int)len;
   GP<T> D0 = data + start;
   LP<T> sc = (LP<T>)scratch[wave];
@@ -1113,12 +1115,12 @@ __device__ __forceinline__ void potrfPanelTiles(GP<T> A, int nb, int lda, T (*bl
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* panels,
-                                                  const int32_t* levelPanels, DataRef<T> dref) {
+__global__ __launch_bounds__(256) void potrfPanel(const PanelDesc* levelPanelDescs,
+                                                  DataRef<T> dref) {
   __shared__ T blk[8 * kPanelWidth][4];  // (ring of three column blocks + sol / the blocked form's two buffers)
   T(*sol)[4] = blk + 3 * kPanelWidth;
   BSP_STAMP(0);
-  const PanelDesc pd = panels[levelPanels[blockIdx.x]];
+  const PanelDesc pd = levelPanelDescs[blockIdx.x];  // (the level's descriptors in launch order)
   potrfPanelTiles<T>(pickData(dref) + pd.diagOff, pd.nb, pd.lda, blk, sol, &blk[4 * kPanelWidth][0]);
   BSP_STAMP(3);
 }
@@ -1399,11 +1401,10 @@ __device__ __forceinline__ void trsmTileRegs(GP<const T> A, GP<const T> dinv, GP
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void trsmPanel(const PanelDesc* panels, const TrsmTask* tasks,
-                                                 DataRef<T> dref) {
+__global__ __launch_bounds__(256) void trsmPanel(const TrsmTaskFat* tasks, DataRef<T> dref) {
   __shared__ T lds[kTrsmLdsElems];
-  const TrsmTask task = tasks[blockIdx.x];
-  const PanelDesc pd = panels[task.panel];
+  const TrsmTaskFat pd = tasks[blockIdx.x];  // (panel fields + row tile in one uniform load)
+  const TrsmTaskFat& task = pd;
   GP<T> data = pickData(dref);
   const int nb = pd.nb, lda = pd.lda;
   GP<T> P = data + pd.diagOff + (int64_t)(nb + task.rowTile) * lda;
@@ -1453,8 +1454,7 @@ constexpr int kUpdChunk = 32;  // K chunk of updateTile: 2 x 64 x 34 doubles = 3
 // multiplies; in saturated launches the other workgroups of the CU already do, and the staging
 // registers held across the multiplies cost more than they bring (64 x GRID: 11.67 against 11.20 ms).
 template <typename T, bool PREFETCH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 3 : 4, 4))) void updateTile(const SrcDesc* srcs, const SegDesc* segs,
-                                                  const UpdTask* tasks, const int64_t* chainOffTab,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 3 : 4, 4))) void updateTile(const UpdTaskWide* tasks, const int64_t* chainOffTab,
                                                   const int32_t* rowChain, const int32_t* rowLocal,
                                                   const int32_t* rowColOff, DataRef<T> dref,
                                                   T* altTarget = nullptr, int64_t altStride = 0,
@@ -1468,65 +1468,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 
   __shared__ int32_t colOff[kTile];
 
   UPD_STAMP(0, (long long)wall_clock64());
-  const UpdTask task = tasks[blockIdx.x];
-  const SegDesc sd = segs[task.seg];
-  const SrcDesc pd = srcs[sd.src];  // (named pd: rowsBelow / nRest / lumpRowBase as for a panel)
+  // Round 4: ONE uniform load (task, segment and source fields side by side, hip_plan.h) instead of
+  // the task -> segment -> source chain of three dependent ones.
+  const UpdTaskWide w = tasks[blockIdx.x];
+  if (w.K <= 0) return;
   GP<T> data = pickData(dref);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = pd.K, lda = pd.lda;
+  const int K = w.K, lda = w.lda;
   UPD_STAMP(6, (long long)K);
   UPD_STAMP(7, -(long long)(gridDim.x * gridDim.y));
   UPD_STAMP(1, (long long)wall_clock64());
-  GP<const T> P = data + pd.off;  // first row below the source columns
-  const bool diagTile = task.rowTile == task.colTile;
-  const int segEnd = sd.q0 + sd.m;
-
-  // per-row / per-column target addressing of this tile
-  if (tid < kTile) {
-    const int q = task.rowTile + tid;
-    int64_t base = 0;
-    if (q < pd.rowsBelow) {
-      if (sd.kind == kSegIntra) {
-        base = sd.tgtBase + (int64_t)q * sd.tgtStride;
-      } else {
-        const int rr = pd.lumpRowBase + (q - pd.nRest);
-        base = chainOffTab[sd.chainTabPtr + (rowChain[rr] - sd.firstChainOrd)] +
-               (int64_t)rowLocal[rr] * sd.tgtStride;
-      }
-    }
-    rowBase[tid] = base;
-  } else if (tid < 2 * kTile) {
-    const int cidx = tid - kTile;
-    const int q = task.colTile + cidx;
-    int32_t off = 0;
-    if (q < segEnd) off = sd.kind == kSegIntra ? q : rowColOff[pd.lumpRowBase + (q - pd.nRest)];
-    colOff[cidx] = off;
-  }
-  const T* Bt = diagTile ? As : Bs;
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-  const int li = lane & 15, lk = lane >> 4;
-  using Acc = typename Mfma<T>::Acc;
-  Acc acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-  // a diagonal tile only needs sub-tiles on or below the diagonal
-  const bool skipUpper = diagTile && wr < wc;
-  // Round 3: which of the wave's four 16 x 16 sub-tiles hold a wanted entry at all (wave-uniform).
-  // On block-sparse structures a quarter of the MFMA steps of whole 64 x 64 tiles only ever reach
-  // masked-off entries (ragged segment ends, rows under rowMin, the upper halves of diagonal tiles):
-  // GRID 82 x 82 runs 1.69 M steps per factor of which 1.28 M are wanted (a plan statistic of round 3).
-  // (Measured neutral on the batched GRID workload, 11.20 against 11.19 ms: its tiles live ~11 us
-  //  of which the matrix pipe accounts for 1-3 -- the rest is dependent memory round trips.)
-  bool live[4];
-  {
-    const int wrU = __builtin_amdgcn_readfirstlane(wr), wcU = __builtin_amdgcn_readfirstlane(wc);
-    const int rowLo = max(sd.rowMin, task.rowTile), rowHi = min(task.rowTile + kTile, pd.rowsBelow);
-    const int colHi = min(task.colTile + kTile, segEnd);
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const int r0 = task.rowTile + wrU + (t >> 1) * 16, c0 = task.colTile + wcU + (t & 1) * 16;
-      live[t] = max(r0, rowLo) < min(r0 + 16, rowHi) && c0 < colHi && min(r0 + 16, rowHi) - 1 >= c0;
-    }
-  }
-  const bool allLive = live[0] && live[1] && live[2] && live[3];
+  GP<const T> P = data + w.srcOff;  // first row below the source columns
+  const bool diagTile = w.rowTile == w.colTile;
+  const int segEnd = w.segEnd;
 
   // K loop in chunks of KC source columns.  Staging map: k = tid % KC, rows (tid / KC) + (256/KC)*it;
   // all loads of a chunk are issued before the first LDS write (memory-level parallelism), then
@@ -1547,7 +1501,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 
     const int kcl = wide ? min(kBase + sk, K - 2) : 0;
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
-      const int qa = min(task.rowTile + sr + RSTEP * it, pd.rowsBelow - 1);
+      const int qa = min(w.rowTile + sr + RSTEP * it, w.rowsBelow - 1);
       GP<const T> pa = P + (int64_t)qa * lda + kcl;
       if (wide) {
         va[it] = *(GP2)pa;
@@ -1558,7 +1512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 
     if (!diagTile) {
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
-        const int qb = min(task.colTile + sr + RSTEP * it, segEnd - 1);
+        const int qb = min(w.colTile + sr + RSTEP * it, segEnd - 1);
         GP<const T> pb = P + (int64_t)qb * lda + kcl;
         if (wide) {
           vb[it] = *(GP2)pb;
@@ -1568,11 +1522,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 
       }
     }
   };
-  if (PREFETCH) fetch(0);
+  // Round 4: the first chunk is requested BEFORE the row / column tables are looked up (a board
+  // segment's tables are two more dependent loads: row -> chain -> chain offset), not after them.
+  fetch(0);
+
+  // per-row / per-column target addressing of this tile
+  if (tid < kTile) {
+    const int q = w.rowTile + tid;
+    int64_t base = 0;
+    if (q < w.rowsBelow) {
+      if (w.kind == kSegIntra) {
+        base = w.tgtBase + (int64_t)q * w.tgtStride;
+      } else {
+        const int rr = w.lumpRowBase + (q - w.nRest);
+        base = chainOffTab[w.chainTabPtr + (rowChain[rr] - w.firstChainOrd)] +
+               (int64_t)rowLocal[rr] * w.tgtStride;
+      }
+    }
+    rowBase[tid] = base;
+  } else if (tid < 2 * kTile) {
+    const int cidx = tid - kTile;
+    const int q = w.colTile + cidx;
+    int32_t off = 0;
+    if (q < segEnd) off = w.kind == kSegIntra ? q : rowColOff[w.lumpRowBase + (q - w.nRest)];
+    colOff[cidx] = off;
+  }
+  const T* Bt = diagTile ? As : Bs;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  const int li = lane & 15, lk = lane >> 4;
+  using Acc = typename Mfma<T>::Acc;
+  Acc acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+  // a diagonal tile only needs sub-tiles on or below the diagonal
+  const bool skipUpper = diagTile && wr < wc;
+  // (Round 3 skipped the MFMA steps of 16 x 16 sub-tiles that only reach masked-off entries --
+  //  a quarter of the steps on GRID 82 x 82 -- behind wave-uniform flags: measured neutral, 11.20
+  //  against 11.19 ms on the batched GRID workload, and the second form of the loop cost 23
+  //  registers; removed in round 4.)
+  GP<T> tbase = altTarget ? (GP<T>)altTarget + (int64_t)blockIdx.y * altStride : data;
+
   for (int kBase = 0; kBase < K; kBase += KC) {
     const int kc = min(KC, K - kBase);
     const int kPad = (kc + 3) & ~3;
-    if (!PREFETCH) fetch(kBase);
+    if (!PREFETCH && kBase > 0) fetch(kBase);
     if (kBase > 0) __syncthreads();  // the previous chunk has been consumed
     // element k of the chunk sits in .x of the loaded pair unless the pair was clamped back by one
     // (k = K - 1 with K odd)
@@ -1581,7 +1572,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int r = sr + RSTEP * it;
-      const bool rowOk = task.rowTile + r < pd.rowsBelow;
+      const bool rowOk = w.rowTile + r < w.rowsBelow;
       As[r * LD + sk] = (ok0 && rowOk) ? (shifted ? va[it].y : va[it].x) : T(0);
       As[r * LD + sk + 1] = (ok1 && rowOk) ? va[it].y : T(0);
     }
@@ -1589,7 +1580,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
         const int r = sr + RSTEP * it;
-        const bool rowOk = task.colTile + r < segEnd;
+        const bool rowOk = w.colTile + r < segEnd;
         Bs[r * LD + sk] = (ok0 && rowOk) ? (shifted ? vb[it].y : vb[it].x) : T(0);
         Bs[r * LD + sk + 1] = (ok1 && rowOk) ? vb[it].y : T(0);
       }
@@ -1598,36 +1589,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 
     if (kBase == 0) { UPD_STAMP(2, (long long)wall_clock64()); }
     if (PREFETCH && kBase + KC < K) fetch(kBase + KC);
     if (!skipUpper) {
-      if (allLive) {
-        for (int k0 = 0; k0 < kPad; k0 += 4) {
-          const T a0 = As[(wr + li) * LD + k0 + lk];
-          const T a1 = As[(wr + 16 + li) * LD + k0 + lk];
-          const T b0 = Bt[(wc + li) * LD + k0 + lk];
-          const T b1 = Bt[(wc + 16 + li) * LD + k0 + lk];
-          acc00 = Mfma<T>::run(a0, b0, acc00);
-          acc01 = Mfma<T>::run(a0, b1, acc01);
-          acc10 = Mfma<T>::run(a1, b0, acc10);
-          acc11 = Mfma<T>::run(a1, b1, acc11);
-        }
-      } else {
-        for (int k0 = 0; k0 < kPad; k0 += 4) {
-          const T a0 = As[(wr + li) * LD + k0 + lk];
-          const T a1 = As[(wr + 16 + li) * LD + k0 + lk];
-          const T b0 = Bt[(wc + li) * LD + k0 + lk];
-          const T b1 = Bt[(wc + 16 + li) * LD + k0 + lk];
-          if (live[0]) acc00 = Mfma<T>::run(a0, b0, acc00);
-          if (live[1]) acc01 = Mfma<T>::run(a0, b1, acc01);
-          if (live[2]) acc10 = Mfma<T>::run(a1, b0, acc10);
-          if (live[3]) acc11 = Mfma<T>::run(a1, b1, acc11);
-        }
+      for (int k0 = 0; k0 < kPad; k0 += 4) {
+        const T a0 = As[(wr + li) * LD + k0 + lk];
+        const T a1 = As[(wr + 16 + li) * LD + k0 + lk];
+        const T b0 = Bt[(wc + li) * LD + k0 + lk];
+        const T b1 = Bt[(wc + 16 + li) * LD + k0 + lk];
+        acc00 = Mfma<T>::run(a0, b0, acc00);
+        acc01 = Mfma<T>::run(a0, b1, acc01);
+        acc10 = Mfma<T>::run(a1, b0, acc10);
+        acc11 = Mfma<T>::run(a1, b1, acc11);
       }
     }
   }
   UPD_STAMP(3, (long long)wall_clock64());
   if (!skipUpper) {
-    // Scatter.  Non-atomic targets: gather all 16 old values first (independent loads in
-    // flight together), then subtract and store -- a read-modify-write per element would
-    // serialise 16 memory round trips.
+    // Scatter.
     // Round 3, built and measured on the batched GRID workload, not kept:
     //  * pair form (the lanes of a column pair swap one accumulator per two rows through DPP, each
     //    then owns both columns of a row: one 16-byte read and write instead of two 8-byte ones,
@@ -1635,49 +1611,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 
     //    11.15 ms -- the instruction count of the read-modify-write is not the bound;
     //  * old values requested BEFORE the K loop, or right after chunk 0 went to LDS (overlapping
     //    one of the tile's dependent memory round trips with the operand fetch): 16 values held
-    //    across the loop do not fit the 128 registers of 4 waves per SIMD in fp64 (127-166
-    //    registers spilled; at 3 waves per SIMD and 168 registers it still spills);
+    //    across the loop do not fit the 128 registers of 4 waves per SIMD in fp64;
+    //  * round 4: requested before the K loop straight INTO the accumulator registers (which then
+    //    hold -old + sum a b, negated once when chunk 0 is in LDS; no register added): GRID 82 x 82
+    //    1.200 against 1.192 ms, batch of 64 10.82 against 10.78 -- hiding this round trip buys
+    //    nothing (and in fp32 the products, added one by one to a large old value, are each rounded
+    //    at its magnitude: the per-op boundary differed from the fused path by 2e-6);
     //  * next chunk fetched during the multiplies in EVERY launch: 11.67 against 11.20 ms (now the
     //    PREFETCH variant, for launches of a few rounds only).
     const Acc* accs[4] = {&acc00, &acc01, &acc10, &acc11};
-    GP<T> tbase = altTarget ? (GP<T>)altTarget + (int64_t)blockIdx.y * altStride : data;
-    GP<T> ptr[16];
-    bool ok[16];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const int r0 = wr + (t >> 1) * 16, c0 = wc + (t & 1) * 16;
-      const int cIn = c0 + li;
-      const int qc = task.colTile + cIn;
-      const int32_t co = colOff[cIn];
-#pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        const int rIn = r0 + Mfma<T>::row(lane, reg);
-        const int qr = task.rowTile + rIn;
-        ok[t * 4 + reg] = qc < segEnd && qr < pd.rowsBelow && qr >= qc && qr >= sd.rowMin;
-        ptr[t * 4 + reg] = tbase + rowBase[rIn] + co;
-      }
-    }
-    if (task.atomic & atomicMask) {
+    const bool atomicTile = (w.atomic & atomicMask) != 0;
+    T old[16];
+    if (!atomicTile) {  // gather all 16 old values first (independent loads in flight together)
 #pragma unroll
       for (int t = 0; t < 4; t++) {
+        const int32_t co = colOff[wc + (t & 1) * 16 + li];
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-          if (ok[t * 4 + reg]) atomicSub(ptr[t * 4 + reg], (*accs[t])[reg]);
+          // (masked-off entries point at valid memory)
+          old[t * 4 + reg] = *(tbase + rowBase[wr + (t >> 1) * 16 + Mfma<T>::row(lane, reg)] + co);
         }
       }
-    } else {
-      T old[16];
-#pragma unroll
-      for (int e = 0; e < 16; e++) old[e] = *ptr[e];  // masked-off entries point at valid memory
 #if defined(BSP_TRACE_UPD)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       UPD_STAMP(4, (long long)wall_clock64());
 #endif
+    }
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < 4; t++) {
+      const int r0 = wr + (t >> 1) * 16, c0 = wc + (t & 1) * 16;
+      const int cIn = c0 + li;
+      const int qc = w.colTile + cIn;
+      const int32_t co = colOff[cIn];
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-          if (ok[t * 4 + reg]) *ptr[t * 4 + reg] = old[t * 4 + reg] - (*accs[t])[reg];
+      for (int reg = 0; reg < 4; reg++) {
+        const int rIn = r0 + Mfma<T>::row(lane, reg);
+        const int qr = w.rowTile + rIn;
+        const bool ok = qc < segEnd && qr < w.rowsBelow && qr >= qc && qr >= w.rowMin;
+        GP<T> ptr = tbase + rowBase[rIn] + co;
+        if (ok) {
+          if (atomicTile) {
+            atomicSub(ptr, (*accs[t])[reg]);
+          } else {
+            *ptr = old[t * 4 + reg] - (*accs[t])[reg];
+          }
         }
       }
     }
@@ -1746,6 +1723,9 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
   // of a bulk launch (17 us per chain launch on average, 100+ us in the worst launches:
   // tools/trace_extents.py).  No-return atomics for every tile (no old values at all) cost the
   // bulk 11 % (3.74 -> 4.15 ms serialised).
+  // (Round 4: requesting them before the loop straight INTO the accumulator registers -- which
+  //  then hold -old + sum a b, no register added -- measured 0.7 % slower on BAL-871, 6.37-6.44
+  //  against 6.33-6.38 ms: the first chunk then waits for sixteen HBM misses instead of an L2 hit.)
   GP<T> tgt = data + t.tgtBase;
   const int oa0 = BulkSwizzle<T>::at(wr + li, lk), oa1 = BulkSwizzle<T>::at(wr + 16 + li, lk);
   const int ob0 = BulkSwizzle<T>::at(wc + li, lk), ob1 = BulkSwizzle<T>::at(wc + 16 + li, lk);

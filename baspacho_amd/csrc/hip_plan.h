@@ -86,10 +86,34 @@ struct UpdTaskFat {
 };
 static_assert(sizeof(UpdTaskFat) == 64, "one scalar load");
 
+// Self-contained form of ANY UpdTask (board segments, ragged K): the fields of the task, its
+// segment and its source that updateTile reads, in one uniform 96-byte load -- the task -> segment
+// -> source chain was three dependent round trips at the head of every tile of a small front.
+// Built at upload time.
+struct UpdTaskWide {
+  int64_t srcOff;       // SrcDesc::off
+  int64_t tgtBase;      // SegDesc::tgtBase
+  int64_t chainTabPtr;  // SegDesc::chainTabPtr
+  int32_t lda, K, rowsBelow, nRest;                 // SrcDesc
+  int32_t lumpRowBase, kind, segEnd, tgtStride;     // SrcDesc / SegDesc (segEnd = q0 + m)
+  int32_t firstChainOrd, rowMin, rowTile, colTile;  // SegDesc / UpdTask
+  int32_t atomic, pad0, pad1, pad2, pad3, pad4;
+};
+static_assert(sizeof(UpdTaskWide) == 96, "two scalar loads");
+
 struct TrsmTask {
   int32_t panel;
   int32_t rowTile;
 };
+
+// Self-contained form of a TrsmTask (the panel fields the kernel reads beside the row tile): one
+// uniform load instead of task -> panel.  Built at upload time.
+struct TrsmTaskFat {
+  int64_t diagOff;
+  int32_t lda, nb, rowsBelow, rowTile;
+  int32_t pad0, pad1;
+};
+static_assert(sizeof(TrsmTaskFat) == 32, "one scalar load");
 
 struct LevelRange {
   int64_t panelBegin, panelEnd;  // into levelPanels
