@@ -1160,13 +1160,14 @@ __global__ __launch_bounds__(256) void potrfPanelDirect(PanelDesc pd, DataRef<T>
 // computed once per workgroup (wave j inverts block j, lane c < 16 solves column c in registers);
 // the solve through inverted 16x16 diagonal blocks is the standard GPU formulation (error grows
 // with the condition of a 16x16 block of L, not of the panel).
-// Ls: 64 x kTrsmLd (lower triangle of L, identity beyond nb), Dv: 64 x kTrsmLdInv.
-constexpr int kTrsmLd = 66, kTrsmLdInv = 18;
-constexpr int kTrsmLdsElems = kPanelWidth * (kTrsmLd + kTrsmLdInv);
+// Ls: 64 x kTrsmLd (lower triangle of L, identity beyond nb; the inverted diagonal blocks take
+// the place of the diagonal blocks).
+constexpr int kTrsmLd = 66;
+constexpr int kTrsmLdsElems = kPanelWidth * kTrsmLd;
 template <typename T>
 __device__ __forceinline__ void trsmTileMfma(GP<const T> A, GP<T> P, int lda, int nb, int rows,
-                                             T* Ls, T* Dv) {
-  constexpr int LDT = kTrsmLd, LDV = kTrsmLdInv, N = kPanelWidth;
+                                             T* Ls) {
+  constexpr int LDT = kTrsmLd, N = kPanelWidth;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, q = lane >> 4;
   const bool active = 16 * w + n < rows;
   GP<T> row = P + (int64_t)(active ? 16 * w + n : 0) * lda;
@@ -1236,9 +1237,12 @@ __device__ __forceinline__ void trsmTileMfma(GP<const T> A, GP<T> P, int lda, in
   {  // wave w inverts diagonal block w
     T y[16];
     invertColumn16(Ls + (16 * w) * LDT + 16 * w, LDT, n, y);
+    // (round 4: written over the diagonal block itself -- only this wave reads it, all its reads
+    //  precede these writes, and the stages below use the off-diagonal blocks only: 33.8 instead of
+    //  43 KB of LDS, four workgroups per CU instead of three)
     if (lane < 16) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) Dv[(16 * w + i) * LDV + n] = y[i];
+      for (int i = 0; i < 16; i++) Ls[(16 * w + i) * LDT + 16 * w + n] = y[i];
     }
   }
   __syncthreads();
@@ -1256,7 +1260,7 @@ __device__ __forceinline__ void trsmTileMfma(GP<const T> A, GP<T> P, int lda, in
       Acc y = {0, 0, 0, 0};
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        y = Mfma<T>::run(Dv[(16 * j + pm) * LDV + 4 * q + r], x[j][r], y);
+        y = Mfma<T>::run(Ls[(16 * j + pm) * LDT + 16 * j + 4 * q + r], x[j][r], y);
       }
       x[j] = y;
     }
@@ -1401,7 +1405,7 @@ __device__ __forceinline__ void trsmTileRegs(GP<const T> A, GP<const T> dinv, GP
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void trsmPanel(const TrsmTaskFat* tasks, DataRef<T> dref) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void trsmPanel(const TrsmTaskFat* tasks, DataRef<T> dref) {
   __shared__ T lds[kTrsmLdsElems];
   const TrsmTaskFat pd = tasks[blockIdx.x];  // (panel fields + row tile in one uniform load)
   const TrsmTaskFat& task = pd;
@@ -1409,7 +1413,7 @@ __global__ __launch_bounds__(256) void trsmPanel(const TrsmTaskFat* tasks, DataR
   const int nb = pd.nb, lda = pd.lda;
   GP<T> P = data + pd.diagOff + (int64_t)(nb + task.rowTile) * lda;
   const int rows = min(kTile, pd.rowsBelow - task.rowTile);
-  trsmTileMfma<T>(data + pd.diagOff, P, lda, nb, rows, lds, lds + kPanelWidth * kTrsmLd);
+  trsmTileMfma<T>(data + pd.diagOff, P, lda, nb, rows, lds);
 }
 
 template <typename T>
