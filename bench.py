@@ -770,6 +770,17 @@ def main():
             sol.solve(main_run.last, work, order, 1)
             torch.cuda.synchronize(device)
             out["solve1_ms"] = round(1e3 * (time.perf_counter() - t0), 3)
+            # ten right-hand sides in one call (column-major, leading dimension = order), as the
+            # reference's bench times solve-1 and solve-10 (Bench.cpp)
+            rhs10 = torch.from_numpy(T.random_data(order * 10, -1, 1, 39)).to(device)
+            work10 = rhs10.clone()
+            sol.solve(main_run.last, work10, order, 10)  # warm-up
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            work10.copy_(rhs10)
+            sol.solve(main_run.last, work10, order, 10)
+            torch.cuda.synchronize(device)
+            out["solve10_ms"] = round(1e3 * (time.perf_counter() - t0), 3)
         except Exception as e:
             out["solve1_ms"] = "error: %s" % e
 
