@@ -86,37 +86,44 @@ int main(int argc, char** argv) {
   int K = argc > 3 ? atoi(argv[3]) : 64;  // source width of the update
   SrcDesc sr{}; sr.off = pd.diagOff + (int64_t)nb * n - (K - nb); sr.lda = n; sr.K = K; sr.rowsBelow = pd.rowsBelow; sr.nRest = pd.nRest; sr.lumpRowBase = 0;
   SegDesc sd{}; sd.src = 0; sd.kind = kSegIntra; sd.q0 = 0; sd.m = pd.nRest; sd.tgtBase = (int64_t)(c0 + nb) * n + (c0 + nb); sd.tgtStride = n;
-  std::vector<TrsmTask> tt; for (int r = 0; r < pd.rowsBelow; r += kTile) tt.push_back({0, r});
-  std::vector<UpdTask> ut;
-  for (int cT = 0; cT < sd.m; cT += kTile) for (int rT = cT; rT < pd.rowsBelow; rT += kTile) ut.push_back({0, rT, cT, 0});
-  std::vector<UpdTask> utA = ut; for (auto& t : utA) t.atomic = 1;
-  int32_t lp = 0;
-  SrcDesc* dsr; CK(hipMalloc(&dsr, sizeof sr)); CK(hipMemcpy(dsr, &sr, sizeof sr, hipMemcpyHostToDevice));
-  PanelDesc* dpd; SegDesc* dsd; TrsmTask* dtt; UpdTask* dut; UpdTask* dutA; int32_t* dlp;
+  // self-contained records, as DevPlan::upload builds them (hip_plan.h: TrsmTaskFat, UpdTaskWide)
+  std::vector<TrsmTaskFat> tt;
+  for (int r = 0; r < pd.rowsBelow; r += kTile) tt.push_back(TrsmTaskFat{pd.diagOff, pd.lda, pd.nb, pd.rowsBelow, r, 0, 0});
+  std::vector<UpdTaskWide> ut;
+  for (int cT = 0; cT < sd.m; cT += kTile) {
+    for (int rT = cT; rT < pd.rowsBelow; rT += kTile) {
+      UpdTaskWide w{};
+      w.srcOff = sr.off; w.tgtBase = sd.tgtBase; w.chainTabPtr = 0;
+      w.lda = sr.lda; w.K = sr.K; w.rowsBelow = sr.rowsBelow; w.nRest = sr.nRest;
+      w.lumpRowBase = 0; w.kind = kSegIntra; w.segEnd = sd.q0 + sd.m; w.tgtStride = sd.tgtStride;
+      w.firstChainOrd = 0; w.rowMin = 0; w.rowTile = rT; w.colTile = cT; w.atomic = 0;
+      ut.push_back(w);
+    }
+  }
+  std::vector<UpdTaskWide> utA = ut; for (auto& t : utA) t.atomic = 1;
+  PanelDesc* dpd; TrsmTaskFat* dtt; UpdTaskWide* dut; UpdTaskWide* dutA;
   CK(hipMalloc(&dpd, sizeof pd)); CK(hipMemcpy(dpd, &pd, sizeof pd, hipMemcpyHostToDevice));
-  CK(hipMalloc(&dsd, sizeof sd)); CK(hipMemcpy(dsd, &sd, sizeof sd, hipMemcpyHostToDevice));
-  CK(hipMalloc(&dtt, tt.size() * sizeof(TrsmTask))); CK(hipMemcpy(dtt, tt.data(), tt.size() * sizeof(TrsmTask), hipMemcpyHostToDevice));
-  CK(hipMalloc(&dut, ut.size() * sizeof(UpdTask))); CK(hipMemcpy(dut, ut.data(), ut.size() * sizeof(UpdTask), hipMemcpyHostToDevice));
-  CK(hipMalloc(&dutA, ut.size() * sizeof(UpdTask))); CK(hipMemcpy(dutA, utA.data(), ut.size() * sizeof(UpdTask), hipMemcpyHostToDevice));
-  CK(hipMalloc(&dlp, 4)); CK(hipMemcpy(dlp, &lp, 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dtt, tt.size() * sizeof(TrsmTaskFat))); CK(hipMemcpy(dtt, tt.data(), tt.size() * sizeof(TrsmTaskFat), hipMemcpyHostToDevice));
+  CK(hipMalloc(&dut, ut.size() * sizeof(UpdTaskWide))); CK(hipMemcpy(dut, ut.data(), ut.size() * sizeof(UpdTaskWide), hipMemcpyHostToDevice));
+  CK(hipMalloc(&dutA, ut.size() * sizeof(UpdTaskWide))); CK(hipMemcpy(dutA, utA.data(), ut.size() * sizeof(UpdTaskWide), hipMemcpyHostToDevice));
   hipk::DataRef<double> ref{d, nullptr};
 
   printf("n=%d panel at %d: rowsBelow=%d trsmTasks=%zu updTasks=%zu\n", n, c0, pd.rowsBelow, tt.size(), ut.size());
   float us;
-  us = timeIt([&] { hipk::potrfPanel<double><<<1, 256>>>(dpd, dlp, ref); }, 50);
+  us = timeIt([&] { hipk::potrfPanel<double><<<1, 256>>>(dpd, ref); }, 50);
   printf("potrfPanel        : %8.1f us\n", us);
   { long long st[16]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(hipk::bspDebugStamps), sizeof st));
     printf("   potrf cycles: load %lld, loop %lld, store %lld (total %lld = %.1f us @2.4GHz)\n", st[1]-st[0], st[2]-st[1], st[3]-st[2], st[3]-st[0], (st[3]-st[0])/2400.0); }
   us = timeIt([&] { emptyKernel<<<1, 256>>>(); }, 200);
   printf("empty kernel      : %8.1f us\n", us);
-  us = timeIt([&] { hipk::trsmPanel<double><<<(unsigned)tt.size(), 256>>>(dpd, dtt, ref); }, 50);
+  us = timeIt([&] { hipk::trsmPanel<double><<<(unsigned)tt.size(), 256>>>(dtt, ref); }, 50);
   printf("trsmPanel         : %8.1f us  (%zu tasks)\n", us, tt.size());
   { long long st[16]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(hipk::bspDebugStamps), sizeof st));
     printf("   trsm cycles (block 0): stage L %lld, rows %lld (total %.1f us)\n", st[5]-st[4], st[6]-st[5], (st[6]-st[4])/2400.0); }
   double updFlops = 0; { double R = pd.rowsBelow, m = sd.m; updFlops = 2.0 * K * (m * R - m * (m - 1) / 2); }
-  us = timeIt([&] { hipk::updateTile<double><<<(unsigned)ut.size(), 256>>>(dsr, dsd, dut, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
+  us = timeIt([&] { hipk::updateTile<double, false><<<(unsigned)ut.size(), 256>>>(dut, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
   printf("updateTile plain  : %8.1f us  -> %.2f TF/s\n", us, updFlops / us / 1e6);
-  us = timeIt([&] { hipk::updateTile<double><<<(unsigned)ut.size(), 256>>>(dsr, dsd, dutA, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
+  us = timeIt([&] { hipk::updateTile<double, false><<<(unsigned)ut.size(), 256>>>(dutA, nullptr, nullptr, nullptr, nullptr, ref); }, 20);
   printf("updateTile atomic : %8.1f us  -> %.2f TF/s\n", us, updFlops / us / 1e6);
   CK(hipDeviceSynchronize());
   return 0;
