@@ -15,11 +15,14 @@ then damp(0, 1.2*order) (1.3 for batches), warm-up factors, timed factors on dev
   Extra workloads measured in the same run and reported inside the same JSON line: "batched" =
   BASELINE configs[3] (64 x GRID 82x82 x 3, one batched factor() per step) and "c5" = BAL-1723
   shaped fp32 factor + fp64 iterative refinement (configs[4]).
---gpus N > 1 (torchrun, one process per GPU): the batched config of BASELINE's metric ("batch
-  throughput at 1/2/4/8 GPUs"): rank 0 runs the symbolic analysis, broadcasts the flat plan over
-  RCCL, the 64 matrices are sharded contiguously (no collective inside a factorisation);
-  "scaling": "strong" (total work fixed).  "bal871_replicas" (one BAL-871 matrix per GPU, weak)
-  and "batched_1gpu" (rank 0 alone factoring all 64: the 1-GPU point of the same curve) ride along.
+--gpus N > 1 (torchrun, one process per GPU; or plain `python bench.py --gpus N`, which spawns its
+  ranks): the SAME headline metric, one BAL-871 matrix per GPU -- a single factorisation is not
+  sharded (no exchange step: replicas), "scaling": "weak", value = N matrices' flops / max-over-ranks
+  time.  The batched config of BASELINE's metric ("batch throughput at 1/2/4/8 GPUs") rides along in
+  "batched" at every N: rank 0 runs the symbolic analysis, broadcasts the flat plan over RCCL, the 64
+  matrices are sharded contiguously (no collective inside a factorisation), "scaling": "strong";
+  "batched_1gpu" = rank 0 alone factoring all 64 in the same job (the 1-GPU point of that curve).
+  `--workload grid82 --batch 64` makes the batched config the headline line instead.
 
 Prints ONE JSON line on rank 0.
 """
@@ -714,11 +717,11 @@ def main():
     if args.suite == "ref":
         return suite_ref(args, device)
 
-    workload = args.workload or ("bal871" if world == 1 else "grid82")
-    if args.batch is None:
-        batch = 64 if (workload == "grid82" and world > 1) else 0
-    else:
-        batch = args.batch
+    # the headline line is the SAME metric at every N: BAL-871, one matrix per GPU (a single
+    # factorisation is not sharded: replicas, weak scaling); the batched config rides along in
+    # "batched" at every N (64 matrices sharded over the N GPUs: strong scaling)
+    workload = args.workload or "bal871"
+    batch = 0 if args.batch is None else args.batch
     batched = batch > 0
     total_batch = batch if batched else world
 
@@ -821,10 +824,12 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     out["comparators"] = {"error": repr(e)[:200]}
             else:
-                r = Runner(ctx, "bal871", world, False)
+                r = Runner(ctx, "grid82", 64, True)   # (collective: plan broadcast, every rank its shard)
                 e = r.run(3, 1)
-                e.update({"workload": "BAL-871 stand-in, one matrix per GPU", "scaling": "weak"})
-                out["bal871_replicas"] = e
+                e.update({"workload": "64 x GRID 82x82 conn 2 x 3 (BASELINE configs[3]) sharded over %d GPUs, "
+                                      "plan broadcast over RCCL, one batched factor() per rank and step" % world,
+                          "n_gpus": world, "scaling": "strong"})
+                out["batched"] = e
                 del r
                 torch.cuda.empty_cache()
                 if rank == 0:   # the 1-GPU point of the batched curve, measured in this very job
