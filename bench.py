@@ -634,7 +634,7 @@ def spawn_ranks(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get("BSP_BENCH_SHARE_GPU") != "1":
         print("bench.py: --gpus %d but only %d GPU(s) visible" % (n, have), file=sys.stderr)
         return 2
     # The rendezvous port is picked by binding port 0 and closing the socket (rank 0's store has to
@@ -703,13 +703,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    # BSP_BENCH_SHARE_GPU=1 (TESTING the N > 1 control flow on a one-GPU box): every rank on GPU 0,
+    # gloo instead of RCCL -- the timings mean nothing, the line's structure and the collectives'
+    # order are what such a run checks
+    share_gpu = os.environ.get("BSP_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (under torchrun use --nproc-per-node == "
                          "--gpus; without torchrun bench.py spawns its own ranks)" % (args.gpus, world))
