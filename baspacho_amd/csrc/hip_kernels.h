@@ -1451,9 +1451,6 @@ __global__ __launch_bounds__(256) void trsmPanelDirect(PanelDesc pd, DataRef<T> 
 #else
 #define UPD_STAMP(slot, val)
 #endif
-#ifndef BSP_BULK_PIPE
-#define BSP_BULK_PIPE 0
-#endif
 constexpr int kUpdChunk = 32;  // K chunk of updateTile: 2 x 64 x 34 doubles = 35 KB LDS -> 4 WG/CU
 // PREFETCH: the next K chunk is requested before the current one is multiplied.  For launches of
 // at most ~2 rounds of workgroups (small batches, the top of an elimination tree) a tile's time is
@@ -1761,49 +1758,25 @@ __device__ __forceinline__ void bulkTileBody(const UpdTaskFat& t, GP<T> data, T*
       yieldWhile(yieldFlag, myCu);
     }
     if (!skipUpper) {
-      // (row r, column k0 + lk): slot (k0 + lk) / E moves by k0 / E under the XOR key
-      auto rd = [&](int k0, T& a0, T& a1, T& b0, T& b1) {
+#pragma unroll
+      for (int k0 = 0; k0 < KC; k0 += 4) {
+        // (row r, column k0 + lk): slot (k0 + lk) / E moves by k0 / E under the XOR key.  (Reading
+        //  the operands of step s+1 before the MFMAs of step s -- two register sets, pinned with a
+        //  sched_barrier -- was measured slower: 4.02 against 3.8 ms for the serialised bulk.  Round 4
+        //  again, letting the compiler pipeline the unrolled loop -- reads one step ahead,
+        //  `s_waitcnt lgkmcnt(2)`, 86 registers: BAL-871 6.43-6.50 against 6.31-6.37 ms, FLAT-50k 27.27
+        //  against 26.86, profiles/r04_ab_bulk_pipelined_reads.txt.  A wave that never waits for its
+        //  own operands takes the matrix pipe from the waves whose chunk loads it should be hiding.)
         const int s = k0 / E;
-        a0 = As[oa0 + E * (((lk / E + s) ^ ka0) - ((lk / E) ^ ka0))];
-        a1 = As[oa1 + E * (((lk / E + s) ^ ka1) - ((lk / E) ^ ka1))];
-        b0 = Bt[ob0 + E * (((lk / E + s) ^ kb0) - ((lk / E) ^ kb0))];
-        b1 = Bt[ob1 + E * (((lk / E + s) ^ kb1) - ((lk / E) ^ kb1))];
-      };
-#if BSP_BULK_PIPE
-      // the operands of step s + 1 are requested right after the FIRST multiply of step s (order
-      // pinned: one MFMA, the LDS reads, three MFMAs), so that a wave's own reads are covered by
-      // its own multiplies instead of by the other waves of the SIMD
-      T ca0, ca1, cb0, cb1;
-      rd(0, ca0, ca1, cb0, cb1);
-#pragma unroll
-      for (int k0 = 0; k0 < KC; k0 += 4) {
-        T na0 = ca0, na1 = ca1, nb0 = cb0, nb1 = cb1;
-        acc00 = Mfma<T>::run(ca0, cb0, acc00);
-        if (k0 + 4 < KC) rd(k0 + 4, na0, na1, nb0, nb1);
-        acc01 = Mfma<T>::run(ca0, cb1, acc01);
-        acc10 = Mfma<T>::run(ca1, cb0, acc10);
-        acc11 = Mfma<T>::run(ca1, cb1, acc11);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        ca0 = na0;
-        ca1 = na1;
-        cb0 = nb0;
-        cb1 = nb1;
-      }
-#else
-#pragma unroll
-      for (int k0 = 0; k0 < KC; k0 += 4) {
-        // (Reading the operands of step s+1 before the MFMAs of step s -- two register sets, pinned
-        //  with a sched_barrier -- was measured slower: 4.02 against 3.8 ms for the serialised bulk.)
-        T a0, a1, b0, b1;
-        rd(k0, a0, a1, b0, b1);
+        const T a0 = As[oa0 + E * (((lk / E + s) ^ ka0) - ((lk / E) ^ ka0))];
+        const T a1 = As[oa1 + E * (((lk / E + s) ^ ka1) - ((lk / E) ^ ka1))];
+        const T b0 = Bt[ob0 + E * (((lk / E + s) ^ kb0) - ((lk / E) ^ kb0))];
+        const T b1 = Bt[ob1 + E * (((lk / E + s) ^ kb1) - ((lk / E) ^ kb1))];
         acc00 = Mfma<T>::run(a0, b0, acc00);
         acc01 = Mfma<T>::run(a0, b1, acc01);
         acc10 = Mfma<T>::run(a1, b0, acc10);
         acc11 = Mfma<T>::run(a1, b1, acc11);
       }
-#endif
     }
   }
   if (!skipUpper) {
