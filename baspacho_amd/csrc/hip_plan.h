@@ -176,7 +176,7 @@ constexpr int kGatherMaxElems = 256;   // rows*cols handled per wave (4 per lane
 // targets) took 256 round trips ~ 0.5 ms and whatever was left of them when the rest of the grid had
 // drained WAS the kernel's tail: BAL-871 1.73 ms at 2048, 1.49 at 512, 1.43 at 128, 1.42 at 64
 // (BSP_GATHER_MAX_PAIRS overrides; 2048+ restores the atomic-free, deterministic form).
-constexpr int kGatherMaxPairs = 128;  // default of HipPlanOptions::gatherMaxPairs
+constexpr int kGatherMaxPairs = 64;  // default of HipPlanOptions::gatherMaxPairs (round 4: 128 -> 64, -0.05 ms on BAL-871)
 constexpr uint32_t kGatherChunkElems = 0xffffffffu;  // optional slicing of the source columns into
                                                      // cache-sized passes: measured 2x SLOWER on
                                                      // BAL-871 (more items + atomics), so disabled
@@ -218,8 +218,8 @@ struct HipPlanOptions {
   bool dropElimUpdate = false; // FAULT INJECTION for the parity tests (bsp_test_set_fault, never read
                                // from the environment): the sparse-elimination update is not launched,
                                // so the factor is wrong and the full-size checks must notice
-  int32_t gatherMaxPairs = 128;  // BSP_GATHER_MAX_PAIRS
-  double bulkAhead = 0.6;     // BSP_BULK_AHEAD
+  int32_t gatherMaxPairs = kGatherMaxPairs;  // BSP_GATHER_MAX_PAIRS
+  double bulkAhead = 0.8;     // BSP_BULK_AHEAD (round 4: 0.6 -> 0.8, -0.04 ms on BAL-871; profiles/r04_ab_plan_knobs.txt)
   static HipPlanOptions fromEnv();
 };
 
