@@ -214,7 +214,10 @@ constexpr int kTinyPerWave = 4;
 // the scratch (heavy-tail points seen by dozens of cameras) takes the direct path lump by lump.
 template <typename T>
 using LP = __attribute__((address_space(3))) T*;
-constexpr int kStagedCap = 1024;  // scratch values per wave (8 KB fp64; 32 KB per workgroup)
+// (round 4, BAL-871, kernel time by cap: 640 0.316 ms, 768 0.310, 896 0.320, 1024 0.335, 1280 0.305,
+//  1536 0.339, 2048 0.40 -- profiles/r04_ab_elim_factor_staged_cap.txt: fewer stretches fall back to
+//  the direct path as the cap grows, fewer workgroups fit a CU)
+constexpr int kStagedCap = 1280;  // scratch values per wave (10 KB fp64; 40 KB per workgroup)
 
 // one lump of width n <= 4 by 16 lanes (sub = 0..15): Cholesky of the diagonal block at D, rows
 // below it (at D + n * n) solved against it; P: global or LDS pointer
