@@ -74,8 +74,7 @@ struct DevPlan {
   // range's bigLevels): the entries die with the plan, an address is never reused under them
   std::map<const void*, SolveInvList> solveInvLists;
   DevBuf panels, levelPanelDescs, trsmTasksFat, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
-      updTasksFat, updTasksWide, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc,
-      levelTileTasks;
+      updTasksFat, updTasksWide, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc;
   int64_t numUpdTasks = 0;
   vector<int64_t> slowPrefix;  // tasks [0, i) that updateTileBulk cannot take
   // forward-solve gather lists, built on the first solve that needs them
@@ -109,73 +108,12 @@ struct DevPlan {
       vector<PanelDesc> lp(host.levelPanels.size());
       for (size_t i = 0; i < lp.size(); i++) lp[i] = host.panels[host.levelPanels[i]];
       levelPanelDescs.upload(lp);
-      // position of every panel inside its level (fused levels: slot of the level's scratch that
-      // holds the panel's inverted diagonal blocks)
-      vector<int32_t> slotOfPanel(host.panels.size(), 0);
-      auto eachLevelList = [&](auto&& fn) {
-        for (auto& er : host.elimRanges) fn(er.bigLevels);
-        fn(host.levels);
-      };
-      eachLevelList([&](vector<LevelRange>& levels) {
-        for (const LevelRange& lr : levels) {
-          for (int64_t k = lr.panelBegin; k < lr.panelEnd; k++) {
-            slotOfPanel[host.levelPanels[k]] = (int32_t)(k - lr.panelBegin);
-          }
-        }
-      });
       vector<TrsmTaskFat> tf(host.trsmTasks.size());
       for (size_t i = 0; i < tf.size(); i++) {
         const PanelDesc& pd = host.panels[host.trsmTasks[i].panel];
-        tf[i] = TrsmTaskFat{pd.diagOff, pd.lda, pd.nb, pd.rowsBelow, host.trsmTasks[i].rowTile,
-                            slotOfPanel[host.trsmTasks[i].panel], 0};
+        tf[i] = TrsmTaskFat{pd.diagOff, pd.lda, pd.nb, pd.rowsBelow, host.trsmTasks[i].rowTile, 0, 0};
       }
       trsmTasksFat.upload(tf);
-      // FUSED LEVELS (levelTrsmUpdate, hip_kernels.h): self-contained tile records, and per level
-      // whether every tile of it can take that kernel
-      if (host.segPanel.size() == host.segs.size() && !host.segs.empty()) {
-        vector<LevelTileTask> lt(host.updTasks.size());
-        for (size_t i = 0; i < host.updTasks.size(); i++) {
-          const UpdTask& t = host.updTasks[i];
-          const SegDesc& sd = host.segs[t.seg];
-          const SrcDesc& sr = host.srcs[sd.src];
-          const int32_t p = host.segPanel[t.seg];
-          const PanelDesc& pd = host.panels[p];
-          LevelTileTask& f = lt[i];
-          std::memset(&f, 0, sizeof(f));
-          f.srcOff = sr.off;
-          f.tgtBase = sd.tgtBase;
-          f.chainTabPtr = sd.chainTabPtr;
-          f.diagOff = pd.diagOff;
-          f.lda = sr.lda;
-          f.nb = pd.nb;
-          f.rowsBelow = sr.rowsBelow;
-          f.nRest = sr.nRest;
-          f.lumpRowBase = sr.lumpRowBase;
-          f.kind = sd.kind;
-          f.segEnd = sd.q0 + sd.m;
-          f.tgtStride = sd.tgtStride;
-          f.firstChainOrd = sd.firstChainOrd;
-          f.rowMin = sd.rowMin;
-          f.rowTile = t.rowTile;
-          f.colTile = t.colTile;
-          f.atomic = t.atomic;
-          f.kMem = sr.K - pd.nb;
-          f.slot = slotOfPanel[p];
-          // the source ends with the panel's own columns: the panel itself, or the outer block it closes
-          f.ok = f.kMem >= 0 && f.kMem % kTile == 0 && sr.lda == pd.lda &&
-                 sr.rowsBelow == pd.rowsBelow &&
-                 sr.off + f.kMem == pd.diagOff + (int64_t)pd.nb * pd.lda;
-        }
-        levelTileTasks.upload(lt);
-        eachLevelList([&](vector<LevelRange>& levels) {
-          for (LevelRange& lr : levels) {
-            bool ok = lr.directPanel < 0 && lr.panelEnd > lr.panelBegin && lr.defEnd == lr.defBegin &&
-                      lr.waitDefLevel < 0 && lr.optWaitLevel < 0;
-            for (int64_t i = lr.updBegin; ok && i < lr.updEnd; i++) ok = lt[i].ok != 0;
-            lr.fusable = ok ? 1 : 0;
-          }
-        });
-      }
     }
     {
       vector<UpdTaskFat> fat(host.updTasks.size());
@@ -425,7 +363,6 @@ struct HipSymbolicCtx : SymbolicCtx {
     // and recorded in the plan; launchLevels takes dueStream from the plan it runs
     planOpts = HipPlanOptions::fromEnv();
     if (const char* e = std::getenv("BSP_LOOKAHEAD_MIN_GF")) lookaheadMinFlops = 1e9 * std::atof(e);
-    if (const char* e = std::getenv("BSP_LEVEL_FUSE_MAX_WGS")) levelFuseMaxWgs = std::atoll(e);
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -652,14 +589,6 @@ struct HipSymbolicCtx : SymbolicCtx {
   // destroyed around every factor() / solve(), Solver.cpp:176,223, while their kernels may still be
   // queued): sized on first use, only ever grown
   DevBuf dinvScratch, rawScratch, yieldBuf;
-  // fused levels (levelTrsmUpdate): inverted diagonal blocks of the panels of a level, two level
-  // slots (the solved rows of a level are stored by the NEXT level's potrf launch)
-  DevBuf levelDinvScratch;
-  // a multi-panel level takes the fused form when its update launch holds at most this many
-  // workgroups (tiles x batch): below it a level is a chain of dependent round trips and the saved
-  // launch + the solved panel's round trip through memory pay; above it the level is bound by
-  // throughput, where the plain tile kernel keeps four workgroups per CU (BSP_LEVEL_FUSE_MAX_WGS; 0: never)
-  int64_t levelFuseMaxWgs = 4096;
   // block solves through inverted diagonal blocks (denseLevels): the inverses of one solve call, and
   // per level list the panels whose diagonal blocks are inverted (uploaded once)
   DevBuf solveInvScratch;
@@ -769,63 +698,10 @@ struct HipNumericCtx : NumericCtx<T> {
     // applies the rest from memory
     int extraApplied = 0;
     bool extraBroken = false;
-    // FUSED LEVELS: which levels of this list take the two-launch form, and their scratch
-    vector<char> fusedLevel(levels.size(), 0);
-    int64_t maxFusedPanels = 0;
-    for (size_t li = 0; li < levels.size(); li++) {
-      const LevelRange& lr = levels[li];
-      if (!lr.fusable || !plan.levelTileTasks.ptr) continue;
-      if ((lr.updEnd - lr.updBegin) * (int64_t)batchSize > sym.levelFuseMaxWgs) continue;
-      fusedLevel[li] = 1;
-      maxFusedPanels = std::max(maxFusedPanels, lr.panelEnd - lr.panelBegin);
-    }
-    const int64_t lvStride = maxFusedPanels * hipk::kDinvSlot;  // per matrix
-    BT* lvDinv[2] = {nullptr, nullptr};
-    if (maxFusedPanels > 0) {
-      sym.levelDinvScratch.resize((size_t)2 * batchSize * lvStride * sizeof(BT));
-      lvDinv[0] = const_cast<BT*>(sym.levelDinvScratch.as<BT>());
-      lvDinv[1] = lvDinv[0] + (size_t)batchSize * lvStride;
-    }
-    int lvParity = 0;
-    int64_t pendBegin = 0, pendCount = 0;  // rows of the previous fused level, not yet stored in place
-    int pendParity = 0;
     for (size_t li = 0; li < levels.size(); li++) {
       const LevelRange& lr = levels[li];
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
-      if (fusedLevel[li]) {
-        // A: potrf + inverses of this level's panels, and the in-place store of the previous
-        // fused level's solved rows; B: trsm + update of this level, tile by tile
-        timer.begin(kProfPotrf);
-        hipk::potrfPanelLevel<BT><<<dim3(nP + (unsigned)pendCount, gy.y), 256, 0, sym.stream>>>(
-            plan.levelPanelDescs.as<PanelDesc>() + lr.panelBegin, (int)nP, ref, lvDinv[lvParity], lvStride,
-            plan.trsmTasksFat.as<TrsmTaskFat>() + pendBegin, lvDinv[pendParity]);
-        timer.end();
-        pendCount = 0;
-        if (lr.updEnd > lr.updBegin) {
-          timer.begin(kProfUpdate);
-          hipk::levelTrsmUpdate<BT><<<dim3((unsigned)(lr.updEnd - lr.updBegin), gy.y), 256, 0, sym.stream>>>(
-              plan.levelTileTasks.as<LevelTileTask>() + lr.updBegin, plan.chainOffTab.as<int64_t>(),
-              plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(), plan.rowColOff.as<int32_t>(), ref,
-              lvDinv[lvParity], lvStride, 1);
-          timer.end();
-        }
-        pendBegin = lr.trsmBegin;
-        pendCount = nT;
-        pendParity = lvParity;
-        lvParity ^= 1;
-        if (pendCount > 0 && !(li + 1 < levels.size() && fusedLevel[li + 1])) {
-          // what follows may read the solved rows from memory: store them now
-          timer.begin(kProfTrsm);
-          hipk::potrfPanelLevel<BT><<<dim3((unsigned)pendCount, gy.y), 256, 0, sym.stream>>>(
-              nullptr, 0, ref, nullptr, lvStride, plan.trsmTasksFat.as<TrsmTaskFat>() + pendBegin,
-              lvDinv[pendParity]);
-          timer.end();
-          pendCount = 0;
-        }
-        rawValid = false;
-        continue;
-      }
       const bool direct = lr.directPanel >= 0;
       const int slot = dinvSlot;
       dinvSlot ^= 1;

@@ -2104,18 +2104,6 @@ struct ChainTile {
     if (!diagTile) trsmLoadRows<T>(rawIn + (int64_t)(actJ ? rj : 0) * kTile, kTile, lane, xj);
     trsmLoadOps<T>(Lkk, dinv, lda, nb, lane, o);
   }
-  // rows straight from the matrix (row stride rawLd, nb columns) instead of the staging buffer
-  __device__ __forceinline__ void loadStrided(GP<const T> rows, int rawLd, GP<const T> Lkk,
-                                              GP<const T> dinv, int lda, int nb, int ri, int rj,
-                                              int rowsBelow, int segEnd, bool diag) {
-    const int lane = threadIdx.x & 63;
-    diagTile = diag;
-    actI = ri < rowsBelow;
-    actJ = rj < segEnd;
-    trsmLoadRows<T>(rows + (int64_t)(actI ? ri : 0) * rawLd, nb, lane, xi);
-    if (!diagTile) trsmLoadRows<T>(rows + (int64_t)(actJ ? rj : 0) * rawLd, nb, lane, xj);
-    trsmLoadOps<T>(Lkk, dinv, lda, nb, lane, o);
-  }
   __device__ __forceinline__ void solve(int nb, T* XB, GP<T> storeRow /* or null */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
     trsmMaskRows<T>(actI, nb, lane, xi);
@@ -2338,135 +2326,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   BSP_STAMP_TILE(7);
   BSP_EXTENT_END(traceId, false);
-}
-
-// ------------------------------------------------------------------------------------------
-// K7  FUSED LEVEL (round 5): the chain's "trsm inside the update tiles" (K6) for levels that hold
-// SEVERAL panels -- the bottom and the middle of an elimination tree, where a level used to be three
-// dependent launches (potrfPanel -> trsmPanel -> updateTile, ~39 us on GRID 82x82 whatever the
-// level holds) and is two now:
-//   A  potrfPanelLevel   one workgroup per panel: Cholesky of the diagonal block + the inverses of
-//                        its 16 x 16 diagonal blocks into the level's scratch slot (as the chain's
-//                        potrf does), PLUS one workgroup per 64-row tile of the PREVIOUS fused
-//                        level's panels that solves those rows and stores them in place;
-//   B  levelTrsmUpdate   one workgroup per update tile (i, j): solves its own copies of the panel
-//                        rows it needs, X_i and X_j, straight from the matrix (register-only MFMA
-//                        trsm, 2 x 40 MFMAs per wave), multiplies and scatters through the board
-//                        tables -- the tile product of updateTile without the round trip of the
-//                        solved panel through memory and without the launch boundary in front of it.
-// B never stores a solved row: other workgroups of the launch still read those rows unsolved, and
-// which tile would be the last reader is not known.  The in-place store is A's second job, one
-// launch later, when nobody reads the unsolved rows any more (the solve is repeated there: 40
-// MFMAs per wave beside the next level's potrf, off the critical path).  The last fused level of a
-// run is flushed by a launch of A without panels.  Tiles of a panel that closes an outer block of
-// several panels take the block's leading source columns from memory (final: stored by earlier A
-// launches) exactly as the chain's block-last step does (ChainTile::multiplyMem).
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void potrfPanelLevel(const PanelDesc* levelPanelDescs, int nPanels,
-                                                       DataRef<T> dref, T* dinvOut,
-                                                       int64_t dinvBatchStride,
-                                                       const TrsmTaskFat* prevTasks,
-                                                       const T* dinvPrev) {
-  __shared__ T blk[8 * kPanelWidth][4];
-  __shared__ T Ld[kPanelWidth * kInvLd];
-  GP<T> data = pickData(dref);
-  if ((int)blockIdx.x >= nPanels) {
-    // rows of a panel of the previous fused level: solve and store in place (pad0 = its slot)
-    const TrsmTaskFat t = prevTasks[blockIdx.x - nPanels];
-    GP<T> P = data + t.diagOff + (int64_t)(t.nb + t.rowTile) * t.lda;
-    trsmTileRegs<T>(data + t.diagOff,
-                    (GP<const T>)dinvPrev + (size_t)blockIdx.y * dinvBatchStride + (size_t)t.pad0 * kDinvSlot,
-                    P, t.lda, t.nb, min(kTile, t.rowsBelow - t.rowTile));
-    return;
-  }
-  T(*sol)[4] = blk + 3 * kPanelWidth;
-  const PanelDesc pd = levelPanelDescs[blockIdx.x];
-  potrfPanelTiles<T>(data + pd.diagOff, pd.nb, pd.lda, blk, sol, &blk[4 * kPanelWidth][0], NoPreUpdate(), Ld,
-                     (GP<T>)dinvOut + (size_t)blockIdx.y * dinvBatchStride + (size_t)blockIdx.x * kDinvSlot);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void levelTrsmUpdate(
-    const LevelTileTask* tasks, const int64_t* chainOffTab, const int32_t* rowChain,
-    const int32_t* rowLocal, const int32_t* rowColOff, DataRef<T> dref, const T* dinvBase,
-    int64_t dinvBatchStride, int atomicMask) {
-  __shared__ T XB[kTile * kXbLd];
-  __shared__ int64_t rowBase[kTile];
-  __shared__ int32_t colOff[kTile];
-  using Acc = typename Mfma<T>::Acc;
-  const LevelTileTask t = tasks[blockIdx.x];
-  GP<T> data = pickData(dref);
-  GP<const T> dinv = (GP<const T>)dinvBase + (size_t)blockIdx.y * dinvBatchStride + (size_t)t.slot * kDinvSlot;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15;
-  const int nb = t.nb, lda = t.lda, rowsBelow = t.rowsBelow, segEnd = t.segEnd;
-  const int rowTile = t.rowTile, colTile = t.colTile;
-  const bool diag = rowTile == colTile;
-  GP<const T> Lkk = data + t.diagOff;
-  GP<const T> P = data + t.srcOff + t.kMem;  // the panel's rows below its diagonal block, unsolved
-  // per-row / per-column target addressing of this tile (as updateTile)
-  if (tid < kTile) {
-    const int q = rowTile + tid;
-    int64_t base = 0;
-    if (q < rowsBelow) {
-      if (t.kind == kSegIntra) {
-        base = t.tgtBase + (int64_t)q * t.tgtStride;
-      } else {
-        const int rr = t.lumpRowBase + (q - t.nRest);
-        base = chainOffTab[t.chainTabPtr + (rowChain[rr] - t.firstChainOrd)] +
-               (int64_t)rowLocal[rr] * t.tgtStride;
-      }
-    }
-    rowBase[tid] = base;
-  } else if (tid < 2 * kTile) {
-    const int cidx = tid - kTile;
-    const int q = colTile + cidx;
-    int32_t off = 0;
-    if (q < segEnd) off = t.kind == kSegIntra ? q : rowColOff[t.lumpRowBase + (q - t.nRest)];
-    colOff[cidx] = off;
-  }
-  const int ri = rowTile + 16 * w + n, rj = colTile + 16 * w + n;
-  Acc D[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-  if (t.kMem > 0) {
-    ChainTile<T>::multiplyMem(data + t.srcOff, lda, t.kMem, rowTile, colTile, rowsBelow, segEnd, diag,
-                              XB, D);
-  }
-  ChainTile<T> ct;
-  ct.loadStrided(P, lda, Lkk, dinv, lda, nb, ri, rj, rowsBelow, segEnd, diag);
-  ct.solve(nb, XB, nullptr);  // (ends with a barrier: the tables above are visible too)
-  const bool atomicTile = (t.atomic & atomicMask) != 0;
-  T old[16];
-  if (!atomicTile) {
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int32_t co = colOff[16 * c + n];
-#pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        // (masked-off entries point at valid memory)
-        old[c * 4 + reg] = *(data + rowBase[16 * w + Mfma<T>::row(lane, reg)] + co);
-      }
-    }
-  }
-  ct.multiply(XB, D);
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const int cIn = 16 * c + n;
-    const int qc = colTile + cIn;
-    const int32_t co = colOff[cIn];
-#pragma unroll
-    for (int reg = 0; reg < 4; reg++) {
-      const int rIn = 16 * w + Mfma<T>::row(lane, reg);
-      const int qr = rowTile + rIn;
-      if (qc < segEnd && qr < rowsBelow && qr >= qc && qr >= t.rowMin) {
-        GP<T> ptr = data + rowBase[rIn] + co;
-        if (atomicTile) {
-          atomicSub(ptr, D[c][reg]);
-        } else {
-          *ptr = old[c * 4 + reg] - D[c][reg];
-        }
-      }
-    }
-  }
 }
 
 // (A 128x128-tile variant of K5 -- 4x4 MFMA tiles per wave, 70 KB LDS, 2 workgroups per CU -- was

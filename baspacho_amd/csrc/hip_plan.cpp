@@ -446,7 +446,6 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
           }
         }
         panelSegEnd.push_back((int64_t)plan.segs.size());
-        plan.segPanel.resize(plan.segs.size(), (int32_t)plan.panels.size() - 1);
       }
     }
     return count;

@@ -115,25 +115,6 @@ struct TrsmTaskFat {
 };
 static_assert(sizeof(TrsmTaskFat) == 32, "one scalar load");
 
-// FUSED LEVEL (round 5): one tile of a multi-panel level whose trsm runs INSIDE the update launch
-// (levelTrsmUpdate, hip_kernels.h): the fields of UpdTaskWide plus what the tile needs to solve its
-// own copies of the panel rows -- the panel's diagonal block, its width, and the slot of the level's
-// scratch that holds the inverted 16 x 16 diagonal blocks written by the level's potrf launch.
-// The source of a tile is either the panel itself (kMem = 0) or the complete outer block the panel
-// closes (kMem = block width - nb leading source columns, final in memory).  Built at upload time.
-struct LevelTileTask {
-  int64_t srcOff;       // SrcDesc::off: (first row below, first source column)
-  int64_t tgtBase;      // SegDesc::tgtBase
-  int64_t chainTabPtr;  // SegDesc::chainTabPtr
-  int64_t diagOff;      // PanelDesc::diagOff
-  int32_t lda, nb, rowsBelow, nRest;                // SrcDesc (nb: the panel's width)
-  int32_t lumpRowBase, kind, segEnd, tgtStride;     // SrcDesc / SegDesc (segEnd = q0 + m)
-  int32_t firstChainOrd, rowMin, rowTile, colTile;  // SegDesc / UpdTask
-  int32_t atomic, kMem, slot, ok;  // slot: panel's position in its level; ok = 0: not eligible
-  int32_t pad[8];
-};
-static_assert(sizeof(LevelTileTask) == 128, "two 64-byte scalar loads");
-
 struct LevelRange {
   int64_t panelBegin, panelEnd;  // into levelPanels
   int64_t trsmBegin, trsmEnd;    // into trsmTasks
@@ -171,10 +152,6 @@ struct LevelRange {
   // due-stream mode: level whose OPTIONAL lookahead units (forked two outer blocks earlier: plain
   // read-modify-write on far columns) must be complete before this level's due units start; -1
   int64_t optWaitLevel = -1;
-  // FUSED LEVEL (set when the plan is uploaded): a level of several panels without lookahead units
-  // whose every update tile can solve its own panel rows (levelTrsmUpdate): potrf + inverses, then
-  // ONE launch for trsm and update, the in-place store of the solved rows one launch later
-  int32_t fusable = 0;
 };
 
 // One work item of the gather-form sparse-elimination update: a target block (sj,si) of the
@@ -258,7 +235,6 @@ struct HipPlanHost {
   std::vector<PanelDesc> panels;
   std::vector<SrcDesc> srcs;
   std::vector<SegDesc> segs;
-  std::vector<int32_t> segPanel;  // panel that owns each segment (buildHipPlan only; fused levels)
   std::vector<int64_t> chainOffTab;
   std::vector<int32_t> rowChain, rowLocal, rowColOff;  // per chain row of every dense lump
   std::vector<int32_t> rowGlobal;                      // ... and its row index in the full matrix
