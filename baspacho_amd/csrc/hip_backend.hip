@@ -1228,9 +1228,23 @@ struct HipSolveCtx : SolveCtx<T> {
       if (BACKWARD) {
         if (er.maxWidth <= 4) {
           const int64_t d0 = plan.solveGather.rangeLumpDesc[&er - plan.host.elimRanges.data()];
-          hipk::solveElimLumpsLt<BT><<<grid((unsigned)((nLumps + 15) / 16)), 256, 0, sym.stream>>>(
-              plan.solveLumpDescs.as<SolveLumpDesc>() + d0, plan.solveLumpBlocks.as<SolveLumpBlock>(),
-              ref, (int)nLumps);
+          // (several right-hand sides per workgroup: the blocks of L are fetched once per group)
+          auto launch = [&](auto kern, int rb) {
+            kern<<<dim3((unsigned)((nLumps + 15) / 16), (unsigned)((nRHS + rb - 1) / rb), (unsigned)batch),
+                   256, 0, sym.stream>>>(plan.solveLumpDescs.as<SolveLumpDesc>() + d0,
+                                         plan.solveLumpBlocks.as<SolveLumpBlock>(), ref, (int)nLumps, nRHS);
+          };
+          if (nRHS == 1) {
+            hipk::solveElimLumpsLt<BT><<<grid((unsigned)((nLumps + 15) / 16)), 256, 0, sym.stream>>>(
+                plan.solveLumpDescs.as<SolveLumpDesc>() + d0, plan.solveLumpBlocks.as<SolveLumpBlock>(),
+                ref, (int)nLumps);
+          } else if (nRHS <= 2) {
+            launch(hipk::solveElimLumpsLtMulti<BT, 2>, 2);
+          } else if (nRHS <= 4) {
+            launch(hipk::solveElimLumpsLtMulti<BT, 4>, 4);
+          } else {
+            launch(hipk::solveElimLumpsLtMulti<BT, 8>, 8);
+          }
         } else {
           hipk::solveElimSmall<BT, true><<<gL, 256, 0, sym.stream>>>(sk, ref, er.lumpBegin,
                                                                     er.lumpEnd);
@@ -1238,12 +1252,15 @@ struct HipSolveCtx : SolveCtx<T> {
         return;
       }
       const auto items = plan.solveGather.rangeItems[&er - plan.host.elimRanges.data()];
-      hipk::solveElimDiagL<BT><<<gL, 256, 0, sym.stream>>>(sk, ref, er.lumpBegin, er.lumpEnd);
+      // (every right-hand side in the thread / 16 right-hand sides per workgroup: L is read once)
+      hipk::solveElimDiagL<BT><<<dim3((unsigned)((nLumps + 255) / 256), 1, (unsigned)batch), 256, 0,
+                                 sym.stream>>>(sk, ref, er.lumpBegin, er.lumpEnd, nRHS);
       if (items.second > items.first) {
-        hipk::solveElimGatherL<BT><<<grid((unsigned)(items.second - items.first)), 256, 0,
-                                     sym.stream>>>(
+        hipk::solveElimGatherL<BT><<<dim3((unsigned)(items.second - items.first),
+                                          (unsigned)((nRHS + 15) / 16), (unsigned)batch),
+                                     256, 0, sym.stream>>>(
             plan.solveItems.as<SolveGatherItem>() + items.first,
-            plan.solveEntries.as<SolveGatherEntry>(), ref);
+            plan.solveEntries.as<SolveGatherEntry>(), ref, nRHS);
       }
     };
     // lumps of a range are mutually independent: the order small/wide does not matter
@@ -1256,12 +1273,11 @@ struct HipSolveCtx : SolveCtx<T> {
     }
   }
 
-  template <bool BACKWARD>
-  void denseLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::SolveRef<BT> ref) {
+  // consecutive one-panel levels that make up one outer block of a wide lump are solved as a
+  // block: 2 launches per 256 columns instead of 8
+  vector<std::pair<int64_t, int64_t>> levelGroups(DevPlan& plan, const vector<LevelRange>& levels) {
     static_assert(hipk::kSolveBlock == kOuterWidth, "block solve steps = outer blocks of the plan");
     const int64_t nL = (int64_t)levels.size();
-    // consecutive one-panel levels that make up one outer block of a wide lump are solved as a
-    // block: 2 launches per 256 columns instead of 8
     vector<std::pair<int64_t, int64_t>> groups;
     for (int64_t l = 0; l < nL;) {
       int64_t e = l + 1;
@@ -1282,6 +1298,12 @@ struct HipSolveCtx : SolveCtx<T> {
       groups.emplace_back(l, e);
       l = e;
     }
+    return groups;
+  }
+
+  template <bool BACKWARD>
+  void denseLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::SolveRef<BT> ref) {
+    const vector<std::pair<int64_t, int64_t>> groups = levelGroups(plan, levels);
     const int64_t nG = (int64_t)groups.size();
     // round 3 (BSP_SOLVE_INV=0 disables): the block triangles through inverted 64 x 64 diagonal
     // blocks -- one launch inverts the diagonal block of every panel of every block group (the list

@@ -32,6 +32,12 @@ __device__ __forceinline__ GP<T> solveVec(const SolveRef<T>& r) {
   return (GP<T>)(r.vecs ? r.vecs[blockIdx.z] : r.vec) + (int64_t)blockIdx.y * r.ldc;
 }
 
+// right-hand side 0 of this batch entry (kernels that take several right-hand sides per workgroup)
+template <typename T>
+__device__ __forceinline__ GP<T> solveVecBase(const SolveRef<T>& r) {
+  return (GP<T>)(r.vecs ? r.vecs[blockIdx.z] : r.vec);
+}
+
 __device__ __forceinline__ double waveSum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -135,47 +141,84 @@ __global__ __launch_bounds__(256) void solveElimSmall(SkelDev sk, SolveRef<T> re
 }
 
 // ---- sparse-elimination ranges, forward pass in gather form --------------------------------
-// K-S1: x_l <- D^-1 x_l for the small lumps of a range (thread per lump)
+// K-S1: x_l <- D^-1 x_l for the small lumps of a range (thread per lump, every right-hand side: the
+// diagonal block is fetched from memory once, not once per right-hand side)
 template <typename T>
 __global__ __launch_bounds__(256) void solveElimDiagL(SkelDev sk, SolveRef<T> ref,
-                                                      int64_t lumpBegin, int64_t lumpEnd) {
+                                                      int64_t lumpBegin, int64_t lumpEnd, int nRhs) {
   const int64_t l = lumpBegin + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (l >= lumpEnd) return;
   const int n = (int)(sk.lumpStart[l + 1] - sk.lumpStart[l]);
   if (n > kElimSmallMax) return;
   GP<const T> D = solveMat(ref) + sk.chainData[sk.chainColPtr[l]];
-  GP<T> xl = solveVec(ref) + sk.lumpStart[l];
-  T x[kElimSmallMax];
-  for (int i = 0; i < n; i++) x[i] = xl[i];
-  for (int i = 0; i < n; i++) {
-    T s = x[i];
-    for (int j = 0; j < i; j++) s -= D[i * n + j] * x[j];
-    x[i] = s / D[i * n + i];
+  if (n <= 4) {  // (the lower triangle stays in registers over the right-hand sides)
+    T d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) d[i][j] = i < n ? D[i * n + j] : (i == j ? T(1) : T(0));
+    }
+    const int64_t x0 = sk.lumpStart[l];
+    for (int rhs = 0; rhs < nRhs; rhs++) {
+      GP<T> xl = solveVecBase(ref) + (int64_t)rhs * ref.ldc + x0;
+      T x[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = i < n ? xl[i] : T(0);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        T s = x[i];
+#pragma unroll
+        for (int j = 0; j < i; j++) s -= d[i][j] * x[j];
+        x[i] = s / d[i][i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (i < n) xl[i] = x[i];
+      }
+    }
+    return;
   }
-  for (int i = 0; i < n; i++) xl[i] = x[i];
+  for (int rhs = 0; rhs < nRhs; rhs++) {
+    GP<T> xl = solveVecBase(ref) + (int64_t)rhs * ref.ldc + sk.lumpStart[l];
+    T x[kElimSmallMax];
+    for (int i = 0; i < n; i++) x[i] = xl[i];
+    for (int i = 0; i < n; i++) {
+      T s = x[i];
+      for (int j = 0; j < i; j++) s -= D[i * n + j] * x[j];
+      x[i] = s / D[i * n + i];
+    }
+    for (int i = 0; i < n; i++) xl[i] = x[i];
+  }
 }
 
 // K-S2: y[span] -= sum over the blocks B that sit in that row span, B * x_lump.  The blocks are
 // listed per target span (SolveGatherEntry, sorted by span), an item is <= 256 entries of one
 // span: thread per block, workgroup reduction, ONE atomic per row and item (instead of one per
 // row and block, all on the few camera rows).
+// Round 5: up to 16 right-hand sides per workgroup (blockIdx.y = group of 16).  The v_mfma's B operand
+// has 16 columns and used one: column c now carries x_lump of right-hand side c, so the blocks of L
+// are read once for all of them (ten right-hand sides re-read the 0.64 GB of point columns of BAL-871
+// ten times: 2.40 ms of a 7.3 ms solve).
 template <typename T>
 __global__ __launch_bounds__(256) void solveElimGatherL(const SolveGatherItem* items,
                                                         const SolveGatherEntry* entries,
-                                                        SolveRef<T> ref) {
-  __shared__ T part[4][16];
+                                                        SolveRef<T> ref, int nRhs) {
+  __shared__ T part[4][16][17];
   const SolveGatherItem it = items[blockIdx.x];
   GP<const T> data = solveMat(ref);
-  GP<T> vec = solveVec(ref);
+  const int rhs0 = 16 * blockIdx.y, nR = min(16, nRhs - rhs0);
+  GP<T> vec0 = solveVecBase(ref) + (int64_t)rhs0 * ref.ldc;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (it.rows <= 16 && it.maxN <= 4) {
     // matrix-core path: per block ONE 8-byte load per lane -- lane (i, k) = (lane & 15, lane >> 4)
     // fetches B[i][k], the lanes together read the contiguous block -- and one v_mfma 16x16x4
-    // whose B operand carries x_lump in column 0; the sum over the wave's blocks stays in the
-    // accumulator (the thread-per-block loop below re-reads every cache line n x rows times)
+    // whose B operand carries x_lump of right-hand side c in column c; the sum over the wave's
+    // blocks stays in the accumulator (the thread-per-block loop below re-reads every cache line
+    // n x rows times)
     using Acc = typename Mfma<T>::Acc;
     constexpr int U = 8;
     const int li = lane & 15, lk = lane >> 4;
+    GP<const T> xcol = vec0 + (int64_t)min(li, nR - 1) * ref.ldc;
     Acc acc = {0, 0, 0, 0};
     const int e0 = it.entryBegin + 64 * wave;
     const int cnt = min(64, it.entryEnd - e0);
@@ -194,46 +237,51 @@ __global__ __launch_bounds__(256) void solveElimGatherL(const SolveGatherItem* i
         // (round 3, tried: x_lump fetched by lanes (15, k) of the SAME wave load as B and shuffled to
         //  lanes (0, k) -- one load per block instead of two in a kernel whose texture addresser is 90 %
         //  busy -- measured 297 against 247 us: the two-region load costs more than it saves)
-        const bool okA = li < it.rows && lk < n, okB = li == 0 && lk < n;
+        const bool okA = li < it.rows && lk < n, okB = li < nR && lk < n;
         a[u] = okA ? data[off + li * n + lk] : T(0);
-        b[u] = okB ? vec[xo + lk] : T(0);
+        b[u] = okB ? xcol[xo + lk] : T(0);
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         if (t0 + u < cnt) acc = Mfma<T>::run(a[u], b[u], acc);  // wave-uniform
       }
     }
-    if (li == 0) {  // column 0 of the product: rows Mfma::row(lane, g)
+    // column c of the product = right-hand side c: rows Mfma::row(lane, g)
 #pragma unroll
-      for (int g = 0; g < 4; g++) part[wave][Mfma<T>::row(lane, g)] = acc[g];
-    }
+    for (int g = 0; g < 4; g++) part[wave][li][Mfma<T>::row(lane, g)] = acc[g];
     __syncthreads();
-    const int r = threadIdx.x;
-    if (r < it.rows) atomicSub(vec + it.rowStart + r, part[0][r] + part[1][r] + part[2][r] + part[3][r]);
+    const int r = threadIdx.x & 15, c = threadIdx.x >> 4;
+    if (r < it.rows && c < nR) {
+      atomicSub(vec0 + (int64_t)c * ref.ldc + it.rowStart + r,
+                part[0][c][r] + part[1][c][r] + part[2][c][r] + part[3][c][r]);
+    }
     return;
   }
   const int e = it.entryBegin + (int)threadIdx.x;
   const bool live = e < it.entryEnd;
-  int n = 0;
-  GP<const T> B = data;
-  T x[kElimSmallMax];
-  if (live) {
-    const SolveGatherEntry en = entries[e];
-    n = en.n;
-    B = data + en.dataOff;
-    GP<const T> xl = vec + en.xOff;
-    for (int k = 0; k < n; k++) x[k] = xl[k];
-  }
-  for (int r = 0; r < it.rows; r++) {
-    T s = T(0);
-    for (int k = 0; k < n; k++) s += B[r * n + k] * x[k];
-    s = waveSum(s);
-    if (lane == 0) part[wave][0] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      atomicSub(vec + it.rowStart + r, part[0][0] + part[1][0] + part[2][0] + part[3][0]);
+  for (int rhs = 0; rhs < nR; rhs++) {
+    GP<T> vec = vec0 + (int64_t)rhs * ref.ldc;
+    int n = 0;
+    GP<const T> B = data;
+    T x[kElimSmallMax];
+    if (live) {
+      const SolveGatherEntry en = entries[e];
+      n = en.n;
+      B = data + en.dataOff;
+      GP<const T> xl = vec + en.xOff;
+      for (int k = 0; k < n; k++) x[k] = xl[k];
     }
-    __syncthreads();
+    for (int r = 0; r < it.rows; r++) {
+      T s = T(0);
+      for (int k = 0; k < n; k++) s += B[r * n + k] * x[k];
+      s = waveSum(s);
+      if (lane == 0) part[wave][0][0] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        atomicSub(vec + it.rowStart + r, part[0][0][0] + part[1][0][0] + part[2][0][0] + part[3][0][0]);
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -332,6 +380,145 @@ __global__ __launch_bounds__(256) void solveElimLumpsLt(const SolveLumpDesc* des
     x[j] = sres / d[j][j];
   }
   if (ip == 0 && kOk) vec[ld.xOff + k] = k == 0 ? x[0] : k == 1 ? x[1] : k == 2 ? x[2] : x[3];
+}
+
+// K-S3m  the same pass for SEVERAL right-hand sides (round 5; blockIdx.y = group of RB).  K-S3 per
+// right-hand side re-read the point columns of BAL-871 ten times for ten right-hand sides (2.76 ms of
+// a 7.3 ms solve), and holding RB accumulator sets in ITS layout moved nothing (2.71 ms): with one
+// element per lane every product needs its y through a lane gather, and the final column sums cost 64
+// LDS-crossbar permutes per right-hand side -- the kernel is bound by ds_bpermute, not by loads.
+// Here lane s of a lump's 16 lanes owns ROW s of every block: its n values come with n strided loads
+// (the 16 lanes together read the contiguous block), its y with one load per right-hand side, no
+// shuffle inside the loop; the column sums over the rows are DPP row rotations (vector ALU, no LDS),
+// and blocks of more than 16 rows simply take several passes.
+template <int N>
+__device__ __forceinline__ double rowRorT(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ float rowRorT(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), in every lane of the row
+template <typename T>
+__device__ __forceinline__ T rowSum16(T v) {
+  v += rowRorT<8>(v);
+  v += rowRorT<4>(v);
+  v += rowRorT<2>(v);
+  v += rowRorT<1>(v);
+  return v;
+}
+
+template <typename T, int RB>
+__global__ __launch_bounds__(256) void solveElimLumpsLtMulti(const SolveLumpDesc* descs,
+                                                             const SolveLumpBlock* blocks,
+                                                             SolveRef<T> ref, int numLumps, int nRhs) {
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const int idx0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const bool liveLump = idx0 < numLumps;
+  const SolveLumpDesc ld = descs[liveLump ? idx0 : numLumps - 1];
+  const int n = ld.n;
+  if (n > 4) return;  // (wider lumps of the range: panel kernels; the caller checks the range's width)
+  GP<const T> data = solveMat(ref);
+  const int rhs0 = RB * blockIdx.y, nR = min(RB, nRhs - rhs0);
+  GP<T> vecs[RB];
+#pragma unroll
+  for (int q = 0; q < RB; q++) vecs[q] = solveVecBase(ref) + (int64_t)(rhs0 + min(q, nR - 1)) * ref.ldc;
+  T acc[RB][4];
+#pragma unroll
+  for (int q = 0; q < RB; q++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[q][j] = T(0);
+  }
+  const int nBlocks = liveLump ? ld.blockEnd - ld.blockBegin : 0;
+  // CB blocks per trip, every load of a trip issued before its first product: a wave's time is its
+  // chain of dependent round trips (descriptor -> values), one block per trip took ten of them for
+  // the typical widest lump of a wave; the next trip's descriptors are requested a trip ahead
+  constexpr int CB = RB <= 4 ? 4 : 2;
+  SolveLumpBlock nb[CB];
+#pragma unroll
+  for (int c = 0; c < CB; c++) nb[c] = blocks[ld.blockBegin + min(c, max(nBlocks - 1, 0))];
+  for (int e0 = 0; e0 < nBlocks; e0 += CB) {
+    SolveLumpBlock b[CB];
+#pragma unroll
+    for (int c = 0; c < CB; c++) b[c] = nb[c];
+    if (e0 + CB < nBlocks) {
+#pragma unroll
+      for (int c = 0; c < CB; c++) nb[c] = blocks[ld.blockBegin + min(e0 + CB + c, nBlocks - 1)];
+    }
+    bool tall = false;
+    T v[CB][4], y[CB][RB];
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+      const bool on = e0 + c < nBlocks && sub < b[c].rows;
+      tall = tall || (e0 + c < nBlocks && b[c].rows > 16);
+      GP<const T> row = data + b[c].dataOff + (on ? sub : 0) * n;
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[c][j] = (on && j < n) ? row[j] : T(0);
+#pragma unroll
+      for (int q = 0; q < RB; q++) {
+        if (q < nR) y[c][q] = on ? vecs[q][b[c].yOff + sub] : T(0);  // (nR: workgroup-uniform)
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+#pragma unroll
+      for (int q = 0; q < RB; q++) {
+        if (q < nR) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[q][j] += v[c][j] * y[c][q];
+        }
+      }
+    }
+    if (__any(tall)) {  // rows 16 .. of blocks taller than a lane group (not the 9 x 3 blocks of BAL)
+#pragma unroll
+      for (int c = 0; c < CB; c++) {
+        const int rowsC = e0 + c < nBlocks ? b[c].rows : 0;
+        for (int r = sub + 16; r < rowsC; r += 16) {
+          GP<const T> row = data + b[c].dataOff + r * n;
+          T vv[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) vv[j] = j < n ? row[j] : T(0);
+#pragma unroll
+          for (int q = 0; q < RB; q++) {
+            if (q < nR) {
+              const T yy = vecs[q][b[c].yOff + r];
+#pragma unroll
+              for (int j = 0; j < 4; j++) acc[q][j] += vv[j] * yy;
+            }
+          }
+        }
+      }
+    }
+  }
+  // (every lane of the wave from here on: the DPP rotations read all 16 lanes of a row)
+  T d[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) d[i][j] = (i < n && j <= i) ? data[ld.diagOff + i * n + j] : (i == j ? T(1) : T(0));
+  }
+#pragma unroll
+  for (int q = 0; q < RB; q++) {
+    T x[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const T xj = j < n ? vecs[q][ld.xOff + j] : T(0);
+      x[j] = xj - rowSum16(acc[q][j]);
+    }
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+      T sres = x[j];
+#pragma unroll
+      for (int i = j + 1; i < 4; i++) sres -= d[i][j] * x[i];
+      x[j] = sres / d[j][j];
+    }
+    if (liveLump && sub < n && q < nR) {
+      vecs[q][ld.xOff + sub] = sub == 0 ? x[0] : sub == 1 ? x[1] : sub == 2 ? x[2] : x[3];
+    }
+  }
 }
 
 // (round 3, tried and removed: K-S3 with the wave's four columns staged through LDS like the factor's
