@@ -8,6 +8,7 @@
 #include <unordered_set>
 
 #include "bal_pipeline.h"
+#include "../../include/baspacho_amd_testing.h"
 #include "computation_model.h"
 #include "hip_backend.h"
 #include "solver.h"

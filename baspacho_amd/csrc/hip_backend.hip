@@ -5,6 +5,7 @@
 // per-lump host->device table uploads.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -379,12 +380,35 @@ struct HipSymbolicCtx : SymbolicCtx {
       prepareDevice(upToLump);
     } catch (const std::exception&) {
       // (eager preparation is an optimisation: whatever it could not do happens -- and fails
-      //  loudly, if it has to -- in the first factor())
+      //  loudly, if it has to -- in the first factor().  Nothing of the eager state has been handed
+      //  out: release ALL of it and forget the device, so that a first real use on another device
+      //  binds there as the lazy path of rounds 1-3 did)
       (void)hipGetLastError();
-      plans.clear();
+      releaseDeviceState();
+      device = -1;
       eagerOnly = false;
       inPrepare = false;
     }
+  }
+
+  // everything this context has put on the GPU (a device buffer is freed on whatever device is
+  // current; events and plans likewise)
+  void releaseDeviceState() {
+    plans.clear();
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    events.clear();
+    nextEvent = 0;
+    dinvScratch.release();
+    rawScratch.release();
+    yieldBuf.release();
+    solveInvScratch.release();
+    for (DevBuf* b : {&dSpanStart, &dSpanToLump, &dLumpStart, &dSpanOffsetInLump, &dChainColPtr,
+                      &dChainRowSpan, &dChainData, &dChainRowsTillEnd, &dBoardColPtr,
+                      &dBoardChainColOrd, &dPermutation}) {
+      b->release();
+    }
+    skelUploaded = false;
+    shared = nullptr;
   }
 
   // The reference builds its SymbolicCtx and every SymElimCtx in the Solver constructor
@@ -423,8 +447,17 @@ struct HipSymbolicCtx : SymbolicCtx {
       hipCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       events.push_back(e);
     }
-    hipk::warmupKernel<<<1, 64, 0, stream>>>();
-    hipCHECK(hipStreamSynchronize(stream));
+    // code object load: one empty launch on a private non-blocking stream (the context's own
+    // stream is the legacy default stream at construction: a launch + sync there would also wait for
+    // every blocking stream of the process -- PyTorch's included -- and is illegal during a capture)
+    {
+      hipStream_t warm = nullptr;
+      hipCHECK(hipStreamCreateWithFlags(&warm, hipStreamNonBlocking));
+      hipk::warmupKernel<<<1, 64, 0, warm>>>();
+      const hipError_t werr = hipStreamSynchronize(warm);
+      (void)hipStreamDestroy(warm);
+      hipCHECK(werr);
+    }
     eagerOnly = true;
   }
 
@@ -438,21 +471,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (device < 0) device = cur;
     if (cur != device && eagerOnly) {
       // only the constructor's eager state lives on `device`: move to the device of the first use
-      // (a device buffer is freed on whatever device is current)
-      plans.clear();
-      for (hipEvent_t e : events) (void)hipEventDestroy(e);
-      events.clear();
-      nextEvent = 0;
-      dinvScratch.release();
-      rawScratch.release();
-      yieldBuf.release();
-      for (DevBuf* b : {&dSpanStart, &dSpanToLump, &dLumpStart, &dSpanOffsetInLump, &dChainColPtr,
-                        &dChainRowSpan, &dChainData, &dChainRowsTillEnd, &dBoardColPtr,
-                        &dBoardChainColOrd, &dPermutation}) {
-        b->release();
-      }
-      skelUploaded = false;
-      shared = nullptr;
+      releaseDeviceState();
       device = cur;
     }
     if (!inPrepare) eagerOnly = false;
@@ -575,6 +594,10 @@ struct HipSymbolicCtx : SymbolicCtx {
   // always finds a slot
   static constexpr unsigned bulkExtraLds = 6 * 1024, dueExtraLds = 6 * 1024;
   bool forcePerOp = false;  // TESTING: drive factor() through the per-op boundary
+  // TESTING, fault injection (bsp_test_set_fault, include/baspacho_amd_testing.h; never read from the
+  // environment): the sparse-elimination update is not launched, so the factor is wrong and the
+  // full-size checks must notice
+  bool faultDropElimUpdate = false;
   SharedStreams* shared = nullptr;  // this device's auxiliary streams (streams())
   HipPlanOptions planOpts;     // the plan builder's switches (BSP_DUE_STREAM, BSP_BULK_AHEAD, ...)
   double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
@@ -937,10 +960,11 @@ struct HipNumericCtx : NumericCtx<T> {
     // FAULT INJECTION (bsp_test_set_fault, tests only): the whole sparse-elimination update is
     // dropped -- the factor of everything the eliminated columns touch is then wrong, and the
     // full-size parity tests must notice (tests/test_full_size_gpu.py)
-    if (sym.planOpts.dropElimUpdate) {
-      static bool warned = false;
-      if (!warned) fprintf(stderr, "baspacho_amd: FAULT INJECTION ACTIVE -- sparse-elimination update dropped (tests only)\n");
-      warned = true;
+    if (sym.faultDropElimUpdate) {
+      static std::atomic<bool> warned{false};
+      if (!warned.exchange(true)) {
+        fprintf(stderr, "baspacho_amd: FAULT INJECTION ACTIVE -- sparse-elimination update dropped (tests only)\n");
+      }
       return;
     }
     if (er.useGather) {
@@ -1742,7 +1766,7 @@ std::vector<int64_t> hipBackendPlanLevels(SymbolicCtx& sym, int64_t startLump, i
 void hipBackendSetFault(SymbolicCtx& sym, int kind) {
   HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
   BASPACHO_CHECK_NOTNULL(h);
-  h->planOpts.dropElimUpdate = kind == 1;
+  h->faultDropElimUpdate = kind == 1;
 }
 
 void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof, bool inSitu) {

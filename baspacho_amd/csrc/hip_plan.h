@@ -215,9 +215,6 @@ struct ElimRangePlan {
 struct HipPlanOptions {
   bool dueStream = true;      // BSP_DUE_STREAM: due lookahead units on a stream of their own
   bool planTiming = false;    // BSP_TIMING: stderr laps of the gather plan
-  bool dropElimUpdate = false; // FAULT INJECTION for the parity tests (bsp_test_set_fault, never read
-                               // from the environment): the sparse-elimination update is not launched,
-                               // so the factor is wrong and the full-size checks must notice
   int32_t gatherMaxPairs = kGatherMaxPairs;  // BSP_GATHER_MAX_PAIRS
   double bulkAhead = 0.8;     // BSP_BULK_AHEAD (round 4: 0.6 -> 0.8, -0.04 ms on BAL-871; profiles/r04_ab_plan_knobs.txt)
   static HipPlanOptions fromEnv();

@@ -144,10 +144,6 @@ int bsp_read_op_stats(bsp_solver* s, int32_t which, double* out, int64_t capacit
    (Solver.cpp:164-219, 270-397, 400-449) -- sparseElimSolveL/Lt, symm, solveL, gemv, assembleVec,
    solveLt, gemvT, assembleVecT, fragmentedMV/SolveL/SolveLt -- instead of the fused paths */
 int bsp_force_per_op(bsp_solver* s, int32_t on);
-/* TESTING, fault injection: kind 1 = factor() skips the sparse-elimination update (Solver.cpp:190-196
- * doElimination's update half), so the factor is WRONG -- tests/test_full_size_gpu.py checks that the
- * full-size parity checks then fail; 0 = off.  Not reachable through the environment. */
-int bsp_test_set_fault(bsp_solver* s, int32_t kind);
 /* Level table of the full-range factor plan (host only; the level schedule replaces the host-serial
  * per-lump loop of Solver.cpp:198-218): 8 values per level -- {sparse-elimination range or -1, panels,
  * widest panel, most rows below a panel, trsm row tiles, update tiles, lookahead tiles, rows below
