@@ -360,7 +360,6 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_NO_LOOKAHEAD")) lookaheadEnabled = e[0] == '0';
     if (const char* e = std::getenv("BSP_BLOCK_SOLVE")) blockSolve = e[0] != '0';
     if (const char* e = std::getenv("BSP_SOLVE_INV")) solveInv = e[0] != '0';
-    if (const char* e = std::getenv("BSP_UPD_LDS")) updLds = e[0] != '0';
     // the plan builder's switches: read here, once per Solver, handed to every buildHipPlan call
     // and recorded in the plan; launchLevels takes dueStream from the plan it runs
     planOpts = HipPlanOptions::fromEnv();
@@ -603,7 +602,6 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipPlanOptions planOpts;     // the plan builder's switches (BSP_DUE_STREAM, BSP_BULK_AHEAD, ...)
   double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
-  bool updLds = true;       // EXPERIMENT switch (BSP_UPD_LDS=0: the register-staged updateTile)
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
   int device = -1;  // device of the first use (checkDevice)
@@ -665,7 +663,6 @@ struct HipNumericCtx : NumericCtx<T> {
     const int64_t wgs = (end - begin) * (int64_t)batchSize;
     const bool few = wgs <= sym.updPrefetchMaxWgs;
     auto kern = few ? hipk::updateTile<BT, true> : hipk::updateTile<BT, false>;
-    if (sym.updLds) kern = few ? hipk::updateTileLds<BT, 2> : hipk::updateTileLds<BT, 1>;
     // (Asking for enough dynamic LDS that only ceil(workgroups / CUs) of a small launch fit on a CU,
     //  in case the dispatcher packs them four to a CU: no effect at batch 1 / 8 / 64 -- it does not.)
     kern<<<dim3((unsigned)(end - begin), (unsigned)batchSize), 256, extraLds, stream>>>(

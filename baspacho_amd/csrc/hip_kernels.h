@@ -1833,233 +1833,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   bulkTileBody<T>(t, pickData(dref), As, Bs, yieldFlag, atomicMask);
 }
 
-// K5c  (round 5) updateTile with the bulk tile's operand path: ANY task -- board segments with their
-// scatter tables, ragged K -- takes its operands straight from global memory to LDS
-// (global_load_lds_dwordx4, unpadded XOR-swizzled rows, no staging registers, no LDS stores) as
-// updateTileBulk does for the lookahead units.  In-situ traces of updateTile (tools/trace_upd.py,
-// round 3) put a K chunk of the register-staged loop at 1.6 us for one matrix and 3.2 us in a batch
-// of 64, against ~0.9 us per chunk for the direct-to-LDS loop (a 67-tile rank-256 launch of GRID
-// 82x82: 7.9 us in updateTileBulk, 17-19 us for like launches in updateTile).
-//   * the last chunk of a ragged K: a lane whose 16-byte slot lies (partly) beyond column K does not
-//     take part in the wave's LDS load; it fetches its valid values by hand and writes them, with
-//     zeros behind, to its own slot before the barrier -- nothing is ever read past column K;
-//   * NB = 2 LDS buffers (launches of at most ~2 rounds of workgroups): the next chunk is requested
-//     before the current one is multiplied, the wait leaves exactly those loads in flight; NB = 1 for
-//     saturated launches (33 KB: four workgroups per CU, as updateTile).
-#ifndef BSP_UPDLDS_OCC
-#define BSP_UPDLDS_OCC 4
-#endif
-template <typename T, int NB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 2 ? 2 : BSP_UPDLDS_OCC, 4))) void updateTileLds(
-    const UpdTaskWide* tasks, const int64_t* chainOffTab, const int32_t* rowChain,
-    const int32_t* rowLocal, const int32_t* rowColOff, DataRef<T> dref, T* altTarget = nullptr,
-    int64_t altStride = 0, int atomicMask = 3) {
-  constexpr int KC = kUpdChunk, E = BulkSwizzle<T>::E, SLOTS = KC / E, RPI = 64 / SLOTS;
-  constexpr int NI = kTile / (4 * RPI);  // wave instructions per operand and wave
-  typedef __attribute__((address_space(1))) const void* GV;
-  typedef __attribute__((address_space(3))) void* LV;
-  __shared__ __attribute__((aligned(16))) T As[NB][kTile * KC];
-  __shared__ __attribute__((aligned(16))) T Bs[NB][kTile * KC];
-  __shared__ int64_t rowBase[kTile];
-  __shared__ int32_t colOff[kTile];
-  const UpdTaskWide w = tasks[blockIdx.x];
-  if (w.K <= 0) return;
-  GP<T> data = pickData(dref);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = w.K, lda = w.lda, segEnd = w.segEnd;
-  GP<const T> P = data + w.srcOff;
-  const bool diagTile = w.rowTile == w.colTile;
-  // wave `wave`, instruction it: rows RPI * (4 it + wave) .. + RPI - 1; lane -> (row, physical slot);
-  // the logical slot (ps ^ key(row)) does not depend on `it` (16 it rows further on: same key)
-  const int ps = lane % SLOTS, rIn = RPI * wave + lane / SLOTS;
-  const int ls = ps ^ BulkSwizzle<T>::key(rIn);
-  // (row pointers are recomputed per chunk instead of kept: 16 registers at four waves per SIMD)
-  auto srcAp = [&](int it) __attribute__((always_inline)) {
-    return P + (int64_t)min(w.rowTile + RPI * 4 * it + rIn, w.rowsBelow - 1) * lda + E * ls;
-  };
-  auto srcBp = [&](int it) __attribute__((always_inline)) {
-    return P + (int64_t)min(w.colTile + RPI * 4 * it + rIn, segEnd - 1) * lda + E * ls;
-  };
-  const int nChunks = (K + KC - 1) / KC;
-  // values of this lane's slot in the LAST chunk when the slot is not entirely inside [0, K)
-  const int lastBase = (nChunks - 1) * KC;
-  const bool fullLast = lastBase + E * ls + E <= K;
-  // (a slot that is not entirely inside [0, K) holds at most E - 1 valid values)
-  constexpr int ET = E - 1;
-  T tailA[NI][ET], tailB[NI][ET];
-  auto issue = [&](int c, int b) __attribute__((always_inline)) {
-    const int kBase = c * KC;
-    const bool full = c + 1 < nChunks || fullLast;  // (per lane)
-    if (full) {
-#pragma unroll
-      for (int it = 0; it < NI; it++) {
-        __builtin_amdgcn_global_load_lds((GV)(srcAp(it) + kBase), (LV)(&As[b][RPI * (4 * it + wave) * KC]), 16, 0, 0);
-      }
-      if (!diagTile) {
-#pragma unroll
-        for (int it = 0; it < NI; it++) {
-          __builtin_amdgcn_global_load_lds((GV)(srcBp(it) + kBase), (LV)(&Bs[b][RPI * (4 * it + wave) * KC]), 16, 0, 0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < NI; it++) {
-#pragma unroll
-        for (int e = 0; e < ET; e++) {
-          const bool ok = kBase + E * ls + e < K;
-          tailA[it][e] = ok ? srcAp(it)[kBase + e] : T(0);
-          tailB[it][e] = (ok && !diagTile) ? srcBp(it)[kBase + e] : T(0);
-        }
-      }
-    }
-  };
-  // the hand-fetched slots of the last chunk go to LDS (own slot: nobody else writes it)
-  auto landTail = [&](int c, int b) __attribute__((always_inline)) {
-    if (c + 1 == nChunks && !fullLast) {
-#pragma unroll
-      for (int it = 0; it < NI; it++) {
-        const int at = (RPI * 4 * it + rIn) * KC + E * ps;
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-          As[b][at + e] = e < ET ? tailA[it][e < ET ? e : 0] : T(0);
-          if (!diagTile) Bs[b][at + e] = e < ET ? tailB[it][e < ET ? e : 0] : T(0);
-        }
-      }
-    }
-  };
-  issue(0, 0);
-
-  // per-row / per-column target addressing of this tile (visible after the first barrier)
-  if (tid < kTile) {
-    const int q = w.rowTile + tid;
-    int64_t base = 0;
-    if (q < w.rowsBelow) {
-      if (w.kind == kSegIntra) {
-        base = w.tgtBase + (int64_t)q * w.tgtStride;
-      } else {
-        const int rr = w.lumpRowBase + (q - w.nRest);
-        base = chainOffTab[w.chainTabPtr + (rowChain[rr] - w.firstChainOrd)] +
-               (int64_t)rowLocal[rr] * w.tgtStride;
-      }
-    }
-    rowBase[tid] = base;
-  } else if (tid < 2 * kTile) {
-    const int cidx = tid - kTile;
-    const int q = w.colTile + cidx;
-    int32_t off = 0;
-    if (q < segEnd) off = w.kind == kSegIntra ? q : rowColOff[w.lumpRowBase + (q - w.nRest)];
-    colOff[cidx] = off;
-  }
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-  const int li = lane & 15, lk = lane >> 4;
-  using Acc = typename Mfma<T>::Acc;
-  Acc acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-  const bool skipUpper = diagTile && wr < wc;
-  GP<T> tbase = altTarget ? (GP<T>)altTarget + (int64_t)blockIdx.y * altStride : data;
-  const int oa0 = BulkSwizzle<T>::at(wr + li, lk), oa1 = BulkSwizzle<T>::at(wr + 16 + li, lk);
-  const int ob0 = BulkSwizzle<T>::at(wc + li, lk), ob1 = BulkSwizzle<T>::at(wc + 16 + li, lk);
-  const int ka0 = BulkSwizzle<T>::key(wr + li), ka1 = BulkSwizzle<T>::key(wr + 16 + li);
-  const int kb0 = BulkSwizzle<T>::key(wc + li), kb1 = BulkSwizzle<T>::key(wc + 16 + li);
-
-  for (int c = 0; c < nChunks; c++) {
-    const int b = NB == 2 ? (c & 1) : 0;
-    if (NB == 2) {
-      if (c + 1 < nChunks) {
-        issue(c + 1, b ^ 1);  // (buffer b ^ 1: consumed in trip c - 1, behind that trip's last barrier)
-        // everything older than the loads just issued has landed
-        if (c + 2 < nChunks || fullLast) {
-          if (diagTile) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-          } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
-          }
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a hand-fetched tail is in flight: wait for all)
-        }
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    } else {
-      if (c > 0) {
-        __syncthreads();  // the previous chunk has been consumed
-        issue(c, 0);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    landTail(c, b);
-    __syncthreads();
-    if (!skipUpper) {
-      const int kc = min(KC, K - c * KC);
-      const int kEnd = (kc + 3) & ~3;
-      const T* Ab = As[b];
-      const T* Bb = diagTile ? As[b] : Bs[b];
-      auto step = [&](int k0) __attribute__((always_inline)) {
-        const int sft = k0 / E;
-        const T a0 = Ab[oa0 + E * (((lk / E + sft) ^ ka0) - ((lk / E) ^ ka0))];
-        const T a1 = Ab[oa1 + E * (((lk / E + sft) ^ ka1) - ((lk / E) ^ ka1))];
-        const T b0 = Bb[ob0 + E * (((lk / E + sft) ^ kb0) - ((lk / E) ^ kb0))];
-        const T b1 = Bb[ob1 + E * (((lk / E + sft) ^ kb1) - ((lk / E) ^ kb1))];
-        acc00 = Mfma<T>::run(a0, b0, acc00);
-        acc01 = Mfma<T>::run(a0, b1, acc01);
-        acc10 = Mfma<T>::run(a1, b0, acc10);
-        acc11 = Mfma<T>::run(a1, b1, acc11);
-      };
-      if (kEnd == KC) {
-#pragma unroll
-        for (int k0 = 0; k0 < KC; k0 += 4) step(k0);
-      } else {
-        for (int k0 = 0; k0 < kEnd; k0 += 4) step(k0);
-      }
-    }
-    if (NB == 2 && c + 1 < nChunks) __syncthreads();  // buffer b may be overwritten in the next trip
-  }
-  if (!skipUpper) {
-    const Acc* accs[4] = {&acc00, &acc01, &acc10, &acc11};
-    const bool atomicTile = (w.atomic & atomicMask) != 0;
-    // (NB = 1: the read-modify-write in two halves of 8 values -- the kernel has to stay within the 128
-    //  registers of four waves per SIMD)
-    constexpr int HALVES = NB == 1 ? 2 : 1, TPH = 4 / HALVES;
-#pragma unroll
-    for (int h = 0; h < HALVES; h++) {
-      T old[4 * TPH];
-      if (!atomicTile) {  // gather the old values first (independent loads in flight together)
-#pragma unroll
-        for (int tt = 0; tt < TPH; tt++) {
-          const int t = h * TPH + tt;
-          const int32_t co = colOff[wc + (t & 1) * 16 + li];
-#pragma unroll
-          for (int reg = 0; reg < 4; reg++) {
-            // (masked-off entries point at valid memory)
-            old[tt * 4 + reg] = *(tbase + rowBase[wr + (t >> 1) * 16 + Mfma<T>::row(lane, reg)] + co);
-          }
-        }
-      }
-#pragma unroll
-      for (int tt = 0; tt < TPH; tt++) {
-        const int t = h * TPH + tt;
-        const int r0 = wr + (t >> 1) * 16, c0 = wc + (t & 1) * 16;
-        const int cIn = c0 + li;
-        const int qc = w.colTile + cIn;
-        const int32_t co = colOff[cIn];
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-          const int rI = r0 + Mfma<T>::row(lane, reg);
-          const int qr = w.rowTile + rI;
-          const bool ok = qc < segEnd && qr < w.rowsBelow && qr >= qc && qr >= w.rowMin;
-          GP<T> ptr = tbase + rowBase[rI] + co;
-          if (ok) {
-            if (atomicTile) {
-              atomicSub(ptr, (*accs[t])[reg]);
-            } else {
-              *ptr = old[tt * 4 + reg] - (*accs[t])[reg];
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
 // K5d  direct variant for the update tiles of a one-panel level that all belong to ONE
 // intra-lump segment: descriptors by value, the tile is decoded from blockIdx.x (same order as
 // the plan's task list: column tiles of the first `mNow` columns, each with its row tiles, then
