@@ -297,6 +297,7 @@ struct LaunchTimer {
 // streams and are merely ordered on them.
 struct SharedStreams {
   hipStream_t side = nullptr, due = nullptr;
+  hipStream_t batch[3] = {nullptr, nullptr, nullptr};  // further parts of a batch factored as concurrent sub-batches (normal priority)
 };
 inline SharedStreams& sharedStreams() {
   static std::mutex mu;
@@ -314,6 +315,7 @@ inline SharedStreams& sharedStreams() {
     hipCHECK(hipStreamCreateWithPriority(&st.side, hipStreamNonBlocking, least));
     // (highest priority for the due units: measured, no effect)
     hipCHECK(hipStreamCreateWithPriority(&st.due, hipStreamNonBlocking, least));
+    for (hipStream_t& b : st.batch) hipCHECK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
   }
   return st;
 }
@@ -360,6 +362,8 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_NO_LOOKAHEAD")) lookaheadEnabled = e[0] == '0';
     if (const char* e = std::getenv("BSP_BLOCK_SOLVE")) blockSolve = e[0] != '0';
     if (const char* e = std::getenv("BSP_SOLVE_INV")) solveInv = e[0] != '0';
+    if (const char* e = std::getenv("BSP_SUB_BATCH_MIN")) subBatchMin = std::max(2, std::atoi(e));
+    if (const char* e = std::getenv("BSP_SUB_BATCHES")) subBatchParts = std::max(2, std::atoi(e));
     // the plan builder's switches: read here, once per Solver, handed to every buildHipPlan call
     // and recorded in the plan; launchLevels takes dueStream from the plan it runs
     planOpts = HipPlanOptions::fromEnv();
@@ -602,6 +606,8 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipPlanOptions planOpts;     // the plan builder's switches (BSP_DUE_STREAM, BSP_BULK_AHEAD, ...)
   double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
+  int subBatchMin = 16;     // batches of at least this many matrices are factored as concurrent sub-batches (BSP_SUB_BATCH_MIN; 0x7fffffff: never)
+  int subBatchParts = 2;    // ... this many (BSP_SUB_BATCHES, at most 4, at least subBatchMin / 2 matrices each)
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
   int device = -1;  // device of the first use (checkDevice)
@@ -705,15 +711,17 @@ struct HipNumericCtx : NumericCtx<T> {
     bool sideUsed = false, dueUsed = false;
     // inverted diagonal blocks of the chain panels: written by a panel's potrf, read by its trsm
     // (two slots per matrix, alternating from panel to panel)
-    sym.dinvScratch.resize((size_t)batchSize * hipk::kDinvBatchStride * sizeof(BT));
-    BT* dinvBase = const_cast<BT*>(sym.dinvScratch.as<BT>());
+    // (a batch factored as concurrent sub-batches, factorRange: every sub-batch its own slice)
+    const int64_t scratchBatch = std::max<int64_t>(batchSize, subBatchTotal);
+    sym.dinvScratch.resize((size_t)scratchBatch * hipk::kDinvBatchStride * sizeof(BT));
+    BT* dinvBase = const_cast<BT*>(sym.dinvScratch.as<BT>()) + (size_t)subBatchBase * hipk::kDinvBatchStride;
     int dinvSlot = 0;  // slot of the current level's panel
     // staging buffer of the chain (chainStep): unsolved rows of the current / next panel
     const int64_t rawSlot = plan.host.maxChainRows * kTile;
     BT* rawBase = nullptr;
     if (rawSlot > 0) {
-      sym.rawScratch.resize((size_t)batchSize * 2 * rawSlot * sizeof(BT));
-      rawBase = const_cast<BT*>(sym.rawScratch.as<BT>());
+      sym.rawScratch.resize((size_t)scratchBatch * 2 * rawSlot * sizeof(BT));
+      rawBase = const_cast<BT*>(sym.rawScratch.as<BT>()) + (size_t)subBatchBase * 2 * rawSlot;
     }
     bool rawValid = false;  // the previous level staged this level's panel rows
     // early tile-(0,0) updates of the next outer block (LevelRange::extraDiag): how many panels of
@@ -1012,6 +1020,47 @@ struct HipNumericCtx : NumericCtx<T> {
   // every launch of a factor over `plan`, in order, on sym.stream and the auxiliary streams
   void enqueueFactor(DevPlan& plan, hipk::DataRef<BT> ref, LaunchTimer& timer) {
     sym.resetEventPool();
+    // CONCURRENT SUB-BATCHES (round 5).  A large batch of a latency-bound structure is three dependent
+    // launches per tree level, each with a ramp and a tail in which most of the GPU idles; two halves
+    // of the batch on two streams fill each other's (64 x GRID 82x82: 10.76 -> 10.2 ms with two Solver
+    // clones on two streams, profiles/r3_concurrent_batch.py re-run in round 5; four halves: host
+    // enqueue bound, slower).  The second half runs on the auxiliary stream, which such a plan does
+    // not use for lookahead; matrices are independent, the halves share nothing but the plan.
+    const bool lookahead = lookaheadOn() && plan.host.lookaheadPays(batchSize, sym.lookaheadMinFlops);
+    if (ref.many && !lookahead && sym.profile == nullptr && batchSize >= sym.subBatchMin) {
+      const int total = batchSize;
+      const int parts = std::max(2, std::min({sym.subBatchParts, 4, total / std::max(1, sym.subBatchMin / 2)}));
+      hipStream_t mainStream = sym.stream;
+      hipEvent_t fork = sym.eventFromPool();
+      hipCHECK(hipEventRecord(fork, mainStream));  // (the pointer array has been copied on this stream)
+      struct Restore {
+        HipNumericCtx& c;
+        hipStream_t st;
+        int bs;
+        ~Restore() {
+          c.sym.stream = st;
+          c.batchSize = bs;
+          c.subBatchBase = c.subBatchTotal = 0;
+        }
+      } restore{*this, mainStream, total};
+      subBatchTotal = total;
+      for (int g = 0; g < parts; g++) {
+        const int b0 = (int)((int64_t)total * g / parts), b1 = (int)((int64_t)total * (g + 1) / parts);
+        subBatchBase = b0;
+        batchSize = b1 - b0;
+        sym.stream = g ? sym.streams().batch[g - 1] : mainStream;
+        if (g) hipCHECK(hipStreamWaitEvent(sym.stream, fork, 0));
+        hipk::DataRef<BT> sub{nullptr, ref.many + subBatchBase};
+        for (const ElimRangePlan& er : plan.host.elimRanges) launchElim(plan, er, sub, timer);
+        launchLevels(plan, plan.host.levels, sub, timer);
+        if (g) {
+          hipEvent_t join = sym.eventFromPool();
+          hipCHECK(hipEventRecord(join, sym.stream));
+          hipCHECK(hipStreamWaitEvent(mainStream, join, 0));
+        }
+      }
+      return;
+    }
     for (const ElimRangePlan& er : plan.host.elimRanges) launchElim(plan, er, ref, timer);
     launchLevels(plan, plan.host.levels, ref, timer);
   }
@@ -1176,6 +1225,7 @@ struct HipNumericCtx : NumericCtx<T> {
 
   HipSymbolicCtx& sym;
   int batchSize;
+  int subBatchBase = 0, subBatchTotal = 0;  // enqueueFactor: the sub-batch being enqueued
   int64_t tempBufSize = 0;
   DevBuf temp, spanToChainOffset;  // per-op boundary only (saveSyrkGemm / prepareAssemble)
   vector<std::unique_ptr<DevPlan>> opPlans;

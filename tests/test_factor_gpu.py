@@ -126,6 +126,27 @@ def test_batched_factor(dtype):
             assert err < EPS[dtype][1], (i, q, err)
 
 
+@pytest.mark.product_defaults
+@pytest.mark.parametrize("bs", [2, 5, 17])
+def test_batch_as_concurrent_halves(bs, monkeypatch):
+    """round 5: a batch is factored as two concurrent halves (second half on the auxiliary stream,
+    its own slice of the per-matrix scratch) when the plan keeps its lookahead units in line --
+    here forced for small batches and odd splits; structures with an elimination range, a multi-
+    panel tree and a one-panel chain (staging buffer and inverted diagonal blocks per matrix)"""
+    monkeypatch.setenv("BSP_SUB_BATCH_MIN", "2")
+    n = 300
+    cols = [set(range(i, min(n, i + 3))) | (set(range(200, n)) if i >= 150 else set()) for i in range(n)]
+    for sol in (solver_random(61, fill=0.03, elim=(0, 60))[0],
+                B.create_solver(B.Settings(), np.full(n, 2, dtype=np.int64), T.columns_to_structure(cols))):
+        datas = [spd_data(sol, 300 + q) for q in range(bs)]
+        devs = [to_dev(d) for d in datas]
+        sol.factor(devs)
+        for q in range(bs):
+            L, _ = dense_lower_chol(sol, datas[q])
+            err = np.linalg.norm(lower_of(sol, devs[q].cpu().numpy()) - L) / np.linalg.norm(L)
+            assert err < 1e-12, (q, err)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_batched_wide_dense_lump(dtype):
     """a batch through the one-panel-level chain kernels (chain step, staging buffer and inverted
