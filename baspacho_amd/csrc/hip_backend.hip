@@ -78,6 +78,13 @@ struct DevPlan {
       updTasksFat, updTasksWide, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc;
   int64_t numUpdTasks = 0;
   vector<int64_t> slowPrefix;  // tasks [0, i) that updateTileBulk cannot take
+  // split-K task lists of small multi-panel levels: level's updBegin -> [begin, end) in updTasksSplit
+  static constexpr int64_t kSplitMaxTiles = 512;
+  // (GRID 82x82, slices of 32 / 64 / 96 / 128 / 160 columns: 1.208 / 1.149 / 1.135 / 1.140 / 1.163 against
+  //  1.180 ms without; profiles/r05_ab_split_k.txt)
+  static constexpr int32_t kSplitMinK = 128, kSplitK = 96;
+  DevBuf updTasksSplit;
+  std::map<int64_t, std::pair<int64_t, int64_t>> splitRange;
   // forward-solve gather lists, built on the first solve that needs them
   bool solveGatherReady = false;
   SolveGatherPlan solveGather;
@@ -160,6 +167,43 @@ struct DevPlan {
       }
       updTasksFat.upload(fat);
       updTasksWide.upload(wide);
+      // SPLIT-K lists (round 5) for the multi-panel levels of latency-bound structures.  A tile of a
+      // block-wide source walks its K = 128 .. 256 columns in chunks of 32, one exposed memory round trip
+      // per chunk (1.6 us, tools/trace_upd.py): 17-19 us per launch where a level of rank-64 tiles takes
+      // 10, on a GPU that is mostly idle.  For small levels every such tile is listed again as ceil(K /
+      // 96) tiles of at most 96 source columns each that accumulate with atomics; launchLevels takes
+      // that list when the launch (tiles x batch) stays within a round of workgroups.
+      vector<UpdTaskWide> split;
+      auto addSplit = [&](const vector<LevelRange>& levels) {
+        for (const LevelRange& lr : levels) {
+          const int64_t n = lr.updEnd - lr.updBegin;
+          if (lr.directPanel >= 0 || n <= 0 || n > kSplitMaxTiles) continue;
+          int64_t extra = 0;
+          for (int64_t i = lr.updBegin; i < lr.updEnd; i++) {
+            if (wide[i].K >= kSplitMinK) extra += (wide[i].K + kSplitK - 1) / kSplitK - 1;
+          }
+          if (extra == 0 || n + extra > 2 * kSplitMaxTiles) continue;
+          const int64_t b = (int64_t)split.size();
+          for (int64_t i = lr.updBegin; i < lr.updEnd; i++) {
+            const UpdTaskWide& w = wide[i];
+            if (w.K < kSplitMinK) {
+              split.push_back(w);
+              continue;
+            }
+            for (int32_t k0 = 0; k0 < w.K; k0 += kSplitK) {
+              UpdTaskWide p = w;
+              p.srcOff = w.srcOff + k0;
+              p.K = std::min<int32_t>(kSplitK, w.K - k0);
+              p.atomic = w.atomic | 1;
+              split.push_back(p);
+            }
+          }
+          splitRange[lr.updBegin] = {b, (int64_t)split.size()};
+        }
+      };
+      for (const auto& er : host.elimRanges) addSplit(er.bigLevels);
+      addSplit(host.levels);
+      updTasksSplit.upload(split);
     }
     elimChainLump.upload(host.elimChainLump);
     elimLumpDesc.upload(host.elimLumpDesc);
@@ -364,6 +408,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_SOLVE_INV")) solveInv = e[0] != '0';
     if (const char* e = std::getenv("BSP_SUB_BATCH_MIN")) subBatchMin = std::max(2, std::atoi(e));
     if (const char* e = std::getenv("BSP_SUB_BATCHES")) subBatchParts = std::max(2, std::atoi(e));
+    if (const char* e = std::getenv("BSP_SPLIT_K")) splitK = e[0] != '0';
     // the plan builder's switches: read here, once per Solver, handed to every buildHipPlan call
     // and recorded in the plan; launchLevels takes dueStream from the plan it runs
     planOpts = HipPlanOptions::fromEnv();
@@ -606,6 +651,8 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipPlanOptions planOpts;     // the plan builder's switches (BSP_DUE_STREAM, BSP_BULK_AHEAD, ...)
   double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
+  bool splitK = true;       // split-K tile lists for small multi-panel levels (BSP_SPLIT_K=0: off)
+  static constexpr int64_t splitKMaxWgs = 1024;  // ... launches of at most this many workgroups (a batch of 8: 2.26 = 2.26 ms at 1024, 2.48 at 4096)
   int subBatchMin = 16;     // batches of at least this many matrices are factored as concurrent sub-batches (BSP_SUB_BATCH_MIN; 0x7fffffff: never)
   int subBatchParts = 2;    // ... this many (BSP_SUB_BATCHES, at most 4, at least subBatchMin / 2 matrices each)
   vector<hipEvent_t> events;
@@ -911,7 +958,18 @@ struct HipNumericCtx : NumericCtx<T> {
               plan.host.srcs[sd.src], sd, (int)nUpd, ref, stage ? rawNext : nullptr, nextPanel.nb,
               2 * rawSlot);
         } else {
-          launchUpdate(plan, updBegin, lr.updEnd, ref, sym.stream);
+          auto sp = sym.splitK ? plan.splitRange.find(updBegin) : plan.splitRange.end();
+          if (sp != plan.splitRange.end() &&
+              (sp->second.second - sp->second.first) * (int64_t)batchSize <= sym.splitKMaxWgs) {
+            // (one round of workgroups at most: the K slices of a tile run side by side)
+            hipk::updateTile<BT, true><<<dim3((unsigned)(sp->second.second - sp->second.first),
+                                              (unsigned)batchSize), 256, 0, sym.stream>>>(
+                plan.updTasksSplit.as<UpdTaskWide>() + sp->second.first, plan.chainOffTab.as<int64_t>(),
+                plan.rowChain.as<int32_t>(), plan.rowLocal.as<int32_t>(), plan.rowColOff.as<int32_t>(), ref,
+                nullptr, 0, 1);
+          } else {
+            launchUpdate(plan, updBegin, lr.updEnd, ref, sym.stream);
+          }
         }
         timer.end();
       }

@@ -1,9 +1,12 @@
 """Mixed-precision solve: fp32 factor on the GPU + fp64 iterative refinement (BASELINE config 5).
 
 The reference's analogue is the fp32-factor preconditioner of its PCG example
-(examples/Preconditioner.h:141-206, LowerPrecSolvePrecond).  Everything numeric is the library:
-factor<float>, solve<float>, and the fp64 residual r = b - A x through Solver::addMvFrom
-(Solver.h:89-91) on the un-factored fp64 matrix; torch only holds the vectors."""
+(examples/Preconditioner.h:141-206, LowerPrecSolvePrecond).  The three heavy steps are library
+kernels -- factor<float>, solve<float>, and the fp64 residual r = b - A x through Solver::addMvFrom
+(Solver.h:89-91) on the un-factored fp64 matrix.  The glue around them is torch: the fp64 <-> fp32
+casts of the correction, the update x += d, the copy of b into r before addMvFrom, and the two norms
+of the stopping test (O(order) element-wise work per iteration, against O(factor size) in the solve
+and the residual)."""
 import torch
 
 

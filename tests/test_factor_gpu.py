@@ -348,6 +348,34 @@ def test_schedule_variants(monkeypatch, knob):
     assert np.linalg.norm((got - ref)[mask]) / np.linalg.norm(ref[mask]) < 1e-12
 
 
+@pytest.mark.parametrize("split", ["1", "0"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_split_k_tiles_of_small_levels(monkeypatch, split, dtype):
+    """round 5: the block-wide update tiles (K = 128 .. 256) of a small multi-panel level are listed again
+    as slices of at most 96 source columns that accumulate with atomics (BSP_SPLIT_K=0: one tile each).
+    Four independent dense blocks of 130 / 130 / 200 / 200 parameters over a common separator: the
+    levels hold four or two panels, the block-closing ones update the separator with K = 130 / 200."""
+    monkeypatch.setenv("BSP_SPLIT_K", split)
+    widths, sep = [130, 130, 200, 200], 150
+    n = sum(widths) + sep
+    cols, base = [], 0
+    for w in widths:
+        for i in range(w):
+            cols.append(set(range(base + i, base + w)) | set(range(n - sep, n)))
+        base += w
+    for i in range(sep):
+        cols.append(set(range(n - sep + i, n)))
+    sol = B.create_solver(B.Settings(), np.ones(n, dtype=np.int64), T.columns_to_structure(cols))
+    for bs in (1, 3):
+        datas = [spd_data(sol, 70 + q, beta_factor=1.2) for q in range(bs)]
+        devs = [to_dev(d.astype(dtype)) for d in datas]
+        sol.factor(devs if bs > 1 else devs[0])
+        for q in range(bs):
+            _, A = dense_lower_chol(sol, datas[q])
+            Lg = lower_of(sol, devs[q].cpu().numpy()).astype(np.float64)
+            assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < (1e-10 if dtype == np.float64 else 5e-5), q
+
+
 @pytest.mark.parametrize("ahead", ["0", "0.6", "100"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_lookahead_units_over_many_outer_blocks(monkeypatch, ahead, dtype):
