@@ -1,11 +1,11 @@
-"""README table of `python bench.py --suite ref` (profiles/r04_ref_suite.json: medians over five instances per family) beside the reference's
+"""README table of `python bench.py --suite ref` (profiles/r05_ref_suite.json: medians over five instances per family) beside the reference's
 published timings (profiles/published_reference_results.json).  usage: python tools/make_suite_table.py [suite.json]"""
 import json
 import os
 import sys
 
 here = os.path.dirname(os.path.abspath(__file__))
-path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "profiles", "r04_ref_suite.json")
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "profiles", "r05_ref_suite.json")
 d = json.load(open(path))
 ms = lambda s: "%.2f" % (1e3 * s) if s is not None else "-"
 print("| problem (Bench.cpp:290-367) | order | GF | first / warm factor ms | TF/s | batch-16 ms/matrix | solve-1 / solve-10 ms | "
