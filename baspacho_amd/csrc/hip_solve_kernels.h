@@ -285,6 +285,28 @@ __global__ __launch_bounds__(256) void solveElimGatherL(const SolveGatherItem* i
   }
 }
 
+// sums over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15) by row rotations: vector-ALU
+// instructions, no LDS crossbar (a __shfl is a ds_bpermute: ~14 clocks of a CU's crossbar each)
+template <int N>
+__device__ __forceinline__ double rowRorT(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ float rowRorT(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), in every lane of the row
+template <typename T>
+__device__ __forceinline__ T rowSum16(T v) {
+  v += rowRorT<8>(v);
+  v += rowRorT<4>(v);
+  v += rowRorT<2>(v);
+  v += rowRorT<1>(v);
+  return v;
+}
+
 // K-S3: backward pass over a range of <= 4-wide lumps: x_l <- L_ll^-T (x_l - sum_blocks B^T y).
 // 16 lanes per lump (four lumps per wave): lane (k, ip) = (sub & 3, sub >> 2) walks rows
 // ip, ip+4, ... of every block and column k, so that the 16 lanes read 12 consecutive values per
@@ -325,6 +347,8 @@ __global__ __launch_bounds__(256) void solveElimLumpsLt(const SolveLumpDesc* des
     allFast = allFast && ((slow >> grp) & 0xffffull) == 0;
     if (!allFast) break;
     const int passB = min(16, nBlocks - b0);
+    // (round 5, measured: y by two direct loads per block instead of one load + two lane gathers 299
+    //  against 270 us; the descriptor by a load per block instead of four lane broadcasts too: 300)
     for (int e = 0; e < passB; e++) {
       const int64_t off = (int64_t)__shfl((int)(myB.dataOff >> 32), grp + e, 64) << 32 |
                           (uint32_t)__shfl((int)(uint32_t)myB.dataOff, grp + e, 64);
@@ -337,15 +361,15 @@ __global__ __launch_bounds__(256) void solveElimLumpsLt(const SolveLumpDesc* des
       c1 += v1 * __shfl(yv, grp + min(15, (sub + 16) / n), 64);
     }
   }
+  T colSum[4];  // column sums of the lump, in every lane of its group
   if (allFast) {
-    // column k of the sum: the lanes whose element index is k modulo n
-    T colSum = T(0);
+    // column j of the sum: the lanes whose element index is j modulo n.  Round 5: DPP row sums instead
+    // of 32 broadcasts per lump -- the kernel was bound by ds_bpermute (64 of its 87 per wave sat here)
 #pragma unroll
-    for (int s2 = 0; s2 < 16; s2++) {
-      const T p0 = __shfl(c0, grp + s2, 64), p1 = __shfl(c1, grp + s2, 64);
-      colSum += (s2 % n == k ? p0 : T(0)) + ((s2 + 16) % n == k ? p1 : T(0));
+    for (int j = 0; j < 4; j++) {
+      const T p = (sub % n == j ? c0 : T(0)) + ((sub + 16) % n == j ? c1 : T(0));
+      colSum[j] = rowSum16(p);
     }
-    acc = T(0.25) * colSum;  // (the reduction below adds the four lanes ip = 0..3 of a column)
   } else {
     acc = T(0);
     for (int e = ld.blockBegin; e < ld.blockEnd; e++) {
@@ -360,15 +384,17 @@ __global__ __launch_bounds__(256) void solveElimLumpsLt(const SolveLumpDesc* des
         acc += va * ya + vb * yb;
       }
     }
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);  // every lane: the sum for its column k
+#pragma unroll
+    for (int j = 0; j < 4; j++) colSum[j] = __shfl(acc, grp + j, 64);
   }
-  acc += __shfl_xor(acc, 4, 64);
-  acc += __shfl_xor(acc, 8, 64);  // every lane: the sum for its column k
   // back substitution with the upper triangle L^T, redundantly in every lane of the group
   T x[4], d[4][4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const T xj = j < n ? vec[ld.xOff + j] : T(0);
-    x[j] = xj - __shfl(acc, grp + j, 64);
+    x[j] = xj - colSum[j];
 #pragma unroll
     for (int i = 0; i < 4; i++) d[i][j] = (i < n && j <= i) ? data[ld.diagOff + i * n + j] : (i == j ? T(1) : T(0));
   }
@@ -391,26 +417,6 @@ __global__ __launch_bounds__(256) void solveElimLumpsLt(const SolveLumpDesc* des
 // (the 16 lanes together read the contiguous block), its y with one load per right-hand side, no
 // shuffle inside the loop; the column sums over the rows are DPP row rotations (vector ALU, no LDS),
 // and blocks of more than 16 rows simply take several passes.
-template <int N>
-__device__ __forceinline__ double rowRorT(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-template <int N>
-__device__ __forceinline__ float rowRorT(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
-}
-// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), in every lane of the row
-template <typename T>
-__device__ __forceinline__ T rowSum16(T v) {
-  v += rowRorT<8>(v);
-  v += rowRorT<4>(v);
-  v += rowRorT<2>(v);
-  v += rowRorT<1>(v);
-  return v;
-}
-
 template <typename T, int RB>
 __global__ __launch_bounds__(256) void solveElimLumpsLtMulti(const SolveLumpDesc* descs,
                                                              const SolveLumpBlock* blocks,
