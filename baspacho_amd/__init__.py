@@ -53,6 +53,12 @@ class _CPlanStats(ctypes.Structure):
                [("deferred_flops", ctypes.c_double)]
 
 
+class _CRunCounters(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in
+                ["sweep_launches", "sweep_timeouts", "split_lists_used", "sub_batches_enqueued",
+                 "lookahead_forks", "sweeps_retired", "sweep_error_pending"]]
+
+
 @dataclass
 class Settings:
     """Solver.h:212-218"""
@@ -466,6 +472,13 @@ class Solver:
         st = _CPlanStats()
         _check(self._lib.bsp_plan_stats_full(self._h, ctypes.byref(st)))
         return {n: getattr(st, n) for n, _ in _CPlanStats._fields_}
+
+    def runCounters(self):
+        """what the calls on this solver actually ran (bsp_run_counters_get): persistent sweeps
+        launched / timed out, split-K lists used, sub-batches enqueued, lookahead forks"""
+        st = _CRunCounters()
+        _check(self._lib.bsp_run_counters_get(self._h, ctypes.byref(st)))
+        return {n: getattr(st, n) for n, _ in _CRunCounters._fields_}
 
     def factorProfiled(self, data, in_situ=False, busy=False):
         """one factor() with every launch bracketed by HIP events; returns {kernel class: (total

@@ -271,6 +271,12 @@ int bsp_force_per_op(bsp_solver* s, int32_t on) {
   BSP_CATCH
 }
 
+int bsp_test_read_sweep_trace(bsp_solver* s, long long* out, int32_t max_blocks, int32_t* n_blocks) {
+  BSP_TRY
+  *n_blocks = hipBackendReadSweepTrace(s->solver->internalSymbolicContext(), out, max_blocks);
+  BSP_CATCH
+}
+
 int bsp_test_set_fault(bsp_solver* s, int32_t kind) {
   BSP_TRY
   hipBackendSetFault(s->solver->internalSymbolicContext(), kind);
@@ -591,6 +597,19 @@ int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out) {
   out->num_gather_groups = p.numGatherGroups;
   out->num_fork_levels = p.numForkLevels;
   out->deferred_flops = p.deferredFlops;
+  BSP_CATCH
+}
+
+int bsp_run_counters_get(bsp_solver* s, bsp_run_counters* out) {
+  BSP_TRY
+  const HipRunCounters c = hipBackendRunCounters(s->solver->internalSymbolicContext());
+  out->sweep_launches = c.sweepLaunches;
+  out->sweep_timeouts = c.sweepTimeouts;
+  out->split_lists_used = c.splitListsUsed;
+  out->sub_batches_enqueued = c.subBatchesEnqueued;
+  out->lookahead_forks = c.lookaheadForks;
+  out->sweeps_retired = c.sweepsRetired;
+  out->sweep_error_pending = c.sweepErrorPending;
   BSP_CATCH
 }
 

@@ -63,6 +63,22 @@ void hipBackendForcePerOp(SymbolicCtx& sym, bool on);
 // Never read from the environment: a leaked variable cannot corrupt a caller's factor.
 void hipBackendSetFault(SymbolicCtx& sym, int kind);
 
+// what the calls on this Solver actually ran (cumulative): lets a test see that the path it means
+// to test was taken, and a caller poll for a watchdog report without waiting for the next solve
+struct HipRunCounters {
+  int64_t sweepLaunches = 0;       // persistent solve sweeps launched (hip_sweep_kernels.h)
+  int64_t sweepTimeouts = 0;       // ... that ran into their watchdog (reported by a later call)
+  int64_t splitListsUsed = 0;      // update launches that took a split-K tile list
+  int64_t subBatchesEnqueued = 0;  // sub-batches enqueued on their own stream
+  int64_t lookaheadForks = 0;      // lookahead launches handed to the auxiliary streams
+  int64_t sweepsRetired = 0;       // 1: a time-out retired the sweeps of this Solver
+  int64_t sweepErrorPending = 0;   // 1: a time-out has been raised and not been reported yet
+};
+HipRunCounters hipBackendRunCounters(SymbolicCtx& sym);
+// developer aid (BSP_SWEEP_TRACE=1 when the Solver is created): clock stamps {start, operands on chip,
+// inputs arrived, x published} (100 MHz) of every spine workgroup of the LAST persistent sweep
+int hipBackendReadSweepTrace(SymbolicCtx& sym, long long* out, int maxBlocks);
+
 // per level of the plan (host only): {elimination range or -1, panels, widest panel, most rows below a
 // panel, trsm tasks, update tiles, lookahead tiles, rows below summed over the panels}
 std::vector<int64_t> hipBackendPlanLevels(SymbolicCtx& sym, int64_t startLump, int64_t upToLump);

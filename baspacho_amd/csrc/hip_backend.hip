@@ -14,6 +14,7 @@
 #include "hip_backend.h"
 #include "hip_kernels.h"
 #include "hip_solve_kernels.h"
+#include "hip_sweep_kernels.h"
 #include "mat_ops.h"
 
 namespace BaSpaCho {
@@ -62,18 +63,35 @@ struct DevBuf {
 
 // block solves through inverted diagonal blocks (denseLevels): per level list of a plan, the panels
 // whose diagonal blocks are inverted (built and uploaded on the first solve)
+// one step of the dense part of a solve (denseLevels): a level, a block group of a wide lump (K-B1i /
+// K-B2, two launches per 256 columns) or a whole run of one-panel levels as ONE persistent sweep
+// (hip_sweep_kernels.h)
+struct SolveSchedItem {
+  enum Kind : int32_t { kLevel = 0, kBlockGroup = 1, kSweep = 2 };
+  int32_t kind = kLevel;
+  int32_t slot = -1;  // first slot in the inverse scratch (block groups through inverses, sweeps)
+  int64_t l = 0, e = 0;  // levels [l, e)
+  hipk::SweepDesc sweep{};
+  int32_t sweepFwdWgs = 0, sweepBwdWgs = 0;
+};
+// per level list of a plan and schedule mode (0: levels + block groups, 1: with sweeps): the steps,
+// and the panels whose diagonal blocks are inverted (built and uploaded on the first solve)
 struct SolveInvList {
   bool built = false;
   int64_t count = 0;
   DevBuf list;
-  vector<int32_t> slotOfGroup;
+  vector<SolveSchedItem> items;
+  int32_t numSweeps = 0;
+  int64_t sweepInstStride = 0;  // values per (right-hand side, batch entry) of the exchange buffer
+  int64_t maxSweepWgs = 0;
+  int32_t maxSweepW = 0, maxSweepBelow = 0;
 };
 
 struct DevPlan {
   HipPlanHost host;
   // keyed by the address of a level list that lives inside `host` (host.levels, an elimination
   // range's bigLevels): the entries die with the plan, an address is never reused under them
-  std::map<const void*, SolveInvList> solveInvLists;
+  std::map<std::pair<const void*, int>, SolveInvList> solveInvLists;
   DevBuf panels, levelPanelDescs, trsmTasksFat, chainOffTab, rowChain, rowLocal, rowColOff, levelPanels, trsmTasks,
       updTasksFat, updTasksWide, elimChainLump, elimItems, elimPairOffJ, elimPairOffI, rowGlobal, elimLumpDesc;
   int64_t numUpdTasks = 0;
@@ -409,6 +427,9 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_SUB_BATCH_MIN")) subBatchMin = std::max(2, std::atoi(e));
     if (const char* e = std::getenv("BSP_SUB_BATCHES")) subBatchParts = std::max(2, std::atoi(e));
     if (const char* e = std::getenv("BSP_SPLIT_K")) splitK = e[0] != '0';
+    if (const char* e = std::getenv("BSP_SOLVE_SWEEP")) sweepEnabled = e[0] != '0';
+    if (const char* e = std::getenv("BSP_SWEEP_MIN_WIDTH")) sweepMinWidth = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("BSP_SWEEP_TRACE")) sweepTraceOn = e[0] != '0';
     // the plan builder's switches: read here, once per Solver, handed to every buildHipPlan call
     // and recorded in the plan; launchLevels takes dueStream from the plan it runs
     planOpts = HipPlanOptions::fromEnv();
@@ -417,6 +438,7 @@ struct HipSymbolicCtx : SymbolicCtx {
 
   virtual ~HipSymbolicCtx() override {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    if (sweepHostErr) (void)hipHostFree(sweepHostErr);
   }
 
   virtual void setSparseElimRanges(const vector<int64_t>& ranges) override {
@@ -451,6 +473,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     rawScratch.release();
     yieldBuf.release();
     solveInvScratch.release();
+    sweepXchg.release();
     for (DevBuf* b : {&dSpanStart, &dSpanToLump, &dLumpStart, &dSpanOffsetInLump, &dChainColPtr,
                       &dChainRowSpan, &dChainData, &dChainRowsTillEnd, &dBoardColPtr,
                       &dBoardChainColOrd, &dPermutation}) {
@@ -458,6 +481,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     }
     skelUploaded = false;
     shared = nullptr;
+    sweepAttr[0] = sweepAttr[1] = 0;
   }
 
   // The reference builds its SymbolicCtx and every SymElimCtx in the Solver constructor
@@ -669,6 +693,70 @@ struct HipSymbolicCtx : SymbolicCtx {
   // per level list the panels whose diagonal blocks are inverted (uploaded once)
   DevBuf solveInvScratch;
   bool solveInv = true;  // BSP_SOLVE_INV=0: the substitution kernels of rounds 1-2
+  // ---- persistent sweeps over wide lumps (hip_sweep_kernels.h, round 6)
+  bool sweepEnabled = true;   // BSP_SOLVE_SWEEP=0: the multi-launch block path
+  int sweepMinWidth = 768;    // runs of one-panel levels at least this wide (BSP_SWEEP_MIN_WIDTH)
+  bool sweepBroken = false;   // a sweep timed out or cannot be launched here: multi-launch path for good
+  int sweepFault = 0;         // TESTING (bsp_test_set_fault kind 2): spine of block 1 never publishes
+  double sweepSpinLimitS = 2.0;  // watchdog: a spin that lasts longer aborts the launch
+  DevBuf sweepXchg;           // control words + exchange values of one denseLevels call
+  DevBuf sweepTrace;          // developer aid (BSP_SWEEP_TRACE=1): clock stamps of the spines of the last sweep
+  bool sweepTraceOn = false;
+  unsigned* sweepHostErr = nullptr;     // pinned host word a timed-out sweep raises ...
+  unsigned* sweepHostErrDev = nullptr;  // ... and its device alias
+  int sweepCapacity = 0;      // workgroups of a sweep launch that are resident at once (one per CU)
+  size_t sweepMaxLds = 0;
+  int sweepAttr[2] = {0, 0};  // per value size (8, 4): 0 not tried, 1 ready, -1 failed
+  struct RunCounters {
+    int64_t sweepLaunches = 0, sweepTimeouts = 0, splitListsUsed = 0, subBatchesEnqueued = 0,
+            lookaheadForks = 0;
+  } counters;
+  // a timed-out sweep is reported ONCE, by the next call that would have used one
+  bool sweepUsable() {
+    if (!sweepEnabled || sweepBroken || !solveInv || !blockSolve) return false;
+    if (sweepHostErr && *reinterpret_cast<volatile unsigned*>(sweepHostErr) != 0u) {
+      *reinterpret_cast<volatile unsigned*>(sweepHostErr) = 0u;
+      sweepBroken = true;
+      counters.sweepTimeouts++;
+      throw std::runtime_error(
+          "HIP backend: a persistent solve sweep of an EARLIER call on this Solver timed out (watchdog); "
+          "the result of that call is invalid.  The sweeps are retired for this Solver: solves take "
+          "the multi-launch path from now on");
+    }
+    return true;
+  }
+  template <typename BT>
+  bool sweepReady() {
+    int& st = sweepAttr[sizeof(BT) == 8 ? 0 : 1];
+    if (st == 0) {
+      st = -1;
+      checkDevice();
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        sweepCapacity = prop.multiProcessorCount;
+        sweepMaxLds = std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor, 160 * 1024) - 1024;
+        const int lds = (int)sweepMaxLds;
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&hipk::solveSweep<BT, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&hipk::solveSweep<BT, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        if (ok && !sweepHostErr) {
+          void* hp = nullptr;
+          ok = hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess;
+          if (ok) {
+            sweepHostErr = reinterpret_cast<unsigned*>(hp);
+            *sweepHostErr = 0u;
+            void* dp = nullptr;
+            ok = hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess;
+            sweepHostErrDev = reinterpret_cast<unsigned*>(dp);
+          }
+        }
+        if (ok) st = 1;
+      }
+      if (st < 0) (void)hipGetLastError();
+    }
+    return st > 0;
+  }
 #ifndef BSP_UPD_PREFETCH_MAX_WGS
 #define BSP_UPD_PREFETCH_MAX_WGS 2048
 #endif
@@ -865,6 +953,7 @@ struct HipNumericCtx : NumericCtx<T> {
         hipEvent_t fork = sym.eventFromPool();
         hipCHECK(hipEventRecord(fork, sym.stream));
         hipCHECK(hipStreamWaitEvent(sym.sideStream(), fork, 0));
+        sym.counters.lookaheadForks++;
         // first the tiles the next block's own update must wait for, then (event) the rest:
         // the side stream keeps running them while the chain goes on, and the next block's
         // deferred tiles queue up right behind
@@ -962,6 +1051,7 @@ struct HipNumericCtx : NumericCtx<T> {
           if (sp != plan.splitRange.end() &&
               (sp->second.second - sp->second.first) * (int64_t)batchSize <= sym.splitKMaxWgs) {
             // (one round of workgroups at most: the K slices of a tile run side by side)
+            sym.counters.splitListsUsed++;
             hipk::updateTile<BT, true><<<dim3((unsigned)(sp->second.second - sp->second.first),
                                               (unsigned)batchSize), 256, 0, sym.stream>>>(
                 plan.updTasksSplit.as<UpdTaskWide>() + sp->second.first, plan.chainOffTab.as<int64_t>(),
@@ -1108,6 +1198,7 @@ struct HipNumericCtx : NumericCtx<T> {
         batchSize = b1 - b0;
         sym.stream = g ? sym.streams().batch[g - 1] : mainStream;
         if (g) hipCHECK(hipStreamWaitEvent(sym.stream, fork, 0));
+        sym.counters.subBatchesEnqueued++;
         hipk::DataRef<BT> sub{nullptr, ref.many + subBatchBase};
         for (const ElimRangePlan& er : plan.host.elimRanges) launchElim(plan, er, sub, timer);
         launchLevels(plan, plan.host.levels, sub, timer);
@@ -1405,81 +1496,184 @@ struct HipSolveCtx : SolveCtx<T> {
     }
   }
 
-  // consecutive one-panel levels that make up one outer block of a wide lump are solved as a
-  // block: 2 launches per 256 columns instead of 8
-  vector<std::pair<int64_t, int64_t>> levelGroups(DevPlan& plan, const vector<LevelRange>& levels) {
+  // The steps of a level list.  Consecutive one-panel levels that make up one outer block of a wide
+  // lump are solved as a block (2 launches per 256 columns instead of 8); withSweeps: a run of
+  // one-panel levels of one lump that is at least sweepMinWidth columns wide is ONE persistent launch.
+  void buildSchedule(DevPlan& plan, const vector<LevelRange>& levels, bool withSweeps,
+                     SolveInvList& ent) {
     static_assert(hipk::kSolveBlock == kOuterWidth, "block solve steps = outer blocks of the plan");
     const int64_t nL = (int64_t)levels.size();
-    vector<std::pair<int64_t, int64_t>> groups;
+    vector<PanelDesc> list;
+    const bool inverses = sym.solveInv && sym.blockSolve;
+    auto colOf = [&](const PanelDesc& p) { return p.lda - p.nRest - p.nb; };  // column inside its lump
     for (int64_t l = 0; l < nL;) {
-      int64_t e = l + 1;
+      SolveSchedItem it;
+      it.l = l;
+      it.e = l + 1;
+      if (withSweeps && levels[l].directPanel >= 0) {
+        const PanelDesc& p0 = plan.host.panels[levels[l].directPanel];
+        int64_t e = l + 1;
+        int w = p0.nb;
+        while (e < nL && levels[e].directPanel >= 0) {
+          const PanelDesc& pe = plan.host.panels[levels[e].directPanel];
+          if (pe.lump != p0.lump || colOf(pe) != colOf(p0) + w) break;
+          if (plan.host.panels[levels[e - 1].directPanel].nb != kPanelWidth) break;
+          w += pe.nb;
+          e++;
+        }
+        if (w >= sym.sweepMinWidth) {
+          const PanelDesc& last = plan.host.panels[levels[e - 1].directPanel];
+          it.kind = SolveSchedItem::kSweep;
+          it.e = e;
+          it.slot = (int32_t)list.size();
+          hipk::SweepDesc& sd = it.sweep;
+          sd.diagOff = p0.diagOff;
+          sd.lda = p0.lda;
+          sd.w = w;
+          sd.rowsBelow = last.rowsBelow;
+          sd.nRest = last.nRest;
+          sd.lumpRowBase = last.lumpRowBase;
+          sd.vecOff = p0.vecOff;
+          sd.nBlocks = (w + hipk::kSweepW - 1) / hipk::kSweepW;
+          sd.invSlot = it.slot;
+          sd.xchgOff = (int32_t)ent.sweepInstStride;
+          sd.ticketOff = 0;  // (set per call: depends on the number of instances)
+          ent.sweepInstStride += 2 * (int64_t)sd.nBlocks * hipk::kSweepW;
+          it.sweepFwdWgs = hipk::kSweepFwdGroup * sd.nBlocks +
+                           (sd.rowsBelow + hipk::kSweepFarRows - 1) / hipk::kSweepFarRows;
+          it.sweepBwdWgs = hipk::kSweepBwdGroup * sd.nBlocks;
+          ent.maxSweepWgs = std::max<int64_t>(ent.maxSweepWgs, std::max(it.sweepFwdWgs, it.sweepBwdWgs));
+          ent.maxSweepW = std::max(ent.maxSweepW, sd.w);
+          ent.maxSweepBelow = std::max(ent.maxSweepBelow, sd.rowsBelow);
+          ent.numSweeps++;
+          for (int64_t q = l; q < e; q++) list.push_back(plan.host.panels[levels[q].directPanel]);
+          ent.items.push_back(it);
+          l = e;
+          continue;
+        }
+      }
       if (sym.blockSolve && levels[l].directPanel >= 0) {
         const PanelDesc& p0 = plan.host.panels[levels[l].directPanel];
-        const int c0 = p0.lda - p0.nRest - p0.nb;  // column of the panel inside its lump
+        const int c0 = colOf(p0);
         if (c0 % kOuterWidth == 0) {
+          int64_t e = l + 1;
           while (e < nL && levels[e].directPanel >= 0) {
             const PanelDesc& pe = plan.host.panels[levels[e].directPanel];
-            const int ce = pe.lda - pe.nRest - pe.nb;
+            const int ce = colOf(pe);
             if (pe.lump != p0.lump || ce != c0 + (int)(e - l) * kPanelWidth || ce >= c0 + kOuterWidth) {
               break;
             }
             e++;
           }
+          it.e = e;
         }
       }
-      groups.emplace_back(l, e);
-      l = e;
+      if (it.e - it.l >= 2) {
+        it.kind = SolveSchedItem::kBlockGroup;
+        if (inverses) {
+          it.slot = (int32_t)list.size();
+          for (int64_t q = it.l; q < it.e; q++) list.push_back(plan.host.panels[levels[q].directPanel]);
+        }
+      }
+      ent.items.push_back(it);
+      l = it.e;
     }
-    return groups;
+    ent.count = (int64_t)list.size();
+    if (ent.count) ent.list.upload(list);
+    ent.built = true;
+  }
+
+  // may this call run the sweeps of `ent`?  Every workgroup of a sweep launch should be resident at
+  // once (correct either way -- roles are dealt by ticket -- but a far role that starts late has a
+  // whole row strip to catch up on at one CU's bandwidth), and its LDS must fit.
+  bool sweepsFit(const SolveInvList& ent) {
+    if (ent.numSweeps == 0) return false;
+    if (!sym.sweepReady<BT>()) return false;
+    const int64_t inst = (int64_t)nRHS * batch;
+    if (ent.maxSweepWgs * inst > sym.sweepCapacity) return false;
+    const size_t lds = std::max(hipk::sweepLdsBytes<BT>(ent.maxSweepW, ent.maxSweepBelow, false),
+                                hipk::sweepLdsBytes<BT>(ent.maxSweepW, ent.maxSweepBelow, true));
+    return lds <= sym.sweepMaxLds;
   }
 
   template <bool BACKWARD>
   void denseLevels(DevPlan& plan, const vector<LevelRange>& levels, hipk::SolveRef<BT> ref) {
-    const vector<std::pair<int64_t, int64_t>> groups = levelGroups(plan, levels);
-    const int64_t nG = (int64_t)groups.size();
+    // schedule: with persistent sweeps when the plan has wide runs and this call fits the GPU
+    SolveInvList* entp = nullptr;
+    if (sym.sweepUsable()) {
+      SolveInvList& es = plan.solveInvLists[{&levels, 1}];
+      if (!es.built) buildSchedule(plan, levels, true, es);
+      if (sweepsFit(es)) entp = &es;
+    }
+    if (!entp) {
+      SolveInvList& eo = plan.solveInvLists[{&levels, 0}];
+      if (!eo.built) buildSchedule(plan, levels, false, eo);
+      entp = &eo;
+    }
+    SolveInvList& ent = *entp;
+    const bool sweeps = ent.numSweeps > 0 && entp == &plan.solveInvLists[{&levels, 1}];
+    const int64_t nG = (int64_t)ent.items.size();
     // round 3 (BSP_SOLVE_INV=0 disables): the block triangles through inverted 64 x 64 diagonal
-    // blocks -- one launch inverts the diagonal block of every panel of every block group (the list
-    // of those panels is built and uploaded once per level list), the block kernel then needs one
-    // round trip (hip_solve_kernels.h, K-B0 / K-B1i)
+    // blocks -- one launch inverts the diagonal block of every panel of every block group and sweep
+    // (the list of those panels is built and uploaded once per level list), the block kernel then
+    // needs one round trip (hip_solve_kernels.h, K-B0 / K-B1i).  Round 6: the same launch arms the
+    // exchange buffer of the sweeps.
     const BT* invBase = nullptr;
     int64_t invBatchStride = 0;
-    const vector<int32_t>* invSlot = nullptr;
-    if (sym.solveInv && sym.blockSolve) {  // (blockSolve off: one-off level lists of the per-op path)
-      auto& ent = plan.solveInvLists[&levels];
-      if (!ent.built) {
-        vector<PanelDesc> list;
-        ent.slotOfGroup.assign(groups.size(), -1);
-        for (size_t g = 0; g < groups.size(); g++) {
-          if (groups[g].second - groups[g].first < 2) continue;
-          ent.slotOfGroup[g] = (int32_t)list.size();
-          for (int64_t l = groups[g].first; l < groups[g].second; l++) {
-            list.push_back(plan.host.panels[levels[l].directPanel]);
-          }
+    BT* xchg = nullptr;
+    hipk::SweepShared sh{};
+    const int64_t nInst = (int64_t)nRHS * batch;
+    if (ent.count > 0) {
+      invBatchStride = ent.count * kPanelWidth * kPanelWidth;
+      sym.solveInvScratch.resize((size_t)(invBatchStride * batch) * sizeof(BT));
+      BT* scratch = const_cast<BT*>(sym.solveInvScratch.as<BT>());
+      unsigned long long* arm = nullptr;
+      int64_t armWords = 0;
+      if (sweeps) {
+        const size_t ctlBytes = (((size_t)(1 + ent.numSweeps * nInst) * sizeof(unsigned)) + 255) / 256 * 256;
+        const size_t bytes = (ctlBytes + (size_t)(nInst * ent.sweepInstStride) * sizeof(BT) + 7) / 8 * 8;
+        sym.sweepXchg.resize(bytes);
+        arm = reinterpret_cast<unsigned long long*>(sym.sweepXchg.ptr);
+        armWords = (int64_t)(bytes / 8);
+        xchg = reinterpret_cast<BT*>(reinterpret_cast<char*>(sym.sweepXchg.ptr) + ctlBytes);
+        sh.ctl = reinterpret_cast<unsigned*>(sym.sweepXchg.ptr);
+        sh.hostErr = sym.sweepHostErrDev;
+        sh.spinLimit = (long long)(sym.sweepSpinLimitS * 1e8);
+        sh.instStride = ent.sweepInstStride;
+        sh.fault = sym.sweepFault;
+        sh.pad = 0;
+        sh.trace = nullptr;
+        if (sym.sweepTraceOn) {
+          sym.sweepTrace.resize(4 * 4096 * sizeof(long long));
+          sh.trace = reinterpret_cast<long long*>(sym.sweepTrace.ptr);
         }
-        ent.count = (int64_t)list.size();
-        if (ent.count) ent.list.upload(list);
-        ent.built = true;
       }
-      if (ent.count > 0) {
-        invBatchStride = ent.count * kPanelWidth * kPanelWidth;
-        sym.solveInvScratch.resize((size_t)(invBatchStride * batch) * sizeof(BT));
-        BT* scratch = const_cast<BT*>(sym.solveInvScratch.as<BT>());
-        hipk::solveInvertPanels<BT><<<dim3((unsigned)ent.count, 1, (unsigned)batch), 64, 0, sym.stream>>>(
-            ent.list.as<PanelDesc>(), scratch, invBatchStride, ref);
-        invBase = scratch;
-        invSlot = &ent.slotOfGroup;
-      }
+      hipk::solveInvertPanels<BT><<<dim3((unsigned)ent.count, 1, (unsigned)batch), 64, 0, sym.stream>>>(
+          ent.list.as<PanelDesc>(), scratch, invBatchStride, ref, arm, armWords);
+      invBase = scratch;
     }
+    int32_t sweepOrd = 0;
     for (int64_t gi = 0; gi < nG; gi++) {
       const int64_t gIdx = BACKWARD ? nG - 1 - gi : gi;
-      const auto& grp = groups[gIdx];
-      if (grp.second - grp.first >= 2) {
-        const PanelDesc& first = plan.host.panels[levels[grp.first].directPanel];
-        const PanelDesc& last = plan.host.panels[levels[grp.second - 1].directPanel];
-        const int w = (int)(grp.second - 1 - grp.first) * kPanelWidth + last.nb;
+      const SolveSchedItem& item = ent.items[gIdx];
+      if (item.kind == SolveSchedItem::kSweep) {
+        hipk::SweepDesc sd = item.sweep;
+        sd.ticketOff = (int32_t)((BACKWARD ? ent.numSweeps - 1 - sweepOrd : sweepOrd) * nInst);
+        sweepOrd++;
+        const size_t lds = hipk::sweepLdsBytes<BT>(sd.w, sd.rowsBelow, BACKWARD);
+        const unsigned gx = (unsigned)(BACKWARD ? item.sweepBwdWgs : item.sweepFwdWgs);
+        hipk::solveSweep<BT, BACKWARD><<<grid(gx), 256, lds, sym.stream>>>(
+            sd, invBase, invBatchStride, xchg, sh, plan.rowGlobal.as<int32_t>(), ref);
+        sym.counters.sweepLaunches++;
+        continue;
+      }
+      if (item.kind == SolveSchedItem::kBlockGroup) {
+        const PanelDesc& first = plan.host.panels[levels[item.l].directPanel];
+        const PanelDesc& last = plan.host.panels[levels[item.e - 1].directPanel];
+        const int w = (int)(item.e - 1 - item.l) * kPanelWidth + last.nb;
         const unsigned nT = (unsigned)((last.rowsBelow + kTile - 1) / kTile);
-        if (invBase && (*invSlot)[gIdx] >= 0) {
-          const BT* inv = invBase + (int64_t)(*invSlot)[gIdx] * kPanelWidth * kPanelWidth;
+        if (invBase && item.slot >= 0) {
+          const BT* inv = invBase + (int64_t)item.slot * kPanelWidth * kPanelWidth;
           if (!BACKWARD) {
             hipk::solveTriBlockInv<BT, false><<<grid(1), 256, 0, sym.stream>>>(first, w, inv, invBatchStride, ref);
             if (nT) {
@@ -1510,7 +1704,7 @@ struct HipSolveCtx : SolveCtx<T> {
         }
         continue;
       }
-      const LevelRange& lr = levels[grp.first];
+      const LevelRange& lr = levels[item.l];
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
       if (!nP) continue;
@@ -1875,6 +2069,34 @@ void hipBackendSetFault(SymbolicCtx& sym, int kind) {
   HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
   BASPACHO_CHECK_NOTNULL(h);
   h->faultDropElimUpdate = kind == 1;
+  // kind 2: the spine of block 1 of every persistent solve sweep never publishes its x, with the
+  // watchdog set to 50 ms: the launch must end by itself and the NEXT solve must report it
+  h->sweepFault = kind == 2 ? 2 : 0;
+  h->sweepSpinLimitS = kind == 2 ? 0.05 : 2.0;
+}
+
+int hipBackendReadSweepTrace(SymbolicCtx& sym, long long* out, int maxBlocks) {
+  HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
+  BASPACHO_CHECK_NOTNULL(h);
+  if (!h->sweepTrace.ptr) return 0;
+  hipCHECK(hipDeviceSynchronize());
+  const int n = std::min(maxBlocks, 4096);
+  hipCHECK(hipMemcpy(out, h->sweepTrace.ptr, (size_t)n * 4 * sizeof(long long), hipMemcpyDeviceToHost));
+  return n;
+}
+
+HipRunCounters hipBackendRunCounters(SymbolicCtx& sym) {
+  HipSymbolicCtx* h = dynamic_cast<HipSymbolicCtx*>(&sym);
+  BASPACHO_CHECK_NOTNULL(h);
+  HipRunCounters c;
+  c.sweepLaunches = h->counters.sweepLaunches;
+  c.sweepTimeouts = h->counters.sweepTimeouts;
+  c.splitListsUsed = h->counters.splitListsUsed;
+  c.subBatchesEnqueued = h->counters.subBatchesEnqueued;
+  c.lookaheadForks = h->counters.lookaheadForks;
+  c.sweepsRetired = h->sweepBroken ? 1 : 0;
+  c.sweepErrorPending = (h->sweepHostErr && *reinterpret_cast<volatile unsigned*>(h->sweepHostErr)) ? 1 : 0;
+  return c;
 }
 
 void hipBackendSetProfile(SymbolicCtx& sym, HipKernelProfile* prof, bool inSitu) {

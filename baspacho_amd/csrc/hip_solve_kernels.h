@@ -805,11 +805,19 @@ __global__ __launch_bounds__(256) void solveTriBlock(PanelDesc first, int w, Sol
 // 64 x 64 diagonal block of L, not with that of the matrix.
 template <typename T>
 __global__ __launch_bounds__(64) void solveInvertPanels(const PanelDesc* list, T* invOut,
-                                                        int64_t batchStride, SolveRef<T> ref) {
+                                                        int64_t batchStride, SolveRef<T> ref,
+                                                        unsigned long long* arm = nullptr,
+                                                        int64_t armWords = 0) {
   constexpr int NB = kPanelWidth, LD = NB + 1;
   __shared__ T Ls[NB * LD];
   const PanelDesc pd = list[blockIdx.x];
   const int t = threadIdx.x, nb = pd.nb, lda = pd.lda;
+  // (round 6: this launch also ARMS the exchange buffer of the persistent sweeps that follow it --
+  //  every word all-ones = "not published yet", hip_sweep_kernels.h)
+  for (int64_t i = ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 64 + t; i < armWords;
+       i += (int64_t)gridDim.x * gridDim.z * 64) {
+    arm[i] = ~0ull;
+  }
   GP<const T> A = solveMat(ref) + pd.diagOff;
   T y[NB];
   {  // row i: lanes = columns; all 64 loads in flight before the first LDS store

@@ -269,6 +269,21 @@ typedef struct bsp_plan_stats {
 } bsp_plan_stats;
 int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out);
 
+/* What the calls on this solver actually RAN (cumulative counters; no reference counterpart): a
+   test can see that the path it means to test was taken, and a caller can poll for a watchdog
+   report of the persistent solve sweeps (hip_sweep_kernels.h) without waiting for the next solve,
+   which would throw it. */
+typedef struct bsp_run_counters {
+  int64_t sweep_launches;       /* persistent solve sweeps launched */
+  int64_t sweep_timeouts;       /* ... that ran into their watchdog (reported by a later call) */
+  int64_t split_lists_used;     /* update launches that took a split-K tile list */
+  int64_t sub_batches_enqueued; /* sub-batches enqueued on a stream of their own */
+  int64_t lookahead_forks;      /* lookahead launches handed to the auxiliary streams */
+  int64_t sweeps_retired;       /* 1: a time-out retired the sweeps of this solver */
+  int64_t sweep_error_pending;  /* 1: a time-out has been raised and not been reported yet */
+} bsp_run_counters;
+int bsp_run_counters_get(bsp_solver* s, bsp_run_counters* out);
+
 /* kernel classes timed by bsp_factor_profiled_* (HIP events on the execution stream) */
 enum {
   BSP_PROF_ELIM_FACTOR = 0,
