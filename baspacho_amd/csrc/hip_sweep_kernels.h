@@ -148,6 +148,60 @@ __device__ __forceinline__ bool sweepWait(GP<const T> (&p)[N], const bool (&need
   }
 }
 
+// ---- sum 16 per-lane values across the 64 lanes, 16 sums at once, WITHOUT the LDS crossbar ----------
+// waveSum16 (hip_solve_kernels.h) is 17 __shfl_xor = 34 ds_bpermute for doubles, a dependent chain
+// of crossbar round trips: 0.6 us per call, and a spine step makes eight (first trace of the sweep:
+// 5.5 of a step's 6.6 us).  Here the two wide exchanges are gfx950's v_permlane32_swap /
+// v_permlane16_swap (tools/permlane_probe.hip: swap(a, b) -> [a.even b.even ...] and [a.odd b.odd ...]
+// halves / rows, so that r0 + r1 IS the halving step of the butterfly), the two narrow ones DPP quad
+// permutes, and the last two plain row rotations: vector-ALU instructions only.
+// The sum of v[sweepRowOf(lane)] ends up in every lane; lanes with sweepRowOwner() write it.
+__device__ __forceinline__ int sweepRowOf(int lane) { return ((lane >> 4) << 2) | (lane & 3); }
+__device__ __forceinline__ bool sweepRowOwner(int lane) { return (lane & 12) == 0; }
+template <int CTRL>
+__device__ __forceinline__ double sweepDpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float sweepDpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double sweepHalve32(double a, double b) {  // lanes < 32: a[l] + a[l+32]; else b[l-32] + b[l]
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ float sweepHalve32(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ double sweepHalve16(double a, double b) {  // even rows: a over {row, row+1}; odd rows: b
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ float sweepHalve16(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <typename T>
+__device__ __forceinline__ T sweepRowSum16(T (&v)[16], int lane) {
+  const bool b1 = lane & 2, b0 = lane & 1;
+  T a[8], b[4], c[2];
+#pragma unroll
+  for (int j = 0; j < 8; j++) a[j] = sweepHalve32(v[j], v[j + 8]);
+#pragma unroll
+  for (int j = 0; j < 4; j++) b[j] = sweepHalve16(a[j], a[j + 4]);
+#pragma unroll
+  for (int j = 0; j < 2; j++) c[j] = (b1 ? b[j + 2] : b[j]) + sweepDpp<0x4E>(b1 ? b[j] : b[j + 2]);  // quad_perm [2,3,0,1]
+  T d = (b0 ? c[1] : c[0]) + sweepDpp<0xB1>(b0 ? c[0] : c[1]);                                       // quad_perm [1,0,3,2]
+  d += sweepDpp<0x124>(d);  // row_ror:4
+  d += sweepDpp<0x128>(d);  // row_ror:8
+  return d;
+}
+
 // position in the vector of row q below the run
 __device__ __forceinline__ int sweepTargetRow(const SweepDesc& sd, const int32_t* rowGlobal, int q) {
   return q < sd.nRest ? sd.vecOff + sd.w + q : rowGlobal[sd.lumpRowBase + (q - sd.nRest)];
@@ -176,63 +230,127 @@ __device__ __forceinline__ void sweepSpine(const SweepDesc& sd, int b, GP<const 
   const bool hasPrev = BACKWARD ? bp < sd.nBlocks : bp >= 0;
   const int cp = bp * W;
   const bool hasFar = BACKWARD ? (sd.rowsBelow > 0 || b + 2 < sd.nBlocks) : b >= 2;
-  const int ur = (lane >> 2) & 15;
+  const int ur = sweepRowOf(lane);
   if (trace && tid == 0) trace[4 * b] = (long long)wall_clock64();
 
-  // everything the step needs, requested before the wait
+  // everything the step needs, requested before the wait.  Forward: tile rows are matrix rows, a lane
+  // reads along a row.  Backward the tiles (and the inverses) are needed TRANSPOSED: read the natural,
+  // coalesced way (next tile in flight) and turned round through an LDS staging tile -- the first
+  // version read them transposed from memory, 64 lines per load: 50-70 us per spine, and the first
+  // two spines of the sweep waited for theirs.
   T Lp[Q][Q][16], Li[Q * (Q - 1) / 2][16];
+  // (every load unconditional, from a clamped row, masked afterwards: a predicated load is a branch
+  //  around it, 600 of them in the first version)
+  if (!BACKWARD) {
 #pragma unroll
-  for (int q = 0; q < Q; q++) {
+    for (int q = 0; q < Q; q++) {
 #pragma unroll
-    for (int pp = 0; pp < Q; pp++) {
+      for (int pp = 0; pp < Q; pp++) {
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int i = cb + NB * q + 16 * wv + u;  // row of the block (forward) / its column (backward)
-        const int j = cp + NB * pp + lane;        // column of the previous block / its row
-        if (!BACKWARD) {
-          Lp[q][pp][u] = (hasPrev && i < w) ? A[(int64_t)i * lda + j] : T(0);
-        } else {
-          Lp[q][pp][u] = (hasPrev && j < w) ? A[(int64_t)j * lda + i] : T(0);
+        for (int u = 0; u < 16; u++) Lp[q][pp][u] = T(0);
+      }
+    }
+    if (hasPrev) {
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+#pragma unroll
+        for (int pp = 0; pp < Q; pp++) {
+#pragma unroll
+          for (int u = 0; u < 16; u++) {
+            const int i = cb + NB * q + 16 * wv + u, j = cp + NB * pp + lane;
+            const T a = A[(int64_t)min(i, w - 1) * lda + j];
+            Lp[q][pp][u] = i < w ? a : T(0);
+          }
         }
       }
     }
-  }
 #pragma unroll
-  for (int hi = 1; hi < Q; hi++) {
+    for (int hi = 1; hi < Q; hi++) {
 #pragma unroll
-    for (int lo = 0; lo < hi; lo++) {
+      for (int lo = 0; lo < hi; lo++) {
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        if (!BACKWARD) {  // target panel hi, source panel lo
+        for (int u = 0; u < 16; u++) {  // target panel hi, source panel lo
           const int i = cb + NB * hi + 16 * wv + u, j = cb + NB * lo + lane;
-          Li[hi * (hi - 1) / 2 + lo][u] = i < w ? A[(int64_t)i * lda + j] : T(0);
-        } else {  // target panel lo, source panel hi
-          const int i = cb + NB * lo + 16 * wv + u, j = cb + NB * hi + lane;
-          Li[hi * (hi - 1) / 2 + lo][u] = j < w ? A[(int64_t)j * lda + i] : T(0);
+          const T a = A[(int64_t)min(i, w - 1) * lda + min(j, w - 1)];
+          Li[hi * (hi - 1) / 2 + lo][u] = i < w ? a : T(0);
         }
       }
     }
-  }
-  {
     GP<const T> src = inv + (int64_t)(sd.invSlot + b * Q) * NB * NB;
 #pragma unroll
     for (int q = 0; q < Q; q++) {
       T v[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int e = tid + 256 * i;
-        const int g = BACKWARD ? (e & 63) * NB + (e >> 6) : e;
-        v[i] = q < nq ? src[(int64_t)q * NB * NB + g] : T(0);
-      }
+      for (int i = 0; i < 16; i++) v[i] = q < nq ? src[(int64_t)q * NB * NB + tid + 256 * i] : T(0);
 #pragma unroll
       for (int i = 0; i < 16; i++) Iv[q * NB * NB + tid + 256 * i] = v[i];
+    }
+  } else {
+    constexpr int LD = NB + 1;
+    T* St = ts + NB;  // staging tile, NB x LD
+    // natural layout: rows = source index (rows of L), lane = target index (its column); every load
+    // of the spine in flight at once, then the tiles are turned round in place, one after the other
+    auto fetch = [&](T(&dst)[16], int r0, int c0) {
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int j = r0 + 16 * wv + u;
+        const T a = A[(int64_t)min(j, w - 1) * lda + min(c0 + lane, w - 1)];
+        dst[u] = j < w ? a : T(0);
+      }
+    };
+    auto turn = [&](T(&tile)[16]) {
+#pragma unroll
+      for (int u = 0; u < 16; u++) St[(16 * wv + u) * LD + lane] = tile[u];
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 16; u++) tile[u] = St[lane * LD + 16 * wv + u];
+      __syncthreads();
+    };
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+#pragma unroll
+      for (int pp = 0; pp < Q; pp++) {
+        if (hasPrev) {
+          fetch(Lp[q][pp], cp + NB * pp, cb + NB * q);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 16; u++) Lp[q][pp][u] = T(0);
+        }
+      }
+    }
+#pragma unroll
+    for (int hi = 1; hi < Q; hi++) {
+#pragma unroll
+      for (int lo = 0; lo < hi; lo++) fetch(Li[hi * (hi - 1) / 2 + lo], cb + NB * hi, cb + NB * lo);
+    }
+    if (hasPrev) {
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+#pragma unroll
+        for (int pp = 0; pp < Q; pp++) turn(Lp[q][pp]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < Q * (Q - 1) / 2; k++) turn(Li[k]);
+    GP<const T> src = inv + (int64_t)(sd.invSlot + b * Q) * NB * NB;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      T vi[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) vi[i] = q < nq ? src[(int64_t)q * NB * NB + tid + 256 * i] : T(0);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int e = tid + 256 * i;
+        Iv[q * NB * NB + (e & 63) * NB + (e >> 6)] = vi[i];
+      }
     }
   }
   T yv[Q];
 #pragma unroll
   for (int q = 0; q < Q; q++) {
     const int r = cb + NB * q + 16 * wv + ur;
-    yv[q] = r < w ? vec[sd.vecOff + r] : T(0);
+    const T y = vec[sd.vecOff + min(r, w - 1)];
+    yv[q] = r < w ? y : T(0);
   }
   if (tid < W) xs[tid] = T(0);
   __syncthreads();
@@ -262,7 +380,7 @@ __device__ __forceinline__ void sweepSpine(const SweepDesc& sd, int b, GP<const 
     for (int u = 0; u < 16; u++) {
       v[u] = Lp[q][0][u] * got[0] + Lp[q][1][u] * got[1] + Lp[q][2][u] * got[2];
     }
-    t[q] = yv[q] - got[Q + q] - waveSum16(v, lane);
+    t[q] = yv[q] - got[Q + q] - sweepRowSum16(v, lane);
   }
 #pragma unroll
   for (int qi = 0; qi < Q; qi++) {
@@ -282,17 +400,17 @@ __device__ __forceinline__ void sweepSpine(const SweepDesc& sd, int b, GP<const 
             for (int u = 0; u < 16; u++) v[u] += Li[hi * (hi - 1) / 2 + lo][u] * xp;
           }
         }
-        t[q] -= waveSum16(v, lane);
+        t[q] -= sweepRowSum16(v, lane);
       }
-      if ((lane & 3) == 0) ts[16 * wv + ur] = t[q];
+      if (sweepRowOwner(lane)) ts[16 * wv + ur] = t[q];
       __syncthreads();
       const T tq = ts[lane];
       T v[16];
 #pragma unroll
       for (int u = 0; u < 16; u++) v[u] = Iv[q * NB * NB + (16 * wv + u) * NB + lane] * tq;
-      const T xv = waveSum16(v, lane);
+      const T xv = sweepRowSum16(v, lane);
       const int r = cb + NB * q + 16 * wv + ur;
-      if ((lane & 3) == 0) {
+      if (sweepRowOwner(lane)) {
         xs[NB * q + 16 * wv + ur] = xv;
         if (r < w) {
           if (fault != b + 1) sweepPublish<T>(xq + r, xv);
@@ -352,9 +470,11 @@ __device__ __forceinline__ void sweepFarL(const SweepDesc& sd, int tile, bool be
   auto load = [&](T(&dst)[16][3], int s) {
 #pragma unroll
     for (int u = 0; u < 16; u++) {
-      GP<const T> row = A + (int64_t)min(rowBase + u, rowEnd - 1) * lda + W * s + lane;
+      GP<const T> row = A + (int64_t)min(rowBase + u, rowEnd - 1) * lda;
 #pragma unroll
-      for (int i = 0; i < 3; i++) dst[u][i] = (W * s + 64 * i + lane < w) ? row[64 * i] : T(0);
+      // (no mask: a clamped element meets x = 0 for a column beyond the run, and a clamped row is
+      //  never published -- a select here would make every prefetch wait for its own loads)
+      for (int i = 0; i < 3; i++) dst[u][i] = row[min(W * s + 64 * i + lane, w - 1)];
     }
   };
   auto step = [&](T(&cur)[16][3], T(&nxt)[16][3], int s) -> bool {
@@ -376,9 +496,9 @@ __device__ __forceinline__ void sweepFarL(const SweepDesc& sd, int tile, bool be
     if (s + 2 >= nSrc) break;
     if (!step(buf[2], buf[1], s + 2)) return;
   }
-  const T sum = waveSum16(acc, lane);
-  const int r = rowBase + ((lane >> 2) & 15);
-  if ((lane & 3) == 0 && r < rowEnd) {
+  const T sum = sweepRowSum16(acc, lane);
+  const int r = rowBase + sweepRowOf(lane);
+  if (sweepRowOwner(lane) && r < rowEnd) {
     if (below) {
       atomicSub(vec + sweepTargetRow(sd, rowGlobal, r - w), sum);
     } else {
@@ -462,7 +582,8 @@ __device__ __forceinline__ void sweepFarLt(const SweepDesc& sd, int ctile, GP<co
 #pragma unroll
       for (int u = 0; u < RW; u++) {
         const int m = m0 + RW * wv + u;
-        dst[u] = (colOk && m < lim) ? A[(int64_t)m * lda + col] : T(0);
+        // (no mask: x is zero for a row beyond the unit's limit, a column beyond the run is not published)
+        dst[u] = A[(int64_t)min(m, lim - 1) * lda + min(col, w - 1)];
       }
     };
     auto step = [&](T(&cur)[RW], T(&nxt)[RW], int unit) -> bool {
@@ -534,6 +655,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     return;
   }
   const int b = BACKWARD ? sd.nBlocks - 1 - blk : blk;
+  // STAGGERED START.  Every role begins by pulling its operands on chip: 40 MB requested in the same
+  // microsecond, and the spines of the first steps -- the only ones anybody is waiting for -- queued
+  // behind all of it (first trace: 21 us before spine 1 had its tiles, 47 backward).  Spine k is not
+  // needed before ~5 k us, the far tiles not before the first x is out: they start a little later.
+  {
+    const long long wait = r == G - 1 ? (blk >= 3 ? min(blk - 2, 30) * 200ll : 0ll) : 500ll;  // 10-ns ticks
+    if (wait > 0) {
+      const long long t0 = (long long)wall_clock64();
+      while ((long long)wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+  }
   if (r == G - 1) {
     sweepSpine<T, BACKWARD>(sd, b, A, vec, inv, xq, farq, watch, lds, sh.fault,
                                (blockIdx.y | blockIdx.z) ? nullptr : sh.trace);
@@ -547,7 +679,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // dynamic LDS of a launch, bytes
 template <typename T>
 inline size_t sweepLdsBytes(int w, int rowsBelow, bool backward) {
-  const size_t spine = (size_t)(kSweepQ * kPanelWidth * kPanelWidth + kSweepW + kPanelWidth) * sizeof(T);
+  const size_t spine = (size_t)(kSweepQ * kPanelWidth * kPanelWidth + kSweepW + kPanelWidth +
+                                (backward ? kPanelWidth * (kPanelWidth + 1) : 0)) * sizeof(T);
   const size_t nB = (size_t)(w + kSweepW - 1) / kSweepW;
   size_t far = (size_t)kSweepLdsHead + nB * kSweepW;
   if (backward) far += (size_t)((rowsBelow + kSweepW - 1) / kSweepW) * kSweepW;
