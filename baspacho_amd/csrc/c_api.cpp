@@ -610,6 +610,7 @@ int bsp_run_counters_get(bsp_solver* s, bsp_run_counters* out) {
   out->lookahead_forks = c.lookaheadForks;
   out->sweeps_retired = c.sweepsRetired;
   out->sweep_error_pending = c.sweepErrorPending;
+  out->gather_chunks_overlapped = c.gatherChunksOverlapped;
   BSP_CATCH
 }
 

@@ -71,6 +71,7 @@ struct HipRunCounters {
   int64_t splitListsUsed = 0;      // update launches that took a split-K tile list
   int64_t subBatchesEnqueued = 0;  // sub-batches enqueued on their own stream
   int64_t lookaheadForks = 0;      // lookahead launches handed to the auxiliary streams
+  int64_t gatherChunksOverlapped = 0;  // sparse-elimination gather chunks launched beside the dense chain
   int64_t sweepsRetired = 0;       // 1: a time-out retired the sweeps of this Solver
   int64_t sweepErrorPending = 0;   // 1: a time-out has been raised and not been reported yet
 };

@@ -428,6 +428,8 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_SUB_BATCHES")) subBatchParts = std::max(2, std::atoi(e));
     if (const char* e = std::getenv("BSP_SPLIT_K")) splitK = e[0] != '0';
     if (const char* e = std::getenv("BSP_SOLVE_SWEEP")) sweepEnabled = e[0] != '0';
+    if (const char* e = std::getenv("BSP_GATHER_OVERLAP")) gatherOverlap = e[0] != '0';
+    if (const char* e = std::getenv("BSP_GATHER_OVERLAP_LDS")) gatherOverlapLds = (unsigned)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BSP_SWEEP_MIN_WIDTH")) sweepMinWidth = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BSP_SWEEP_TRACE")) sweepTraceOn = e[0] != '0';
     // the plan builder's switches: read here, once per Solver, handed to every buildHipPlan call
@@ -676,6 +678,8 @@ struct HipSymbolicCtx : SymbolicCtx {
   double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
   bool splitK = true;       // split-K tile lists for small multi-panel levels (BSP_SPLIT_K=0: off)
+  unsigned gatherOverlapLds = 0;  // dynamic LDS of the overlapped chunks' launches (throttle; BSP_GATHER_OVERLAP_LDS)
+  bool gatherOverlap = true;  // gather chunks beside the dense chain (BSP_GATHER_OVERLAP=0: also keeps the plan unchunked)
   static constexpr int64_t splitKMaxWgs = 1024;  // ... launches of at most this many workgroups (a batch of 8: 2.26 = 2.26 ms at 1024, 2.48 at 4096)
   int subBatchMin = 16;     // batches of at least this many matrices are factored as concurrent sub-batches (BSP_SUB_BATCH_MIN; 0x7fffffff: never)
   int subBatchParts = 2;    // ... this many (BSP_SUB_BATCHES, at most 4, at least subBatchMin / 2 matrices each)
@@ -709,7 +713,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   int sweepAttr[2] = {0, 0};  // per value size (8, 4): 0 not tried, 1 ready, -1 failed
   struct RunCounters {
     int64_t sweepLaunches = 0, sweepTimeouts = 0, splitListsUsed = 0, subBatchesEnqueued = 0,
-            lookaheadForks = 0;
+            lookaheadForks = 0, gatherChunksOverlapped = 0;
   } counters;
   // a timed-out sweep is reported ONCE, by the next call that would have used one
   bool sweepUsable() {
@@ -864,11 +868,20 @@ struct HipNumericCtx : NumericCtx<T> {
     // applies the rest from memory
     int extraApplied = 0;
     bool extraBroken = false;
+    // gather overlap: chunks each stream has already waited for (events of one stream complete in order)
+    const bool chunks = &levels == &plan.host.levels && !gatherChunkDone.empty();
+    int waitedExec = 0, waitedDue = 0, waitedSide = 0;
+    auto waitChunk = [&](hipStream_t st, int& waited, int32_t chunk) {
+      if (!chunks || chunk <= waited || chunk >= (int32_t)gatherChunkDone.size()) return;
+      hipCHECK(hipStreamWaitEvent(st, gatherChunkDone[chunk], 0));
+      waited = chunk;
+    };
     for (size_t li = 0; li < levels.size(); li++) {
       const LevelRange& lr = levels[li];
       const unsigned nP = (unsigned)(lr.panelEnd - lr.panelBegin);
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
       const bool direct = lr.directPanel >= 0;
+      waitChunk(sym.stream, waitedExec, lr.gatherNow);
       const int slot = dinvSlot;
       dinvSlot ^= 1;
       BT* dinvCur = dinvBase + slot * hipk::kDinvSlot;
@@ -963,6 +976,8 @@ struct HipNumericCtx : NumericCtx<T> {
           // units forked two blocks ago, whose far columns are plain read-modify-write.
           hipStream_t due = sym.dueSideStream();
           hipCHECK(hipStreamWaitEvent(due, fork, 0));
+          waitChunk(due, waitedDue, lr.gatherDue);
+          waitChunk(sym.sideStream(), waitedSide, lr.gatherOpt);
           const int64_t f2 = lr.optWaitLevel;
           if (f2 >= 0 && optDone[f2]) hipCHECK(hipStreamWaitEvent(due, optDone[f2], 0));
           if (lr.defMid > lr.defBegin) {
@@ -982,6 +997,7 @@ struct HipNumericCtx : NumericCtx<T> {
           sideUsed = dueUsed = true;
           return;
         }
+        waitChunk(sym.sideStream(), waitedSide, std::max(lr.gatherDue, lr.gatherOpt));
         if (lr.defMid > lr.defBegin) {
           timer.begin(kProfUpdate, sym.sideStream());
           launchUpdate(plan, lr.defBegin, lr.defMid, ref, sym.sideStream(), nullptr, 0, sym.bulkExtraLds, sideMask);
@@ -1088,6 +1104,10 @@ struct HipNumericCtx : NumericCtx<T> {
       hipCHECK(hipEventRecord(join, sym.dueSideStream()));
       hipCHECK(hipStreamWaitEvent(sym.stream, join, 0));
     }
+    if (chunks) {  // (the last level waited for the last chunk already; a plan without levels did not)
+      waitChunk(sym.stream, waitedExec, (int32_t)gatherChunkDone.size() - 1);
+      gatherChunkDone.clear();
+    }
   }
 
   void launchElim(DevPlan& plan, const ElimRangePlan& er, hipk::DataRef<BT> ref,
@@ -1125,12 +1145,41 @@ struct HipNumericCtx : NumericCtx<T> {
     }
     if (er.useGather) {
       const int64_t nItems = er.itemEnd - er.itemBegin;
-      if (nItems > 0) {
-        timer.begin(kProfElimUpdate);
-        hipk::elimGatherMfma<BT><<<dim3((unsigned)((nItems + 3) / 4), gy), 256, 0, sym.stream>>>(
-            plan.elimItems.as<ElimGatherItem>() + er.itemBegin, plan.elimPairOffJ.as<uint32_t>(),
-            plan.elimPairOffI.as<uint32_t>(), ref, (int)nItems);
+      // (extraLds: overlapped chunks may be throttled to fewer workgroups per CU, BSP_GATHER_OVERLAP_LDS)
+      auto gatherRange = [&](int64_t b, int64_t e, hipStream_t st, unsigned extraLds = 0) {
+        if (e <= b) return;
+        timer.begin(kProfElimUpdate, st);
+        hipk::elimGatherMfma<BT><<<dim3((unsigned)((e - b + 3) / 4), gy), 256, extraLds, st>>>(
+            plan.elimItems.as<ElimGatherItem>() + b, plan.elimPairOffJ.as<uint32_t>(),
+            plan.elimPairOffI.as<uint32_t>(), ref, (int)(e - b));
         timer.end();
+      };
+      gatherChunkDone.clear();
+      if (!er.chunkItemPtr.empty()) {
+        // GATHER OVERLAP (hip_plan.h, ElimRangePlan::chunkItemPtr): chunk 0 here, the others on a
+        // stream of their own beside the dense chain, one event per chunk; launchLevels makes every
+        // dense launch wait for the chunk of the last column block it touches
+        const size_t nChunks = er.chunkItemPtr.size() - 1;
+        const bool overlap = er.overlapLump >= 0 && sym.gatherOverlap && lookaheadOn() &&
+                             plan.host.lookaheadPays(batchSize, sym.lookaheadMinFlops);
+        if (overlap) {
+          hipStream_t gs = sym.streams().batch[0];
+          hipEvent_t factored = sym.eventFromPool();
+          hipCHECK(hipEventRecord(factored, sym.stream));
+          hipCHECK(hipStreamWaitEvent(gs, factored, 0));
+          gatherRange(er.chunkItemPtr[0], er.chunkItemPtr[1], sym.stream);
+          gatherChunkDone.assign(nChunks, nullptr);
+          for (size_t c = 1; c < nChunks; c++) {
+            gatherRange(er.chunkItemPtr[c], er.chunkItemPtr[c + 1], gs, sym.gatherOverlapLds);
+            gatherChunkDone[c] = sym.eventFromPool();
+            hipCHECK(hipEventRecord(gatherChunkDone[c], gs));
+          }
+          sym.counters.gatherChunksOverlapped += (int64_t)nChunks - 1;
+        } else {
+          for (size_t c = 0; c < nChunks; c++) gatherRange(er.chunkItemPtr[c], er.chunkItemPtr[c + 1], sym.stream);
+        }
+      } else {
+        gatherRange(er.itemBegin, er.itemBegin + nItems, sym.stream);
       }
       const int64_t nWide = er.ldsEnd - er.ldsBegin;
       if (nWide > 0) {
@@ -1375,6 +1424,9 @@ struct HipNumericCtx : NumericCtx<T> {
   HipSymbolicCtx& sym;
   int batchSize;
   int subBatchBase = 0, subBatchTotal = 0;  // enqueueFactor: the sub-batch being enqueued
+  // gather overlap: events of the gather chunks of THIS factor call that run beside the dense chain
+  // (launchElim -> launchLevels; [0] is null: chunk 0 runs on the execution stream)
+  vector<hipEvent_t> gatherChunkDone;
   int64_t tempBufSize = 0;
   DevBuf temp, spanToChainOffset;  // per-op boundary only (saveSyrkGemm / prepareAssemble)
   vector<std::unique_ptr<DevPlan>> opPlans;
@@ -2094,6 +2146,7 @@ HipRunCounters hipBackendRunCounters(SymbolicCtx& sym) {
   c.splitListsUsed = h->counters.splitListsUsed;
   c.subBatchesEnqueued = h->counters.subBatchesEnqueued;
   c.lookaheadForks = h->counters.lookaheadForks;
+  c.gatherChunksOverlapped = h->counters.gatherChunksOverlapped;
   c.sweepsRetired = h->sweepBroken ? 1 : 0;
   c.sweepErrorPending = (h->sweepHostErr && *reinterpret_cast<volatile unsigned*>(h->sweepHostErr)) ? 1 : 0;
   return c;

@@ -60,7 +60,8 @@ void sortBuckets(V& v, const std::vector<int64_t>& ptr, Less less) {
   for (auto& th : pool) th.join();
 }
 
-void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, ElimRangePlan& er) {
+void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, ElimRangePlan& er,
+                     int64_t soleDenseLump) {
   er.useGather = false;
   if (sk.dataSize() >= (int64_t(1) << 32)) return;
   const bool timing = plan.opts.planTiming;
@@ -220,12 +221,68 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
     er.ldsBegin = er.tinyEnd;
     er.ldsEnd = er.ldsBegin + (int64_t)wide.size();
   }
+  // GATHER OVERLAP: group the MFMA items by chunk of target column blocks (stable: row order inside a
+  // chunk stays what it was), when every target lies in the one dense lump of the plan
+  vector<std::pair<int64_t, int64_t>> orderRanges;  // item ranges (relative to itemBegin) to XCD-order
+  {
+    const int64_t nLarge = er.itemEnd - er.itemBegin;
+    bool chunked = false;
+    if (plan.opts.gatherOverlap && soleDenseLump >= 0 && nLarge >= 4096 && er.tinyEnd == er.tinyBegin &&
+        er.ldsEnd == er.ldsBegin) {
+      const int64_t T = soleDenseLump;
+      const int64_t n = sk.lumpStart[T + 1] - sk.lumpStart[T];
+      const int64_t nBlk = (n + kOuterWidth - 1) / kOuterWidth;
+      const int64_t base = sk.chainData[sk.chainColPtr[T]];  // data offset of the lump column
+      const int64_t rowsT = n + lumpCols(sk, T).rowsBelow;
+      bool ok = nBlk >= plan.opts.overlapMinBlocks && n * n < (int64_t(1) << 40);
+      vector<int32_t> chunkOf((size_t)nBlk, 0);
+      int32_t nChunks = 0;
+      if (ok) {
+        const int32_t first = std::max(1, plan.opts.overlapFirst), step = std::max(1, plan.opts.overlapStep);
+        for (int64_t cb = 0; cb < nBlk; cb++) {
+          chunkOf[cb] = cb < first ? 0 : 1 + (int32_t)((cb - first) / step);
+        }
+        nChunks = chunkOf[nBlk - 1] + 1;
+        vector<int32_t> itemChunk((size_t)nLarge);
+        for (int64_t k = 0; k < nLarge && ok; k++) {
+          const ElimGatherItem& it = plan.elimItems[er.itemBegin + k];
+          const int64_t rel = it.tgtOff - base;
+          if (rel < 0 || it.tgtStride != n || rel >= rowsT * n) {
+            ok = false;
+            break;
+          }
+          itemChunk[k] = chunkOf[(rel % n) / kOuterWidth];
+        }
+        if (ok && nChunks >= 2) {
+          vector<ElimGatherItem> tmp(plan.elimItems.begin() + er.itemBegin, plan.elimItems.begin() + er.itemEnd);
+          vector<int64_t> tagTmp = itemRowTag;
+          vector<int64_t> ptr((size_t)nChunks + 1, 0);
+          for (int64_t k = 0; k < nLarge; k++) ptr[itemChunk[k] + 1]++;
+          for (int32_t c = 0; c < nChunks; c++) ptr[c + 1] += ptr[c];
+          vector<int64_t> cursor(ptr.begin(), ptr.end() - 1);
+          for (int64_t k = 0; k < nLarge; k++) {
+            const int64_t d = cursor[itemChunk[k]]++;
+            plan.elimItems[er.itemBegin + d] = tmp[k];
+            itemRowTag[d] = tagTmp[k];
+          }
+          er.chunkItemPtr.resize((size_t)nChunks + 1);
+          for (int32_t c = 0; c <= nChunks; c++) er.chunkItemPtr[c] = er.itemBegin + ptr[c];
+          er.chunkOfColBlock = chunkOf;
+          er.overlapLump = T;
+          for (int32_t c = 0; c < nChunks; c++) orderRanges.emplace_back(ptr[c], ptr[c + 1]);
+          chunked = true;
+        }
+      }
+    }
+    if (!chunked) orderRanges.emplace_back(0, nLarge);
+  }
   // XCD-aware order (speed only).  A workgroup takes 4 consecutive items and
   // workgroup b runs on XCD b % 8, each XCD with its own 4 MB L2.  All items of one target ROW (same
   // sj) read the same B_j source blocks, so a row is handed to ONE XCD (row r -> XCD r % 8, rows
   // balance the load statistically) instead of being sprayed over all eight L2s (measured L2 hit
   // rate 26 %).
-  const int64_t g0 = 0, g1 = er.itemEnd - er.itemBegin;
+  for (const auto& rng : orderRanges) {
+  const int64_t g0 = rng.first, g1 = rng.second;
   if (g1 - g0 >= 512) {
     const int64_t nItems = g1 - g0;
     vector<ElimGatherItem> tmp(plan.elimItems.begin() + er.itemBegin + g0,
@@ -262,6 +319,7 @@ void buildElimGather(const CoalescedBlockMatrixSkel& sk, HipPlanHost& plan, Elim
     }
     BASPACHO_CHECK_EQ(out, er.itemBegin + g1);
   }
+  }
   lap("sort + emit items");
 }
 
@@ -278,6 +336,9 @@ HipPlanOptions HipPlanOptions::fromEnv() {
   o.planTiming = std::getenv("BSP_TIMING") != nullptr;
   if (const char* e = std::getenv("BSP_GATHER_MAX_PAIRS")) o.gatherMaxPairs = std::max(8, atoi(e));
   if (const char* e = std::getenv("BSP_BULK_AHEAD")) o.bulkAhead = std::atof(e);
+  if (const char* e = std::getenv("BSP_GATHER_OVERLAP")) o.gatherOverlap = e[0] != '0';
+  if (const char* e = std::getenv("BSP_GATHER_OVERLAP_FIRST")) o.overlapFirst = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("BSP_GATHER_OVERLAP_STEP")) o.overlapStep = std::max(1, std::atoi(e));
   return o;
 }
 
@@ -517,7 +578,12 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       }
     }
     elimBigBuckets.push_back(std::move(big));
-    buildElimGather(sk, plan, er);
+    {
+      // (gather overlap: the dense part of this plan is exactly one lump, and it is the last range)
+      const int64_t denseBegin0 = std::max(startLump, denseFrom);
+      const bool lastRange = re == denseFrom;
+      buildElimGather(sk, plan, er, (lastRange && upToLump - denseBegin0 == 1) ? denseBegin0 : -1);
+    }
     plan.elimRanges.push_back(std::move(er));
   }
   // ---- dense lumps
@@ -767,6 +833,36 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     plan.numLaunches += 2;
   }
   emitLevels(levelBuckets, plan.levels);
+  // gather overlap: which chunk every dense launch has to wait for (every level must be a one-panel
+  // level of the target lump; otherwise the chunks simply run one after the other before the dense part)
+  for (ElimRangePlan& er : plan.elimRanges) {
+    if (er.chunkItemPtr.empty()) continue;
+    bool ok = !plan.levels.empty();
+    for (const LevelRange& lr : plan.levels) {
+      ok = ok && lr.directPanel >= 0 && plan.panels[lr.directPanel].lump == er.overlapLump;
+    }
+    if (!ok) {
+      er.overlapLump = -1;
+      continue;
+    }
+    const int64_t nBlk = (int64_t)er.chunkOfColBlock.size();
+    for (LevelRange& lr : plan.levels) {
+      const PanelDesc& pd = plan.panels[lr.directPanel];
+      const int64_t b = (pd.lda - pd.nRest - pd.nb) / kOuterWidth;
+      lr.gatherNow = er.chunkOfColBlock[std::min(b + 1, nBlk - 1)];
+      auto maxChunk = [&](int64_t begin, int64_t end) {
+        int32_t m = -1;
+        for (int64_t t = begin; t < end; t++) {
+          // (lookahead units: tile columns count from the end of the source block)
+          const int64_t cb = std::min(nBlk - 1, (kOuterWidth * (b + 1) + plan.updTasks[t].colTile) / kOuterWidth);
+          m = std::max(m, er.chunkOfColBlock[cb]);
+        }
+        return m;
+      };
+      lr.gatherDue = maxChunk(lr.defBegin, lr.defMid);
+      lr.gatherOpt = maxChunk(lr.defMid, lr.defEnd);
+    }
+  }
 
   // board segments carried their target lump in tgtBase only for the atomic analysis
   for (auto& s : plan.segs) {

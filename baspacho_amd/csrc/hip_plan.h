@@ -152,6 +152,9 @@ struct LevelRange {
   // due-stream mode: level whose OPTIONAL lookahead units (forked two outer blocks earlier: plain
   // read-modify-write on far columns) must be complete before this level's due units start; -1
   int64_t optWaitLevel = -1;
+  // gather overlap (ElimRangePlan::chunkItemPtr): chunk that must be complete before this level's
+  // own launches / its due lookahead units / its optional ones; -1: none
+  int32_t gatherNow = -1, gatherDue = -1, gatherOpt = -1;
 };
 
 // One work item of the gather-form sparse-elimination update: a target block (sj,si) of the
@@ -205,6 +208,16 @@ struct ElimRangePlan {
                                       // elements (3x3 parameters): 7 items per wave
   int64_t ldsBegin = 0, ldsEnd = 0;   // items wider or taller than 16: LDS-staged kernel (K2g);
                                       // [itemBegin, itemEnd) go to the MFMA kernel (K2m)
+  // OVERLAP WITH THE DENSE PHASE (round 6).  When every target of the range's gather lies in ONE wide
+  // lump that is the whole dense part of the plan (a Schur complement whose cameras merged into one
+  // lump), the MFMA items are grouped into CHUNKS of target column blocks (kOuterWidth columns each),
+  // first columns first: chunk 0 runs on the execution stream, the others on a stream of their own
+  // BESIDE the dense chain, and every dense launch waits (event) for the chunk of the last column
+  // block it touches -- LevelRange::gatherNow / gatherDue / gatherOpt.  No atomics: a target block is
+  // never worked on from both sides.
+  std::vector<int64_t> chunkItemPtr;     // [chunks + 1], into elimItems; empty: one launch
+  std::vector<int32_t> chunkOfColBlock;  // chunk of every outer column block of the target lump
+  int64_t overlapLump = -1;
 };
 
 // Every switch the plan builder honours, read ONCE (HipPlanOptions::fromEnv, called when a
@@ -217,6 +230,10 @@ struct HipPlanOptions {
   bool planTiming = false;    // BSP_TIMING: stderr laps of the gather plan
   int32_t gatherMaxPairs = kGatherMaxPairs;  // BSP_GATHER_MAX_PAIRS
   double bulkAhead = 0.8;     // BSP_BULK_AHEAD (round 4: 0.6 -> 0.8, -0.04 ms on BAL-871; profiles/r04_ab_plan_knobs.txt)
+  bool gatherOverlap = true;  // BSP_GATHER_OVERLAP=0: the whole gather before the dense phase
+  int32_t overlapFirst = 2;   // column blocks in chunk 0 (BSP_GATHER_OVERLAP_FIRST)
+  int32_t overlapStep = 3;    // ... in every later chunk (BSP_GATHER_OVERLAP_STEP)
+  int32_t overlapMinBlocks = 8;  // narrowest target lump, in column blocks
   static HipPlanOptions fromEnv();
 };
 

@@ -559,7 +559,6 @@ __device__ __forceinline__ void sweepFarLt(const SweepDesc& sd, int ctile, GP<co
     }
   } else {
     const int col = 64 * ctile + lane;
-    const bool colOk = col < w;
     T buf[4][RW], acc = T(0);
     const int nUnits = 2 * nSrc;
     // unit -> first matrix row, first x slot, row limit
