@@ -679,7 +679,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
   bool splitK = true;       // split-K tile lists for small multi-panel levels (BSP_SPLIT_K=0: off)
   unsigned gatherOverlapLds = 0;  // dynamic LDS of the overlapped chunks' launches (throttle; BSP_GATHER_OVERLAP_LDS)
-  bool gatherOverlap = true;  // gather chunks beside the dense chain (BSP_GATHER_OVERLAP=0: also keeps the plan unchunked)
+  bool gatherOverlap = false;  // gather chunks beside the dense chain (BSP_GATHER_OVERLAP=1; off: the plan is not chunked either)
   static constexpr int64_t splitKMaxWgs = 1024;  // ... launches of at most this many workgroups (a batch of 8: 2.26 = 2.26 ms at 1024, 2.48 at 4096)
   int subBatchMin = 16;     // batches of at least this many matrices are factored as concurrent sub-batches (BSP_SUB_BATCH_MIN; 0x7fffffff: never)
   int subBatchParts = 2;    // ... this many (BSP_SUB_BATCHES, at most 4, at least subBatchMin / 2 matrices each)

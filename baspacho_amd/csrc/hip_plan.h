@@ -230,7 +230,7 @@ struct HipPlanOptions {
   bool planTiming = false;    // BSP_TIMING: stderr laps of the gather plan
   int32_t gatherMaxPairs = kGatherMaxPairs;  // BSP_GATHER_MAX_PAIRS
   double bulkAhead = 0.8;     // BSP_BULK_AHEAD (round 4: 0.6 -> 0.8, -0.04 ms on BAL-871; profiles/r04_ab_plan_knobs.txt)
-  bool gatherOverlap = true;  // BSP_GATHER_OVERLAP=0: the whole gather before the dense phase
+  bool gatherOverlap = false; // BSP_GATHER_OVERLAP=1: gather chunks beside the dense chain (measured: no gain, profiles/r06_ab_gather_overlap.txt)
   int32_t overlapFirst = 2;   // column blocks in chunk 0 (BSP_GATHER_OVERLAP_FIRST)
   int32_t overlapStep = 3;    // ... in every later chunk (BSP_GATHER_OVERLAP_STEP)
   int32_t overlapMinBlocks = 8;  // narrowest target lump, in column blocks
