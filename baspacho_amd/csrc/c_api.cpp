@@ -611,6 +611,7 @@ int bsp_run_counters_get(bsp_solver* s, bsp_run_counters* out) {
   out->sweeps_retired = c.sweepsRetired;
   out->sweep_error_pending = c.sweepErrorPending;
   out->gather_chunks_overlapped = c.gatherChunksOverlapped;
+  out->tail_launches = c.tailLaunches;
   BSP_CATCH
 }
 

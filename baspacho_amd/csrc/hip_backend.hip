@@ -15,6 +15,7 @@
 #include "hip_kernels.h"
 #include "hip_solve_kernels.h"
 #include "hip_sweep_kernels.h"
+#include "hip_tail_kernel.h"
 #include "mat_ops.h"
 
 namespace BaSpaCho {
@@ -476,6 +477,8 @@ struct HipSymbolicCtx : SymbolicCtx {
     yieldBuf.release();
     solveInvScratch.release();
     sweepXchg.release();
+    tailCtl.release();
+    tailDinv.release();
     for (DevBuf* b : {&dSpanStart, &dSpanToLump, &dLumpStart, &dSpanOffsetInLump, &dChainColPtr,
                       &dChainRowSpan, &dChainData, &dChainRowsTillEnd, &dBoardColPtr,
                       &dBoardChainColOrd, &dPermutation}) {
@@ -703,6 +706,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool sweepBroken = false;   // a sweep timed out or cannot be launched here: multi-launch path for good
   int sweepFault = 0;         // TESTING (bsp_test_set_fault kind 2): spine of block 1 never publishes
   double sweepSpinLimitS = 2.0;  // watchdog: a spin that lasts longer aborts the launch
+  DevBuf tailCtl, tailDinv;   // persistent tail (hip_tail_kernel.h): control words, inverted diagonal blocks
   DevBuf sweepXchg;           // control words + exchange values of one denseLevels call
   DevBuf sweepTrace;          // developer aid (BSP_SWEEP_TRACE=1): clock stamps of the spines of the last sweep
   bool sweepTraceOn = false;
@@ -713,21 +717,42 @@ struct HipSymbolicCtx : SymbolicCtx {
   int sweepAttr[2] = {0, 0};  // per value size (8, 4): 0 not tried, 1 ready, -1 failed
   struct RunCounters {
     int64_t sweepLaunches = 0, sweepTimeouts = 0, splitListsUsed = 0, subBatchesEnqueued = 0,
-            lookaheadForks = 0, gatherChunksOverlapped = 0;
+            lookaheadForks = 0, gatherChunksOverlapped = 0, tailLaunches = 0;
   } counters;
-  // a timed-out sweep is reported ONCE, by the next call that would have used one
-  bool sweepUsable() {
-    if (!sweepEnabled || sweepBroken || !solveInv || !blockSolve) return false;
+  // a timed-out persistent launch (solve sweep, factor tail) is reported ONCE, by the next factor()
+  // or solve() on this Solver; the persistent kernels are then retired for good
+  void checkAsyncError() {
     if (sweepHostErr && *reinterpret_cast<volatile unsigned*>(sweepHostErr) != 0u) {
       *reinterpret_cast<volatile unsigned*>(sweepHostErr) = 0u;
       sweepBroken = true;
       counters.sweepTimeouts++;
+      if (planOpts.tailBlocks > 0) {
+        (void)hipDeviceSynchronize();  // (nothing of the old plans may still be queued)
+        planOpts.tailBlocks = 0;
+        plans.clear();
+      }
       throw std::runtime_error(
-          "HIP backend: a persistent solve sweep of an EARLIER call on this Solver timed out (watchdog); "
-          "the result of that call is invalid.  The sweeps are retired for this Solver: solves take "
-          "the multi-launch path from now on");
+          "HIP backend: a persistent launch (solve sweep / factor tail) of an EARLIER call on this "
+          "Solver timed out (watchdog); the result of that call is invalid.  The persistent kernels "
+          "are retired for this Solver: it takes the multi-launch paths from now on");
     }
-    return true;
+  }
+  bool sweepUsable() {
+    checkAsyncError();
+    return sweepEnabled && !sweepBroken && solveInv && blockSolve;
+  }
+  // pinned host word a watchdog raises (persistent sweeps and tails), and its device alias
+  unsigned* asyncErrWord() {
+    if (!sweepHostErr) {
+      void* hp = nullptr;
+      hipCHECK(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+      sweepHostErr = reinterpret_cast<unsigned*>(hp);
+      *sweepHostErr = 0u;
+      void* dp = nullptr;
+      hipCHECK(hipHostGetDevicePointer(&dp, hp, 0));
+      sweepHostErrDev = reinterpret_cast<unsigned*>(dp);
+    }
+    return sweepHostErrDev;
   }
   template <typename BT>
   bool sweepReady() {
@@ -871,6 +896,7 @@ struct HipNumericCtx : NumericCtx<T> {
     // gather overlap: chunks each stream has already waited for (events of one stream complete in order)
     const bool chunks = &levels == &plan.host.levels && !gatherChunkDone.empty();
     int waitedExec = 0, waitedDue = 0, waitedSide = 0;
+    hipEvent_t lastOpt = nullptr;  // the most recent optional lookahead launch (side stream)
     auto waitChunk = [&](hipStream_t st, int& waited, int32_t chunk) {
       if (!chunks || chunk <= waited || chunk >= (int32_t)gatherChunkDone.size()) return;
       hipCHECK(hipStreamWaitEvent(st, gatherChunkDone[chunk], 0));
@@ -882,6 +908,42 @@ struct HipNumericCtx : NumericCtx<T> {
       const unsigned nT = (unsigned)(lr.trsmEnd - lr.trsmBegin);
       const bool direct = lr.directPanel >= 0;
       waitChunk(sym.stream, waitedExec, lr.gatherNow);
+      if (lr.tail) {
+        if (lr.tail == 1) {
+          // PERSISTENT TAIL (hip_tail_kernel.h): everything the lookahead streams still owe to these
+          // columns first, then one launch for all the panels of the tail
+          auto joinStream = [&](hipStream_t st) {
+            hipEvent_t e = sym.eventFromPool();
+            hipCHECK(hipEventRecord(e, st));
+            hipCHECK(hipStreamWaitEvent(sym.stream, e, 0));
+          };
+          if (sideUsed) joinStream(sym.sideStream());
+          if (dueUsed) joinStream(sym.dueSideStream());
+          sideUsed = dueUsed = false;
+          const PanelDesc& p0 = plan.host.panels[lr.directPanel];
+          hipk::TailDesc td;
+          td.diagOff = p0.diagOff;
+          td.lda = p0.lda;
+          td.K = p0.nb + p0.nRest;
+          td.nP = (td.K + kTile - 1) / kTile;
+          td.ctlStride = hipk::tailCtlWords(td.nP);
+          BASPACHO_CHECK_EQ(td.nP, lr.tailPanels);
+          const size_t ctlBytes = (size_t)td.ctlStride * scratchBatch * sizeof(unsigned);
+          sym.tailCtl.resize(ctlBytes);
+          sym.tailDinv.resize((size_t)scratchBatch * td.nP * hipk::kDinvSlot * sizeof(BT));
+          unsigned* ctl = reinterpret_cast<unsigned*>(sym.tailCtl.ptr) + (size_t)subBatchBase * td.ctlStride;
+          BT* tdinv = const_cast<BT*>(sym.tailDinv.as<BT>()) + (size_t)subBatchBase * td.nP * hipk::kDinvSlot;
+          hipCHECK(hipMemsetAsync(ctl, 0xff, (size_t)td.ctlStride * batchSize * sizeof(unsigned), sym.stream));
+          timer.begin(kProfChainUpdate);
+          hipk::tailFactor<BT><<<dim3((unsigned)hipk::tailRoles(td.nP), gy.y), 256, 0, sym.stream>>>(
+              td, ref, tdinv, ctl, sym.asyncErrWord(), (long long)(sym.sweepSpinLimitS * 1e8));
+          timer.end();
+          sym.counters.tailLaunches++;
+        }
+        rawValid = false;
+        potrfFused = false;
+        continue;
+      }
       const int slot = dinvSlot;
       dinvSlot ^= 1;
       BT* dinvCur = dinvBase + slot * hipk::kDinvSlot;
@@ -978,6 +1040,7 @@ struct HipNumericCtx : NumericCtx<T> {
           hipCHECK(hipStreamWaitEvent(due, fork, 0));
           waitChunk(due, waitedDue, lr.gatherDue);
           waitChunk(sym.sideStream(), waitedSide, lr.gatherOpt);
+          if (lr.flushDue && lastOpt) hipCHECK(hipStreamWaitEvent(due, lastOpt, 0));
           const int64_t f2 = lr.optWaitLevel;
           if (f2 >= 0 && optDone[f2]) hipCHECK(hipStreamWaitEvent(due, optDone[f2], 0));
           if (lr.defMid > lr.defBegin) {
@@ -993,6 +1056,7 @@ struct HipNumericCtx : NumericCtx<T> {
             timer.end();
             optDone[li] = sym.eventFromPool();
             hipCHECK(hipEventRecord(optDone[li], sym.sideStream()));
+            lastOpt = optDone[li];
           }
           sideUsed = dueUsed = true;
           return;
@@ -1267,6 +1331,7 @@ struct HipNumericCtx : NumericCtx<T> {
   //  stack -- GRID 82x82 1.66-1.79 against 1.74-1.77 ms, BAL-871 7.15 = 7.16: the runtime plays a
   //  graph back as the same packets on the same queues -- and removed in round 4)
   virtual void factorRange(T* data, int64_t startLump, int64_t upToLump) override {
+    sym.checkAsyncError();
     DevPlan& plan = sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
     hipk::DataRef<BT> ref = makeRef(data);
     LaunchTimer timer(sym.stream, sym.profile);
@@ -2147,6 +2212,7 @@ HipRunCounters hipBackendRunCounters(SymbolicCtx& sym) {
   c.subBatchesEnqueued = h->counters.subBatchesEnqueued;
   c.lookaheadForks = h->counters.lookaheadForks;
   c.gatherChunksOverlapped = h->counters.gatherChunksOverlapped;
+  c.tailLaunches = h->counters.tailLaunches;
   c.sweepsRetired = h->sweepBroken ? 1 : 0;
   c.sweepErrorPending = (h->sweepHostErr && *reinterpret_cast<volatile unsigned*>(h->sweepHostErr)) ? 1 : 0;
   return c;

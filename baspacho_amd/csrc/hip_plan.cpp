@@ -336,6 +336,7 @@ HipPlanOptions HipPlanOptions::fromEnv() {
   o.planTiming = std::getenv("BSP_TIMING") != nullptr;
   if (const char* e = std::getenv("BSP_GATHER_MAX_PAIRS")) o.gatherMaxPairs = std::max(8, atoi(e));
   if (const char* e = std::getenv("BSP_BULK_AHEAD")) o.bulkAhead = std::atof(e);
+  if (const char* e = std::getenv("BSP_TAIL_BLOCKS")) o.tailBlocks = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("BSP_GATHER_OVERLAP")) o.gatherOverlap = e[0] != '0';
   if (const char* e = std::getenv("BSP_GATHER_OVERLAP_FIRST")) o.overlapFirst = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BSP_GATHER_OVERLAP_STEP")) o.overlapStep = std::max(1, std::atoi(e));
@@ -374,6 +375,16 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     int32_t count = 0;
     const int64_t n = g.width;
     vector<int64_t> pendingFrom;  // per column block of this lump (lookahead schedule, see below)
+    // PERSISTENT TAIL: columns from tailFrom on belong to one launch of hip_tail_kernel.h -- their
+    // panels exist (the solves walk them) but carry no segments, and the block before them hands ALL
+    // its pending lookahead units over at once
+    int64_t tailFrom = -1;
+    {
+      const int64_t numBlocks = (n + kOuterWidth - 1) / kOuterWidth;
+      if (opts.tailBlocks > 0 && g.rowsBelow == 0 && numBlocks >= opts.tailMinBlocks) {
+        tailFrom = kOuterWidth * std::max<int64_t>(1, numBlocks - opts.tailBlocks);
+      }
+    }
     for (int64_t blockStart = 0; blockStart < n; blockStart += kOuterWidth) {
       const int64_t blockEnd = std::min<int64_t>(n, blockStart + kOuterWidth);
       for (int64_t c0 = blockStart; c0 < blockEnd; c0 += kPanelWidth, count++) {
@@ -387,11 +398,17 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         pd.lumpRowBase = lumpRowBase;
         pd.lump = (int32_t)l;
         pd.vecOff = (int32_t)(sk.lumpStart[l] + c0);
-        pd.pad = 0;
+        pd.pad = (tailFrom >= 0 && c0 >= tailFrom) ? 1 : 0;
         plan.panels.push_back(pd);
         plan.potrfFlops += double(nb) * nb * nb / 3.0;
         plan.trsmFlops += double(pd.rowsBelow) * nb * nb;
         panelSegBegin.push_back((int64_t)plan.segs.size());
+        if (pd.pad) {  // inside the tail: no segments
+          panelSegEnd.push_back((int64_t)plan.segs.size());
+          const double m = double(n - c0 - nb);
+          plan.tailUpdFlops += 2.0 * nb * (m * (m + 1) / 2);
+          continue;
+        }
         const int64_t innerCols = blockEnd - c0 - nb;
         if (innerCols > 0) {
           SrcDesc sr{};
@@ -488,6 +505,10 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
               // (topping the first launch up to a full round of workgroups with the nearest
               //  optional targets was measured slower: the execution stream waits on it)
               int64_t c = b + 2;
+              if (tailFrom >= 0 && blockEnd == tailFrom) {
+                // the block before a persistent tail: everything still pending, as due units
+                for (; c < numBlocks; c++) pushUnit(c, 2);
+              }
               if (c < numBlocks) {
                 budgetUs -= unitFlops(c) / kBulkFlopsPerUs;
                 pushUnit(c++, 2);
@@ -644,6 +665,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
   auto emitLevels = [&](const vector<vector<PanelBuild>>& buckets, vector<LevelRange>& out) {
     std::map<int32_t, int64_t> lastDeferredLevel;  // lump -> level index that deferred tiles
     std::map<int32_t, std::vector<int64_t>> blockForks;  // lump -> its block-boundary fork levels
+    int64_t tailHead = -1;
     for (const auto& bucket : buckets) {
       LevelRange lr;
       lr.panelBegin = (int64_t)plan.levelPanels.size();
@@ -653,9 +675,26 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       const int64_t levelIdx = (int64_t)out.size();
       // single-panel level followed by a single-panel level of the same lump?
       const size_t bi = (size_t)(&bucket - &buckets[0]);
+      // (a persistent tail takes the chain over: the level before it fuses / stages nothing for it)
       const bool chain = bucket.size() == 1 && bi + 1 < buckets.size() &&
                          buckets[bi + 1].size() == 1 &&
-                         plan.panels[buckets[bi + 1][0].panel].lump == plan.panels[bucket[0].panel].lump;
+                         plan.panels[buckets[bi + 1][0].panel].lump == plan.panels[bucket[0].panel].lump &&
+                         plan.panels[buckets[bi + 1][0].panel].pad == 0;
+      if (bucket.size() == 1 && plan.panels[bucket[0].panel].pad == 1) {
+        const bool first = out.empty() || out.back().tail == 0;
+        lr.panelEnd = lr.panelBegin;
+        lr.trsmEnd = lr.trsmBegin;
+        lr.updEnd = lr.defBegin = lr.defMid = lr.defEnd = lr.updBegin;
+        lr.directPanel = bucket[0].panel;
+        lr.tail = first ? 1 : 2;
+        if (first) {
+          plan.numLaunches += 1;
+          tailHead = (int64_t)out.size();
+        }
+        out.push_back(lr);
+        out[tailHead].tailPanels++;
+        continue;
+      }
       vector<UpdTask> deferred, deferredLate;  // due / optional
       int32_t nowSegs = 0, nowSeg = -1;  // segments with non-deferred 64x64 tiles in this level
       bool nowPlain = true;              // ... all intra-lump, non-atomic, untouched order
@@ -802,6 +841,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       plan.numLaunches += 1 + (lr.trsmEnd > lr.trsmBegin) + (lr.updEnd > lr.updBegin) +
                           (lr.defEnd > lr.defBegin);
       out.push_back(lr);
+    }
+    for (size_t li = 1; li < out.size(); li++) {
+      if (out[li].tail == 1) out[li - 1].flushDue = 1;
     }
     // which trsm / potrf run inside another launch (measurement only)
     for (size_t li = 0; li < out.size(); li++) {

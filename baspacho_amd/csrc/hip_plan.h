@@ -155,6 +155,13 @@ struct LevelRange {
   // gather overlap (ElimRangePlan::chunkItemPtr): chunk that must be complete before this level's
   // own launches / its due lookahead units / its optional ones; -1: none
   int32_t gatherNow = -1, gatherDue = -1, gatherOpt = -1;
+  // persistent tail: 1 = this level's panel is the first of a tail (the launch factors tailPanels
+  // panels from here, after a join with the lookahead streams), 2 = a panel inside a tail (nothing to launch)
+  int32_t tail = 0, tailPanels = 0;
+  // the level before a tail hands over every pending lookahead unit as due units: their launch must
+  // also wait for the optional units of the PREVIOUS block boundary (plain read-modify-write on the
+  // same columns)
+  int32_t flushDue = 0;
 };
 
 // One work item of the gather-form sparse-elimination update: a target block (sj,si) of the
@@ -234,6 +241,11 @@ struct HipPlanOptions {
   int32_t overlapFirst = 2;   // column blocks in chunk 0 (BSP_GATHER_OVERLAP_FIRST)
   int32_t overlapStep = 3;    // ... in every later chunk (BSP_GATHER_OVERLAP_STEP)
   int32_t overlapMinBlocks = 8;  // narrowest target lump, in column blocks
+  // PERSISTENT TAIL (hip_tail_kernel.h): the last tailBlocks outer blocks of a lump that has nothing
+  // below it and is at least tailMinBlocks blocks wide are factored by ONE flag-synchronised launch
+  // (BSP_TAIL_BLOCKS; 0: the level schedule to the end)
+  int32_t tailBlocks = 0;
+  int32_t tailMinBlocks = 6;
   static HipPlanOptions fromEnv();
 };
 
@@ -253,6 +265,7 @@ struct HipPlanHost {
   std::vector<int32_t> rowChain, rowLocal, rowColOff;  // per chain row of every dense lump
   std::vector<int32_t> rowGlobal;                      // ... and its row index in the full matrix
 
+  double tailUpdFlops = 0;  // update flops done inside persistent tail launches (not in updFlops)
   double updFlopsDirect = 0, elimPairOperandElems = 0, elimTargetElems = 0, trsmFlops = 0,
          potrfFlops = 0;  // part of updFlops launched through the direct chain kernels
   // of trsmFlops / potrfFlops: the part done inside chainStep launches / inside the previous

@@ -1,0 +1,250 @@
+// Persistent, flag-synchronised Cholesky of the TAIL of a wide root lump (round 6).
+//
+// The last outer blocks of a wide lump that has nothing below it (the camera block of a Schur
+// complement, the root front of FLAT) are a plain dense Cholesky whose trailing matrix no longer
+// fills the GPU: the level schedule walks them with one chainStep launch per 64-column panel, 17-19
+// us each plus the event gaps of the lookahead streams -- ~95 us per 256 columns with a tenth of the
+// machine working.  Here ONE launch factors the whole K x K tail.  Replaces the cusolverDnDpotrf +
+// cublasDtrsm + cublasDgemm chain of MatOpsCuda.cu:508-590 for those columns.
+//
+// Workgroups take ROLES over the 64 x 64 tiles (i, j), i >= j, of the tail's lower triangle; a role
+// keeps the rank-64 updates its tile has received so far in MFMA ACCUMULATORS for the whole launch
+// (no read-modify-write of the trailing matrix at all) and meets the others only through flags:
+//   tile (i, j), i >= j + 2:  for p < j: wait X(p, i), X(p, j) -> D += X_i^p (X_j^p)^T;  then wait
+//        diag(j) -> X_i^j = (A_ij - D) L_jj^-T (register trsm through the inverted 16 x 16 diagonal
+//        blocks, as chainStep), stored in place = the final entries of L -> flag X(j, i); done.
+//   spine q:  owns BOTH the diagonal tile (q, q) and the tile left of it (q, q-1), so that the
+//        serial chain crosses workgroups ONCE per panel: it accumulates both tiles for p < q-1, and
+//        when diag(q-1) arrives it solves X_q^{q-1} itself, applies it to its diagonal tile, runs the
+//        blocked panel Cholesky (potrfPanelTiles, with the pending update folded into its load) and
+//        raises diag(q).  Its X_q^{q-1} is stored and flagged for the tiles of column q.
+// Roles are dealt by ticket in an order in which a role only waits for smaller tickets (spine 0; then
+// per column j: spine j+1, tiles (j+2.., j)), so the launch cannot deadlock whether or not all of it
+// is resident; a role that starts late replays the finished panels at L2 speed.  Flags: release
+// (agent) after the stores, relaxed polls, one acquire fence per wait (tools/flag_hop_probe.hip: 2.05
+// us per hop with a 32-KB tile read and written).  Every spin is bounded by the watchdog of the
+// persistent sweeps (SweepWatch): on expiry the launch aborts and the host retires the kernel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "hip_kernels.h"
+#include "hip_sweep_kernels.h"
+
+namespace BaSpaCho {
+namespace hipk {
+
+struct TailDesc {
+  int64_t diagOff;  // data offset of element (0, 0) of the tail
+  int32_t lda;      // row stride (lump width)
+  int32_t K;        // order of the tail
+  int32_t nP;       // ceil(K / 64)
+  int32_t ctlStride;  // control words per matrix: abort, ticket, nP diag flags, nP x nP X flags
+};
+inline int tailCtlWords(int nP) { return 2 + nP + nP * nP; }
+inline int tailRoles(int nP) { return 1 + nP * (nP - 1) / 2; }
+
+// control words are armed to all ones (one memset): a flag is raised by storing 0
+__device__ __forceinline__ void tailRaise(GP<unsigned> f) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every wave waits for itself (no workgroup barrier inside a wait); false = abort
+__device__ __forceinline__ bool tailWait(GP<const unsigned> f0, GP<const unsigned> f1, SweepWatch& watch) {
+  watch.reset();
+  for (;;) {
+    const unsigned a = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned b = f1 ? __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (a == 0u && b == 0u) break;
+    if (watch.expired()) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+
+template <typename T>
+struct TailTile {
+  using Acc = typename Mfma<T>::Acc;
+  // D[t] += X_i (X_j rows 16 t .. 16 t + 15)^T for source panel p: X_i = rows of tile row `ti`, X_j =
+  // rows of tile row `tj`, both columns 64 p .. 64 p + 63 of the tail (final entries of L, in place)
+  static __device__ __forceinline__ void fetch(GP<const T> A, int lda, int K, int ti, int tj, int p,
+                                               Acc (&xi)[4], T (&v)[16]) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15;
+    const int ri = kTile * ti + 16 * w + n;
+    trsmLoadRows<T>(A + (int64_t)min(ri, K - 1) * lda + kTile * p, kTile, lane, xi);
+    trsmMaskRows<T>(ri < K, kTile, lane, xi);
+    const int rj = kTile * tj + (tid >> 2);
+    GP<const T> rowJ = A + (int64_t)min(rj, K - 1) * lda + kTile * p + 16 * (tid & 3);
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const T a = rowJ[c];
+      v[c] = rj < K ? a : T(0);
+    }
+  }
+  static __device__ __forceinline__ void stageB(const T (&v)[16], T* XB) {
+    const int tid = threadIdx.x;
+    ldsBarrier();  // XB free
+#pragma unroll
+    for (int c = 0; c < 16; c++) XB[(tid >> 2) * kXbLd + 16 * (tid & 3) + c] = v[c];
+    ldsBarrier();
+  }
+  static __device__ __forceinline__ void multiply(const Acc (&xi)[4], const T* XB, bool diag, Acc (&D)[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (!diag || t <= w) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            D[t] = Mfma<T>::run(xi[j][r], XB[(16 * t + n) * kXbLd + 16 * j + 4 * q + r], D[t]);
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+  }
+  // x = (A_ij - D) L_jj^-T for the rows of tile row ti against panel j (nb columns): in the layout of
+  // trsmStages (lane (q, n): row n of the wave's 16, columns 16 jj + 4 q + r), stored in place
+  static __device__ __forceinline__ void solve(GP<T> A, GP<const T> dinv, int lda, int K, int ti, int j,
+                                               int nb, const Acc (&D)[4], const Acc (&raw)[4], T* XB,
+                                               Acc (&x)[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    TrsmOps<T> o;
+    trsmLoadOps<T>((GP<const T>)A + (int64_t)kTile * j * lda + kTile * j, dinv, lda, nb, lane, o);
+    // the accumulated update, from accumulator layout to row layout through XB
+    ldsBarrier();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) XB[(16 * w + Mfma<T>::row(lane, reg)) * kXbLd + 16 * t + n] = D[t][reg];
+    }
+    ldsBarrier();
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) x[jj][r] = raw[jj][r] - XB[(16 * w + n) * kXbLd + 16 * jj + 4 * q + r];
+    }
+    const int ri = kTile * ti + 16 * w + n;
+    trsmMaskRows<T>(ri < K, nb, lane, x);
+    trsmMaskOps<T>(nb, lane, o);
+    trsmStages<T>(o, nb, x);
+    trsmStoreRows<T>(A + (int64_t)min(ri, K - 1) * lda + kTile * j, ri < K, nb, lane, x);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void tailFactor(
+    TailDesc td, DataRef<T> dref, T* dinvBase, unsigned* ctlBase, unsigned* hostErr, long long spinLimit) {
+  __shared__ T XB[kTile * kXbLd];
+  __shared__ int sTicket;
+  static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd + 4 * kPanelWidth * 4 <= kTile * kXbLd, "potrf buffers fit in XB");
+  using Acc = typename Mfma<T>::Acc;
+  using TT = TailTile<T>;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15;
+  const int nP = td.nP, lda = td.lda, K = td.K;
+  GP<unsigned> ctl = (GP<unsigned>)ctlBase + (size_t)blockIdx.y * td.ctlStride;
+  if (tid == 0) sTicket = (int)(atomicAdd((unsigned*)ctl + 1, 1u) + 1u);  // armed to all ones
+  __syncthreads();
+  int k = sTicket, i = 0, j = 0;
+  bool spine = true;
+  if (k > 0) {  // column j: spine j + 1, then tiles (j + 2 .., j)
+    k -= 1;
+    for (;;) {
+      const int cnt = nP - 1 - j;
+      if (k < cnt) break;
+      k -= cnt;
+      j++;
+    }
+    spine = k == 0;
+    i = j + 1 + k;
+  }
+  SweepWatch watch;
+  watch.abortWord = ctl;
+  watch.hostErr = hostErr;
+  watch.limit = spinLimit;
+  watch.reset();
+  GP<T> A = pickData(dref) + td.diagOff;
+  GP<T> dinvAll = (GP<T>)dinvBase + (size_t)blockIdx.y * nP * kDinvSlot;
+  GP<unsigned> diagFlag = ctl + 2;
+  GP<unsigned> xFlag = ctl + 2 + nP;  // [p * nP + i]: rows of tile row i of panel p are final
+  auto nbOf = [&](int p) { return min(kTile, K - kTile * p); };
+
+  if (!spine) {
+    // ---- tile (i, j), i >= j + 2
+    Acc D[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, xi[4];
+    T v[16];
+    for (int p = 0; p < j; p++) {
+      if (!tailWait(xFlag + p * nP + i, xFlag + p * nP + j, watch)) return;
+      TT::fetch(A, lda, K, i, j, p, xi, v);
+      TT::stageB(v, XB);
+      TT::multiply(xi, XB, false, D);
+    }
+    Acc raw[4], x[4];
+    const int ri = kTile * i + 16 * w + n, nb = nbOf(j);
+    trsmLoadRows<T>((GP<const T>)A + (int64_t)min(ri, K - 1) * lda + kTile * j, nb, lane, raw);
+    if (!tailWait(diagFlag + j, nullptr, watch)) return;
+    TT::solve(A, dinvAll + (size_t)j * kDinvSlot, lda, K, i, j, nb, D, raw, XB, x);
+    __syncthreads();  // every wave's stores issued
+    if (tid == 0) tailRaise(xFlag + j * nP + i);
+    return;
+  }
+
+  // ---- spine q: diagonal tile (q, q) and, for q >= 1, the tile left of it
+  const int q = i;  // (spine 0: i = j = 0)
+  Acc Dd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  if (q >= 1) {
+    Acc Ds[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, xi[4];
+    T v[16];
+    for (int p = 0; p < q - 1; p++) {
+      if (!tailWait(xFlag + p * nP + q, xFlag + p * nP + q - 1, watch)) return;
+      TT::fetch(A, lda, K, q, q - 1, p, xi, v);
+      TT::stageB(v, XB);
+      TT::multiply(xi, XB, false, Ds);
+      // the diagonal tile: X_q against itself
+      TT::fetch(A, lda, K, q, q, p, xi, v);
+      TT::stageB(v, XB);
+      TT::multiply(xi, XB, true, Dd);
+    }
+    Acc raw[4], x[4];
+    const int ri = kTile * q + 16 * w + n;
+    trsmLoadRows<T>((GP<const T>)A + (int64_t)min(ri, K - 1) * lda + kTile * (q - 1), kTile, lane, raw);
+    if (!tailWait(diagFlag + q - 1, nullptr, watch)) return;
+    TT::solve(A, dinvAll + (size_t)(q - 1) * kDinvSlot, lda, K, q, q - 1, kTile, Ds, raw, XB, x);
+    // X_q^{q-1} against itself: the B operand is x in XB's row layout
+    ldsBarrier();
+    {
+      const int qq = lane >> 4;
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) XB[(16 * w + n) * kXbLd + 16 * jj + 4 * qq + r] = x[jj][r];
+      }
+    }
+    ldsBarrier();
+    TT::multiply(x, XB, true, Dd);
+    __syncthreads();  // the stores of X_q^{q-1} are issued by every wave; XB free for the potrf
+    if (tid == 0 && q + 1 < nP) tailRaise(xFlag + (q - 1) * nP + q);
+  }
+  {
+    __builtin_amdgcn_s_setprio(3);
+    T(*blk)[4] = reinterpret_cast<T(*)[4]>(XB);
+    T(*sol)[4] = blk + 3 * kPanelWidth;
+    T* Ld = XB + 4 * kPanelWidth * 4;
+    auto pre = [&](Acc* acc) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (t <= w) acc[t] -= Dd[t];
+      }
+    };
+    potrfPanelTiles<T>(A + (int64_t)kTile * q * lda + kTile * q, nbOf(q), lda, blk, sol,
+                       XB + 4 * kPanelWidth * 4 + kPanelWidth * kInvLd, pre, Ld,
+                       dinvAll + (size_t)q * kDinvSlot);
+    __syncthreads();
+    if (tid == 0 && q + 1 < nP) tailRaise(diagFlag + q);
+  }
+}
+
+}  // namespace hipk
+}  // namespace BaSpaCho

@@ -282,6 +282,7 @@ typedef struct bsp_run_counters {
   int64_t sweeps_retired;       /* 1: a time-out retired the sweeps of this solver */
   int64_t sweep_error_pending;  /* 1: a time-out has been raised and not been reported yet */
   int64_t gather_chunks_overlapped; /* sparse-elimination gather chunks launched beside the dense chain */
+  int64_t tail_launches;        /* persistent tail launches (csrc/hip_tail_kernel.h) */
 } bsp_run_counters;
 int bsp_run_counters_get(bsp_solver* s, bsp_run_counters* out);
 

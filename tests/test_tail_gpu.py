@@ -1,0 +1,77 @@
+"""Persistent, flag-synchronised Cholesky of the tail of a wide root lump (csrc/hip_tail_kernel.h,
+round 6): ONE launch factors the last outer blocks of a lump that has nothing below it, in place of
+the per-panel chain launches (cusolverDnDpotrf + cublasDtrsm + cublasDgemm, MatOpsCuda.cu:508-590).
+Parity against numpy's Cholesky at the reference's tolerances (tests/FactorTest.cpp:32-41) for tails
+of 2 .. all-but-one outer blocks, ragged last panels, fp64 / fp32, a batch; the run counters assert
+that the tail launch was the path taken."""
+import numpy as np
+import pytest
+
+import baspacho_amd as B
+from baspacho_amd import testing as T
+from helpers import spd_data, dense_lower_chol, lower_of, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_solver(W, span=8):
+    sizes = [span] * (W // span) + ([W % span] if W % span else [])
+    nparam = len(sizes)
+    cols = [list(range(c, nparam)) for c in range(nparam)]
+    ss = T.columns_to_structure(cols)
+    return B.create_solver(B.Settings(findSparseEliminationRanges=False), np.asarray(sizes, dtype=np.int64), ss, [])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("blocks", [2, 4, 100])
+def test_tail_of_one_wide_lump(monkeypatch, dtype, blocks):
+    monkeypatch.setenv("BSP_TAIL_BLOCKS", str(blocks))
+    for W in (1536, 1599, 1601, 1664, 2049, 2500):
+        sol = _dense_solver(W, span=8 if W % 2 == 0 else 7)
+        data = spd_data(sol, 3 + W, dtype=dtype)
+        L, A = dense_lower_chol(sol, data)
+        dev = to_dev(data)
+        before = sol.runCounters()["tail_launches"]
+        sol.factor(dev)
+        got = lower_of(sol, dev.cpu().numpy())
+        assert sol.runCounters()["tail_launches"] == before + 1, "the persistent tail was not the path taken"
+        err = np.linalg.norm(got - L) / np.linalg.norm(L)
+        assert err < (1e-12 if dtype == np.float64 else 2e-5), (W, blocks, err)
+        tail = np.linalg.norm(got[-64:, -64:] - L[-64:, -64:]) / np.linalg.norm(L[-64:, -64:])
+        assert tail < (1e-11 if dtype == np.float64 else 1e-4), (W, blocks, tail)
+        # and a solve on that factor (the tail's panels are ordinary panels to the solve paths)
+        n = sol.order()
+        rhs = np.random.default_rng(W).standard_normal(n)
+        v = to_dev(rhs.astype(dtype))
+        sol.solve(dev, v, n, 1)
+        X = np.linalg.solve(A, rhs)
+        serr = np.linalg.norm(v.cpu().numpy().astype(np.float64) - X) / np.linalg.norm(X)
+        assert serr < (1e-10 if dtype == np.float64 else 1e-3), (W, blocks, serr)
+
+
+def test_tail_batched(monkeypatch):
+    monkeypatch.setenv("BSP_TAIL_BLOCKS", "3")
+    sol = _dense_solver(1700)
+    mats, dense = [], []
+    for q in range(3):
+        data = spd_data(sol, 40 + q)
+        mats.append(to_dev(data))
+        dense.append(dense_lower_chol(sol, data)[0])
+    before = sol.runCounters()["tail_launches"]
+    sol.factor(mats)
+    assert sol.runCounters()["tail_launches"] == before + 1
+    for q in range(3):
+        got = lower_of(sol, mats[q].cpu().numpy())
+        assert np.linalg.norm(got - dense[q]) / np.linalg.norm(dense[q]) < 1e-12, q
+
+
+def test_no_tail_for_a_lump_with_rows_below_or_a_narrow_one(monkeypatch):
+    monkeypatch.setenv("BSP_TAIL_BLOCKS", "4")
+    sol = _dense_solver(1100)  # five outer blocks: below the minimum
+    data = spd_data(sol, 5)
+    dev = to_dev(data)
+    sol.factor(dev)
+    assert sol.runCounters()["tail_launches"] == 0
+    L, _ = dense_lower_chol(sol, data)
+    got = lower_of(sol, dev.cpu().numpy())
+    assert np.linalg.norm(got - L) / np.linalg.norm(L) < 1e-12
