@@ -430,6 +430,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_SPLIT_K")) splitK = e[0] != '0';
     if (const char* e = std::getenv("BSP_SOLVE_SWEEP")) sweepEnabled = e[0] != '0';
     if (const char* e = std::getenv("BSP_GATHER_OVERLAP")) gatherOverlap = e[0] != '0';
+    if (const char* e = std::getenv("BSP_TAIL_FLAGS")) tailFlags = std::atoi(e);
     if (const char* e = std::getenv("BSP_GATHER_OVERLAP_LDS")) gatherOverlapLds = (unsigned)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BSP_SWEEP_MIN_WIDTH")) sweepMinWidth = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BSP_SWEEP_TRACE")) sweepTraceOn = e[0] != '0';
@@ -706,6 +707,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool sweepBroken = false;   // a sweep timed out or cannot be launched here: multi-launch path for good
   int sweepFault = 0;         // TESTING (bsp_test_set_fault kind 2): spine of block 1 never publishes
   double sweepSpinLimitS = 2.0;  // watchdog: a spin that lasts longer aborts the launch
+  int tailFlags = 1;          // TailDesc::flags (BSP_TAIL_FLAGS)
   DevBuf tailCtl, tailDinv;   // persistent tail (hip_tail_kernel.h): control words, inverted diagonal blocks
   DevBuf sweepXchg;           // control words + exchange values of one denseLevels call
   DevBuf sweepTrace;          // developer aid (BSP_SWEEP_TRACE=1): clock stamps of the spines of the last sweep
@@ -740,6 +742,14 @@ struct HipSymbolicCtx : SymbolicCtx {
   bool sweepUsable() {
     checkAsyncError();
     return sweepEnabled && !sweepBroken && solveInv && blockSolve;
+  }
+  long long* tailTrace() {  // developer aid (BSP_SWEEP_TRACE=1): the spines' clock stamps
+    if (!sweepTraceOn) return nullptr;
+    if (!sweepTrace.ptr) {
+      sweepTrace.resize(4 * 4096 * sizeof(long long));
+      hipCHECK(hipMemset(sweepTrace.ptr, 0, 4 * 4096 * sizeof(long long)));
+    }
+    return reinterpret_cast<long long*>(sweepTrace.ptr);
   }
   // pinned host word a watchdog raises (persistent sweeps and tails), and its device alias
   unsigned* asyncErrWord() {
@@ -927,6 +937,8 @@ struct HipNumericCtx : NumericCtx<T> {
           td.K = p0.nb + p0.nRest;
           td.nP = (td.K + kTile - 1) / kTile;
           td.ctlStride = hipk::tailCtlWords(td.nP);
+          td.flags = sym.tailFlags;
+          td.pad = 0;
           BASPACHO_CHECK_EQ(td.nP, lr.tailPanels);
           const size_t ctlBytes = (size_t)td.ctlStride * scratchBatch * sizeof(unsigned);
           sym.tailCtl.resize(ctlBytes);
@@ -936,7 +948,7 @@ struct HipNumericCtx : NumericCtx<T> {
           hipCHECK(hipMemsetAsync(ctl, 0xff, (size_t)td.ctlStride * batchSize * sizeof(unsigned), sym.stream));
           timer.begin(kProfChainUpdate);
           hipk::tailFactor<BT><<<dim3((unsigned)hipk::tailRoles(td.nP), gy.y), 256, 0, sym.stream>>>(
-              td, ref, tdinv, ctl, sym.asyncErrWord(), (long long)(sym.sweepSpinLimitS * 1e8));
+              td, ref, tdinv, ctl, sym.asyncErrWord(), (long long)(sym.sweepSpinLimitS * 1e8), sym.tailTrace());
           timer.end();
           sym.counters.tailLaunches++;
         }

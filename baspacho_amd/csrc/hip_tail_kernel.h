@@ -39,10 +39,12 @@ struct TailDesc {
   int32_t lda;      // row stride (lump width)
   int32_t K;        // order of the tail
   int32_t nP;       // ceil(K / 64)
-  int32_t ctlStride;  // control words per matrix: abort, ticket, nP diag flags, nP x nP X flags
+  int32_t ctlStride;  // control words per matrix: abort, ticket, nP diag flags, nP x nP X flags, yield word
+  int32_t flags;      // bit 0: tiles yield the CU of a spine that is in its panel Cholesky
+  int32_t pad;
 };
-inline int tailCtlWords(int nP) { return 2 + nP + nP * nP; }
-inline int tailRoles(int nP) { return 1 + nP * (nP - 1) / 2; }
+inline int tailCtlWords(int nP) { return 2 + nP + nP * nP + 1; }  // (+ the yield word)
+inline int tailRoles(int nP) { return 1 + (nP - 1) + nP * (nP - 1) / 2; }
 
 // control words are armed to all ones (one memset): a flag is raised by storing 0
 __device__ __forceinline__ void tailRaise(GP<unsigned> f) {
@@ -109,7 +111,7 @@ struct TailTile {
   // trsmStages (lane (q, n): row n of the wave's 16, columns 16 jj + 4 q + r), stored in place
   static __device__ __forceinline__ void solve(GP<T> A, GP<const T> dinv, int lda, int K, int ti, int j,
                                                int nb, const Acc (&D)[4], const Acc (&raw)[4], T* XB,
-                                               Acc (&x)[4]) {
+                                               Acc (&x)[4], bool store = true) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
     TrsmOps<T> o;
     trsmLoadOps<T>((GP<const T>)A + (int64_t)kTile * j * lda + kTile * j, dinv, lda, nb, lane, o);
@@ -130,13 +132,14 @@ struct TailTile {
     trsmMaskRows<T>(ri < K, nb, lane, x);
     trsmMaskOps<T>(nb, lane, o);
     trsmStages<T>(o, nb, x);
-    trsmStoreRows<T>(A + (int64_t)min(ri, K - 1) * lda + kTile * j, ri < K, nb, lane, x);
+    if (store) trsmStoreRows<T>(A + (int64_t)min(ri, K - 1) * lda + kTile * j, ri < K, nb, lane, x);
   }
 };
 
 template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void tailFactor(
-    TailDesc td, DataRef<T> dref, T* dinvBase, unsigned* ctlBase, unsigned* hostErr, long long spinLimit) {
+    TailDesc td, DataRef<T> dref, T* dinvBase, unsigned* ctlBase, unsigned* hostErr, long long spinLimit,
+    long long* trace) {
   __shared__ T XB[kTile * kXbLd];
   __shared__ int sTicket;
   static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd + 4 * kPanelWidth * 4 <= kTile * kXbLd, "potrf buffers fit in XB");
@@ -149,16 +152,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __syncthreads();
   int k = sTicket, i = 0, j = 0;
   bool spine = true;
-  if (k > 0) {  // column j: spine j + 1, then tiles (j + 2 .., j)
+  if (k > 0) {  // column j: spine j + 1, then tiles (j + 1 .., j)
     k -= 1;
     for (;;) {
-      const int cnt = nP - 1 - j;
+      const int cnt = nP - j;
       if (k < cnt) break;
       k -= cnt;
       j++;
     }
     spine = k == 0;
-    i = j + 1 + k;
+    i = spine ? j + 1 : j + k;
   }
   SweepWatch watch;
   watch.abortWord = ctl;
@@ -171,20 +174,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   GP<unsigned> xFlag = ctl + 2 + nP;  // [p * nP + i]: rows of tile row i of panel p are final
   auto nbOf = [&](int p) { return min(kTile, K - kTile * p); };
 
+  // (cooperative CU yield, hip_kernels.h: a tile that shares its CU with a spine pauses while the
+  //  spine's panel Cholesky runs -- fp64 MFMA and fp64 VALU share one pipe)
+  GP<unsigned> yieldWord = ctl + td.ctlStride - 1;
   if (!spine) {
-    // ---- tile (i, j), i >= j + 2
+    // ---- tile (i, j), i >= j + 1 (tile (j + 1, j) repeats what spine j + 1 solves for itself and
+    // is the one that STORES it: the spine's critical path has no store and no release in it)
+    const unsigned myCu = cuKey();
     Acc D[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, xi[4];
     T v[16];
     for (int p = 0; p < j; p++) {
       if (!tailWait(xFlag + p * nP + i, xFlag + p * nP + j, watch)) return;
       TT::fetch(A, lda, K, i, j, p, xi, v);
       TT::stageB(v, XB);
+      if ((td.flags & 1) && __hip_atomic_load(yieldWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == myCu) {
+        yieldWhile((const unsigned*)yieldWord, myCu);
+      }
       TT::multiply(xi, XB, false, D);
     }
     Acc raw[4], x[4];
     const int ri = kTile * i + 16 * w + n, nb = nbOf(j);
     trsmLoadRows<T>((GP<const T>)A + (int64_t)min(ri, K - 1) * lda + kTile * j, nb, lane, raw);
-    if (!tailWait(diagFlag + j, nullptr, watch)) return;
+    // (tile (j + 1, j): spine j + 1 has taken its copy of the unsolved tile before it is overwritten)
+    if (!tailWait(diagFlag + j, i == j + 1 ? xFlag + j * nP + j : nullptr, watch)) return;
     TT::solve(A, dinvAll + (size_t)j * kDinvSlot, lda, K, i, j, nb, D, raw, XB, x);
     __syncthreads();  // every wave's stores issued
     if (tid == 0) tailRaise(xFlag + j * nP + i);
@@ -192,9 +204,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 
   // ---- spine q: diagonal tile (q, q) and, for q >= 1, the tile left of it
+  __builtin_amdgcn_s_setprio(3);
   const int q = i;  // (spine 0: i = j = 0)
+  if (blockIdx.y) trace = nullptr;
+  if (trace && tid == 0) trace[4 * q] = (long long)wall_clock64();
   Acc Dd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  // the diagonal tile itself, in the accumulator layout of the panel Cholesky (identity beyond nb,
+  // zero above the diagonal: potrfTilesBlocked's own load, done here BEFORE the wait for the previous
+  // panel -- its loads inside the call are dead once `pre` overwrites the accumulators)
+  Acc own[4];
+  {
+    GP<const T> Aq = (GP<const T>)A + (int64_t)kTile * q * lda + kTile * q;
+    const int nbq = nbOf(q), li = lane & 15;
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * w + Mfma<T>::row(lane, r), col = 16 * tj + li;
+        const int rl = min(row, nbq - 1);
+        const T val = Aq[(int64_t)rl * lda + min(col, rl)];
+        own[tj][r] = (row < nbq && col <= row) ? val : ((row >= nbq && col == row) ? T(1) : T(0));
+      }
+    }
+  }
   if (q >= 1) {
+    // the unsolved tile (q, q-1) FIRST: tile role (q, q-1) overwrites it with X_q^{q-1} later, and waits
+    // for this spine's word that its copy is taken (the unused diagonal entry of the X flags)
+    Acc raw[4], x[4];
+    const int ri = kTile * q + 16 * w + n;
+    trsmLoadRows<T>((GP<const T>)A + (int64_t)min(ri, K - 1) * lda + kTile * (q - 1), kTile, lane, raw);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(xFlag + (q - 1) * nP + (q - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Acc Ds[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, xi[4];
     T v[16];
     for (int p = 0; p < q - 1; p++) {
@@ -207,11 +247,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       TT::stageB(v, XB);
       TT::multiply(xi, XB, true, Dd);
     }
-    Acc raw[4], x[4];
-    const int ri = kTile * q + 16 * w + n;
-    trsmLoadRows<T>((GP<const T>)A + (int64_t)min(ri, K - 1) * lda + kTile * (q - 1), kTile, lane, raw);
     if (!tailWait(diagFlag + q - 1, nullptr, watch)) return;
-    TT::solve(A, dinvAll + (size_t)(q - 1) * kDinvSlot, lda, K, q, q - 1, kTile, Ds, raw, XB, x);
+    if (trace && tid == 0) trace[4 * q + 2] = (long long)wall_clock64();  // diag(q-1) seen
+    TT::solve(A, dinvAll + (size_t)(q - 1) * kDinvSlot, lda, K, q, q - 1, kTile, Ds, raw, XB, x, /*store=*/false);
     // X_q^{q-1} against itself: the B operand is x in XB's row layout
     ldsBarrier();
     {
@@ -224,25 +262,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     ldsBarrier();
     TT::multiply(x, XB, true, Dd);
-    __syncthreads();  // the stores of X_q^{q-1} are issued by every wave; XB free for the potrf
-    if (tid == 0 && q + 1 < nP) tailRaise(xFlag + (q - 1) * nP + q);
+    ldsBarrier();  // XB free for the potrf
   }
   {
-    __builtin_amdgcn_s_setprio(3);
+    if (trace && tid == 0) trace[4 * q + 1] = (long long)wall_clock64();  // the panel Cholesky begins
+    yieldPublish((unsigned*)yieldWord, cuKey());
     T(*blk)[4] = reinterpret_cast<T(*)[4]>(XB);
     T(*sol)[4] = blk + 3 * kPanelWidth;
     T* Ld = XB + 4 * kPanelWidth * 4;
     auto pre = [&](Acc* acc) {
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        if (t <= w) acc[t] -= Dd[t];
-      }
+      for (int t = 0; t < 4; t++) acc[t] = t <= w ? own[t] - Dd[t] : own[t];
     };
     potrfPanelTiles<T>(A + (int64_t)kTile * q * lda + kTile * q, nbOf(q), lda, blk, sol,
                        XB + 4 * kPanelWidth * 4 + kPanelWidth * kInvLd, pre, Ld,
                        dinvAll + (size_t)q * kDinvSlot);
+    yieldPublish((unsigned*)yieldWord, 0u);
     __syncthreads();
     if (tid == 0 && q + 1 < nP) tailRaise(diagFlag + q);
+    if (trace && tid == 0) trace[4 * q + 3] = (long long)wall_clock64();  // diag(q) raised
   }
 }
 
