@@ -746,8 +746,8 @@ struct HipSymbolicCtx : SymbolicCtx {
   long long* tailTrace() {  // developer aid (BSP_SWEEP_TRACE=1): the spines' clock stamps
     if (!sweepTraceOn) return nullptr;
     if (!sweepTrace.ptr) {
-      sweepTrace.resize(4 * 4096 * sizeof(long long));
-      hipCHECK(hipMemset(sweepTrace.ptr, 0, 4 * 4096 * sizeof(long long)));
+      sweepTrace.resize(8 * 4096 * sizeof(long long));
+      hipCHECK(hipMemset(sweepTrace.ptr, 0, 8 * 4096 * sizeof(long long)));
     }
     return reinterpret_cast<long long*>(sweepTrace.ptr);
   }
@@ -940,15 +940,23 @@ struct HipNumericCtx : NumericCtx<T> {
           td.flags = sym.tailFlags;
           td.pad = 0;
           BASPACHO_CHECK_EQ(td.nP, lr.tailPanels);
-          const size_t ctlBytes = (size_t)td.ctlStride * scratchBatch * sizeof(unsigned);
-          sym.tailCtl.resize(ctlBytes);
+          // control words and exchange slots of every matrix in one buffer, armed by one memset
+          const size_t ctlBytes = ((size_t)td.ctlStride * scratchBatch * sizeof(unsigned) + 255) / 256 * 256;
+          const size_t xchPerMat = (size_t)td.nP * kTile * kTile * sizeof(BT);
+          sym.tailCtl.resize(ctlBytes + xchPerMat * scratchBatch);
           sym.tailDinv.resize((size_t)scratchBatch * td.nP * hipk::kDinvSlot * sizeof(BT));
           unsigned* ctl = reinterpret_cast<unsigned*>(sym.tailCtl.ptr) + (size_t)subBatchBase * td.ctlStride;
+          BT* xch = reinterpret_cast<BT*>(reinterpret_cast<char*>(sym.tailCtl.ptr) + ctlBytes + xchPerMat * subBatchBase);
           BT* tdinv = const_cast<BT*>(sym.tailDinv.as<BT>()) + (size_t)subBatchBase * td.nP * hipk::kDinvSlot;
-          hipCHECK(hipMemsetAsync(ctl, 0xff, (size_t)td.ctlStride * batchSize * sizeof(unsigned), sym.stream));
+          if (subBatchTotal > 0) {  // (a sub-batch arms its own slices only)
+            hipCHECK(hipMemsetAsync(ctl, 0xff, (size_t)td.ctlStride * batchSize * sizeof(unsigned), sym.stream));
+            hipCHECK(hipMemsetAsync(xch, 0xff, xchPerMat * batchSize, sym.stream));
+          } else {
+            hipCHECK(hipMemsetAsync(sym.tailCtl.ptr, 0xff, ctlBytes + xchPerMat * scratchBatch, sym.stream));
+          }
           timer.begin(kProfChainUpdate);
           hipk::tailFactor<BT><<<dim3((unsigned)hipk::tailRoles(td.nP), gy.y), 256, 0, sym.stream>>>(
-              td, ref, tdinv, ctl, sym.asyncErrWord(), (long long)(sym.sweepSpinLimitS * 1e8), sym.tailTrace());
+              td, ref, tdinv, ctl, xch, sym.asyncErrWord(), (long long)(sym.sweepSpinLimitS * 1e8), sym.tailTrace());
           timer.end();
           sym.counters.tailLaunches++;
         }
@@ -1773,7 +1781,7 @@ struct HipSolveCtx : SolveCtx<T> {
         sh.pad = 0;
         sh.trace = nullptr;
         if (sym.sweepTraceOn) {
-          sym.sweepTrace.resize(4 * 4096 * sizeof(long long));
+          sym.sweepTrace.resize(8 * 4096 * sizeof(long long));
           sh.trace = reinterpret_cast<long long*>(sym.sweepTrace.ptr);
         }
       }

@@ -682,8 +682,13 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                          plan.panels[buckets[bi + 1][0].panel].pad == 0;
       if (bucket.size() == 1 && plan.panels[bucket[0].panel].pad == 1) {
         const bool first = out.empty() || out.back().tail == 0;
-        lr.panelEnd = lr.panelBegin;
-        lr.trsmEnd = lr.trsmBegin;
+        // (the panel and its row tiles stay listed: the solves walk a tail level like any other
+        //  one-panel level; factor() skips it)
+        const PanelDesc& tp = plan.panels[bucket[0].panel];
+        plan.levelPanels.push_back(bucket[0].panel);
+        for (int32_t r = 0; r < tp.rowsBelow; r += kTile) plan.trsmTasks.push_back({bucket[0].panel, r});
+        lr.panelEnd = (int64_t)plan.levelPanels.size();
+        lr.trsmEnd = (int64_t)plan.trsmTasks.size();
         lr.updEnd = lr.defBegin = lr.defMid = lr.defEnd = lr.updBegin;
         lr.directPanel = bucket[0].panel;
         lr.tail = first ? 1 : 2;

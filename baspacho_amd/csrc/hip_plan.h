@@ -244,7 +244,7 @@ struct HipPlanOptions {
   // PERSISTENT TAIL (hip_tail_kernel.h): the last tailBlocks outer blocks of a lump that has nothing
   // below it and is at least tailMinBlocks blocks wide are factored by ONE flag-synchronised launch
   // (BSP_TAIL_BLOCKS; 0: the level schedule to the end)
-  int32_t tailBlocks = 0;
+  int32_t tailBlocks = 6;
   int32_t tailMinBlocks = 6;
   static HipPlanOptions fromEnv();
 };

@@ -18,6 +18,12 @@
 //        when diag(q-1) arrives it solves X_q^{q-1} itself, applies it to its diagonal tile, runs the
 //        blocked panel Cholesky (potrfPanelTiles, with the pending update folded into its load) and
 //        raises diag(q).  Its X_q^{q-1} is stored and flagged for the tiles of column q.
+// Round-6 refinement (second trace): the spine also owns the tile TWO left of its diagonal, (q, q-2), and
+// receives X_{q-1}^{q-2} from spine q-1 through an exchange slot of self-validating words (published with
+// plain write-through stores the moment it is solved, polled as data: no store-release-flag on anybody's
+// critical path).  The serial chain then runs from spine to spine only -- one flag hop per panel -- and
+// every other tile has two full steps to deliver; tiles (q, q-1) and (q, q-2) exist as roles too: they
+// repeat the solve and STORE the result in place for everybody else.
 // Roles are dealt by ticket in an order in which a role only waits for smaller tickets (spine 0; then
 // per column j: spine j+1, tiles (j+2.., j)), so the launch cannot deadlock whether or not all of it
 // is resident; a role that starts late replays the finished panels at L2 speed.  Flags: release
@@ -39,11 +45,11 @@ struct TailDesc {
   int32_t lda;      // row stride (lump width)
   int32_t K;        // order of the tail
   int32_t nP;       // ceil(K / 64)
-  int32_t ctlStride;  // control words per matrix: abort, ticket, nP diag flags, nP x nP X flags, yield word
+  int32_t ctlStride;  // control words per matrix: abort, ticket, nP diag flags, nP x nP X flags, nP copy-taken, yield
   int32_t flags;      // bit 0: tiles yield the CU of a spine that is in its panel Cholesky
   int32_t pad;
 };
-inline int tailCtlWords(int nP) { return 2 + nP + nP * nP + 1; }  // (+ the yield word)
+inline int tailCtlWords(int nP) { return 2 + nP + nP * nP + nP + 1; }  // (+ copy-taken words, yield word)
 inline int tailRoles(int nP) { return 1 + (nP - 1) + nP * (nP - 1) / 2; }
 
 // control words are armed to all ones (one memset): a flag is raised by storing 0
@@ -52,16 +58,18 @@ __device__ __forceinline__ void tailRaise(GP<unsigned> f) {
   __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // every wave waits for itself (no workgroup barrier inside a wait); false = abort
-__device__ __forceinline__ bool tailWait(GP<const unsigned> f0, GP<const unsigned> f1, SweepWatch& watch) {
+__device__ __forceinline__ bool tailWait(GP<const unsigned> f0, GP<const unsigned> f1, SweepWatch& watch,
+                                         GP<const unsigned> f2 = nullptr, bool acquire = true) {
   watch.reset();
   for (;;) {
     const unsigned a = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned b = f1 ? __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    if (a == 0u && b == 0u) break;
+    const unsigned c = f2 ? __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (a == 0u && b == 0u && c == 0u) break;
     if (watch.expired()) return false;
     __builtin_amdgcn_s_sleep(2);
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return true;
 }
 
@@ -70,12 +78,20 @@ struct TailTile {
   using Acc = typename Mfma<T>::Acc;
   // D[t] += X_i (X_j rows 16 t .. 16 t + 15)^T for source panel p: X_i = rows of tile row `ti`, X_j =
   // rows of tile row `tj`, both columns 64 p .. 64 p + 63 of the tail (final entries of L, in place)
-  static __device__ __forceinline__ void fetch(GP<const T> A, int lda, int K, int ti, int tj, int p,
-                                               Acc (&xi)[4], T (&v)[16]) {
+  // (Exchanging the solved rows through agent-scope relaxed loads and stores instead of plain accesses
+  //  between release / acquire fences was tried -- an acquire fence invalidates the whole L2 of its XCD,
+  //  and with the tiles' fences switched off for a timing experiment 12 blocks took 920 instead of
+  //  1180-1260 us.  It is WRONG on this memory system: a coherent load can return a line that a plain
+  //  load of the unsolved tile left in the L2 (vector probe 4e-7), and it was slower besides, every
+  //  operand coming from the far side of the fabric: 1600 us.)
+  static __device__ __forceinline__ void fetchA(GP<const T> A, int lda, int K, int ti, int p, Acc (&xi)[4]) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15;
     const int ri = kTile * ti + 16 * w + n;
     trsmLoadRows<T>(A + (int64_t)min(ri, K - 1) * lda + kTile * p, kTile, lane, xi);
     trsmMaskRows<T>(ri < K, kTile, lane, xi);
+  }
+  static __device__ __forceinline__ void fetchB(GP<const T> A, int lda, int K, int tj, int p, T (&v)[16]) {
+    const int tid = threadIdx.x;
     const int rj = kTile * tj + (tid >> 2);
     GP<const T> rowJ = A + (int64_t)min(rj, K - 1) * lda + kTile * p + 16 * (tid & 3);
 #pragma unroll
@@ -83,6 +99,36 @@ struct TailTile {
       const T a = rowJ[c];
       v[c] = rj < K ? a : T(0);
     }
+  }
+  static __device__ __forceinline__ void fetch(GP<const T> A, int lda, int K, int ti, int tj, int p,
+                                               Acc (&xi)[4], T (&v)[16]) {
+    fetchA(A, lda, K, ti, p, xi);
+    fetchB(A, lda, K, tj, p, v);
+  }
+  // D = -(tile (ti, tj)) in accumulator layout: with the products added on top, the solve's
+  // right-hand side is -D and no copy of the unsolved tile has to stay in registers
+  static __device__ __forceinline__ void loadNeg(GP<const T> A, int lda, int K, int ti, int tj, Acc (&D)[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int row = kTile * ti + 16 * w + Mfma<T>::row(lane, reg);
+        const T a = A[(int64_t)min(row, K - 1) * lda + kTile * tj + 16 * t + n];
+        D[t][reg] = row < K ? -a : T(0);
+      }
+    }
+  }
+  // x (row layout of trsmStages) -> XB as the B operand of a product against itself / another tile
+  static __device__ __forceinline__ void stageX(const Acc (&x)[4], T* XB) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, qq = lane >> 4;
+    ldsBarrier();
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) XB[(16 * w + n) * kXbLd + 16 * jj + 4 * qq + r] = x[jj][r];
+    }
+    ldsBarrier();
   }
   static __device__ __forceinline__ void stageB(const T (&v)[16], T* XB) {
     const int tid = threadIdx.x;
@@ -110,7 +156,7 @@ struct TailTile {
   // x = (A_ij - D) L_jj^-T for the rows of tile row ti against panel j (nb columns): in the layout of
   // trsmStages (lane (q, n): row n of the wave's 16, columns 16 jj + 4 q + r), stored in place
   static __device__ __forceinline__ void solve(GP<T> A, GP<const T> dinv, int lda, int K, int ti, int j,
-                                               int nb, const Acc (&D)[4], const Acc (&raw)[4], T* XB,
+                                               int nb, const Acc (&D)[4], const Acc* raw, T* XB,
                                                Acc (&x)[4], bool store = true) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
     TrsmOps<T> o;
@@ -126,7 +172,9 @@ struct TailTile {
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) x[jj][r] = raw[jj][r] - XB[(16 * w + n) * kXbLd + 16 * jj + 4 * q + r];
+      for (int r = 0; r < 4; r++) {
+        x[jj][r] = (raw ? raw[jj][r] : T(0)) - XB[(16 * w + n) * kXbLd + 16 * jj + 4 * q + r];
+      }
     }
     const int ri = kTile * ti + 16 * w + n;
     trsmMaskRows<T>(ri < K, nb, lane, x);
@@ -138,8 +186,8 @@ struct TailTile {
 
 template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void tailFactor(
-    TailDesc td, DataRef<T> dref, T* dinvBase, unsigned* ctlBase, unsigned* hostErr, long long spinLimit,
-    long long* trace) {
+    TailDesc td, DataRef<T> dref, T* dinvBase, unsigned* ctlBase, T* xchBase, unsigned* hostErr,
+    long long spinLimit, long long* trace) {
   __shared__ T XB[kTile * kXbLd];
   __shared__ int sTicket;
   static_assert(4 * kPanelWidth * 4 + kPanelWidth * kInvLd + 4 * kPanelWidth * 4 <= kTile * kXbLd, "potrf buffers fit in XB");
@@ -172,6 +220,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   GP<T> dinvAll = (GP<T>)dinvBase + (size_t)blockIdx.y * nP * kDinvSlot;
   GP<unsigned> diagFlag = ctl + 2;
   GP<unsigned> xFlag = ctl + 2 + nP;  // [p * nP + i]: rows of tile row i of panel p are final
+  GP<unsigned> taken2 = ctl + 2 + nP + nP * nP;  // [q]: spine q has its copy of the unsolved tile (q, q-2)
+  GP<T> xch = (GP<T>)xchBase + (size_t)blockIdx.y * nP * kTile * kTile;  // slot q: X_q^{q-1}, per-lane order
   auto nbOf = [&](int p) { return min(kTile, K - kTile * p); };
 
   // (cooperative CU yield, hip_kernels.h: a tile that shares its CU with a spine pauses while the
@@ -195,8 +245,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     Acc raw[4], x[4];
     const int ri = kTile * i + 16 * w + n, nb = nbOf(j);
     trsmLoadRows<T>((GP<const T>)A + (int64_t)min(ri, K - 1) * lda + kTile * j, nb, lane, raw);
-    // (tile (j + 1, j): spine j + 1 has taken its copy of the unsolved tile before it is overwritten)
-    if (!tailWait(diagFlag + j, i == j + 1 ? xFlag + j * nP + j : nullptr, watch)) return;
+    // (tiles (j + 1, j) and (j + 2, j): the spine of their row has taken its copy of the unsolved tile
+    //  before it is overwritten)
+    if (!tailWait(diagFlag + j, i == j + 1 ? xFlag + j * nP + j : (i == j + 2 ? taken2 + i : nullptr), watch)) return;
     TT::solve(A, dinvAll + (size_t)j * kDinvSlot, lda, K, i, j, nb, D, raw, XB, x);
     __syncthreads();  // every wave's stores issued
     if (tid == 0) tailRaise(xFlag + j * nP + i);
@@ -207,8 +258,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __builtin_amdgcn_s_setprio(3);
   const int q = i;  // (spine 0: i = j = 0)
   if (blockIdx.y) trace = nullptr;
-  if (trace && tid == 0) trace[4 * q] = (long long)wall_clock64();
+  if (trace && tid == 0) trace[8 * q] = (long long)wall_clock64();
   Acc Dd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  Acc Ds[4], D3[4], x[4];
+  if (q >= 1) {
+    // the unsolved tiles (q, q-1) and (q, q-2) FIRST: their tile roles overwrite them with the solved
+    // rows later, and wait for this spine's word that its copies are taken
+    TT::loadNeg(A, lda, K, q, q - 1, Ds);
+    if (q >= 2) TT::loadNeg(A, lda, K, q, q - 2, D3);
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(xFlag + (q - 1) * nP + (q - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (q >= 2) __hip_atomic_store(taken2 + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    Acc xi[4];
+    T v[16];
+    for (int p = 0; p + 2 < q; p++) {
+      if (!tailWait(xFlag + p * nP + q, xFlag + p * nP + q - 1, watch, xFlag + p * nP + q - 2)) return;
+      TT::fetch(A, lda, K, q, q - 2, p, xi, v);
+      TT::stageB(v, XB);
+      TT::multiply(xi, XB, false, D3);
+      TT::fetchB(A, lda, K, q - 1, p, v);
+      TT::stageB(v, XB);
+      TT::multiply(xi, XB, false, Ds);
+      TT::fetchB(A, lda, K, q, p, v);
+      TT::stageB(v, XB);
+      TT::multiply(xi, XB, true, Dd);
+    }
+    if (q >= 2) {
+      // panel q-2: its own copy of X_q^{q-2}; X_{q-1}^{q-2} from spine q-1's exchange slot
+      if (!tailWait(diagFlag + q - 2, nullptr, watch)) return;
+      TT::solve(A, dinvAll + (size_t)(q - 2) * kDinvSlot, lda, K, q, q - 2, kTile, D3, nullptr, XB, x, /*store=*/false);
+      {
+        GP<const T> slot = xch + (size_t)(q - 1) * kTile * kTile + tid;  // (value e of thread t at [e][t]: coalesced)
+        GP<const T> pp[16];
+        bool need[16];
+        T got[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          pp[e] = slot + 256 * e;
+          need[e] = true;
+          got[e] = T(0);
+        }
+        if (!sweepWait<T, 16>(pp, need, got, watch)) return;
+        const int qq = lane >> 4;
+        ldsBarrier();
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) XB[(16 * w + n) * kXbLd + 16 * jj + 4 * qq + r] = got[4 * jj + r];
+        }
+        ldsBarrier();
+      }
+      TT::multiply(x, XB, false, Ds);
+      TT::stageX(x, XB);
+      TT::multiply(x, XB, true, Dd);
+    }
+  }
   // the diagonal tile itself, in the accumulator layout of the panel Cholesky (identity beyond nb,
   // zero above the diagonal: potrfTilesBlocked's own load, done here BEFORE the wait for the previous
   // panel -- its loads inside the call are dead once `pre` overwrites the accumulators)
@@ -228,44 +334,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   if (q >= 1) {
-    // the unsolved tile (q, q-1) FIRST: tile role (q, q-1) overwrites it with X_q^{q-1} later, and waits
-    // for this spine's word that its copy is taken (the unused diagonal entry of the X flags)
-    Acc raw[4], x[4];
-    const int ri = kTile * q + 16 * w + n;
-    trsmLoadRows<T>((GP<const T>)A + (int64_t)min(ri, K - 1) * lda + kTile * (q - 1), kTile, lane, raw);
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(xFlag + (q - 1) * nP + (q - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    Acc Ds[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, xi[4];
-    T v[16];
-    for (int p = 0; p < q - 1; p++) {
-      if (!tailWait(xFlag + p * nP + q, xFlag + p * nP + q - 1, watch)) return;
-      TT::fetch(A, lda, K, q, q - 1, p, xi, v);
-      TT::stageB(v, XB);
-      TT::multiply(xi, XB, false, Ds);
-      // the diagonal tile: X_q against itself
-      TT::fetch(A, lda, K, q, q, p, xi, v);
-      TT::stageB(v, XB);
-      TT::multiply(xi, XB, true, Dd);
-    }
     if (!tailWait(diagFlag + q - 1, nullptr, watch)) return;
-    if (trace && tid == 0) trace[4 * q + 2] = (long long)wall_clock64();  // diag(q-1) seen
-    TT::solve(A, dinvAll + (size_t)(q - 1) * kDinvSlot, lda, K, q, q - 1, kTile, Ds, raw, XB, x, /*store=*/false);
-    // X_q^{q-1} against itself: the B operand is x in XB's row layout
-    ldsBarrier();
-    {
-      const int qq = lane >> 4;
+    if (trace && tid == 0) trace[8 * q + 2] = (long long)wall_clock64();  // diag(q-1) seen
+    TT::solve(A, dinvAll + (size_t)(q - 1) * kDinvSlot, lda, K, q, q - 1, kTile, Ds, nullptr, XB, x, /*store=*/false);
+    if (trace && tid == 0) trace[8 * q + 4] = (long long)wall_clock64();  // solved
+    if (q + 1 < nP) {  // for spine q+1: plain write-through stores of self-validating words
+      GP<T> slot = xch + (size_t)q * kTile * kTile + tid;
 #pragma unroll
       for (int jj = 0; jj < 4; jj++) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) XB[(16 * w + n) * kXbLd + 16 * jj + 4 * qq + r] = x[jj][r];
+        for (int r = 0; r < 4; r++) sweepPublish<T>(slot + 256 * (4 * jj + r), x[jj][r]);
       }
     }
-    ldsBarrier();
+    if (trace && tid == 0) trace[8 * q + 5] = (long long)wall_clock64();  // published
+    TT::stageX(x, XB);
     TT::multiply(x, XB, true, Dd);
     ldsBarrier();  // XB free for the potrf
   }
   {
-    if (trace && tid == 0) trace[4 * q + 1] = (long long)wall_clock64();  // the panel Cholesky begins
+    if (trace && tid == 0) trace[8 * q + 1] = (long long)wall_clock64();  // the panel Cholesky begins
     yieldPublish((unsigned*)yieldWord, cuKey());
     T(*blk)[4] = reinterpret_cast<T(*)[4]>(XB);
     T(*sol)[4] = blk + 3 * kPanelWidth;
@@ -280,7 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     yieldPublish((unsigned*)yieldWord, 0u);
     __syncthreads();
     if (tid == 0 && q + 1 < nP) tailRaise(diagFlag + q);
-    if (trace && tid == 0) trace[4 * q + 3] = (long long)wall_clock64();  // diag(q) raised
+    if (trace && tid == 0) trace[8 * q + 3] = (long long)wall_clock64();  // diag(q) raised
   }
 }
 

@@ -49,6 +49,27 @@ def test_tail_of_one_wide_lump(monkeypatch, dtype, blocks):
         assert serr < (1e-10 if dtype == np.float64 else 1e-3), (W, blocks, serr)
 
 
+def test_tail_panels_in_the_multi_launch_solves(monkeypatch):
+    """with the persistent sweeps off, the solves walk the tail's panels through the block and level
+    kernels (a last outer block of ONE panel is a plain level: found by the 65 600-wide lump)"""
+    monkeypatch.setenv("BSP_TAIL_BLOCKS", "6")
+    monkeypatch.setenv("BSP_SOLVE_SWEEP", "0")
+    for W in (1536 + 64, 1536 + 40, 2048 + 1):
+        sol = _dense_solver(W)
+        data = spd_data(sol, 3 + W)
+        _, A = dense_lower_chol(sol, data)
+        dev = to_dev(data)
+        sol.factor(dev)
+        assert sol.runCounters()["tail_launches"] == 1
+        n = sol.order()
+        rhs = np.random.default_rng(W).standard_normal((2, n))
+        v = to_dev(rhs.reshape(-1).copy())
+        sol.solve(dev, v, n, 2)
+        X = np.linalg.solve(A, rhs.T)
+        err = np.linalg.norm(v.cpu().numpy().reshape(2, n).T - X) / np.linalg.norm(X)
+        assert err < 1e-10, (W, err)
+
+
 def test_tail_batched(monkeypatch):
     monkeypatch.setenv("BSP_TAIL_BLOCKS", "3")
     sol = _dense_solver(1700)

@@ -27,7 +27,7 @@ torch.cuda.synchronize()
 buf = (ctypes.c_longlong * (4 * 4096))()
 nb = ctypes.c_int32(0)
 assert sol._lib.bsp_test_read_sweep_trace(sol._h, buf, 4096, ctypes.byref(nb)) == 0
-t = np.array(buf[:4 * nb.value], dtype=np.int64).reshape(-1, 4)
+t = np.array(buf[:4 * nb.value], dtype=np.int64).reshape(-1, 8)
 n = int((t[:, 3] > 0).sum())
 t = t[:n]
 t0 = t[0, 0]
@@ -41,7 +41,7 @@ for q in range(n):
     if q:
         steps.append((step, r[2] - us[q - 1][3], r[1] - r[2], r[3] - r[1]))
     if q < 6 or q >= n - 3 or q % 6 == 0:
-        print("  %3d %7.1f %8.1f %8.1f %7.1f | %6.2f %8.2f %10.2f %12.2f" % (q, r[0], r[1], r[2], r[3], step, (r[2] - us[q - 1][3]) if q else float("nan"), r[1] - r[2], r[3] - r[1]))
+        print("  %3d %7.1f %8.1f %8.1f %7.1f | %6.2f %8.2f %10.2f %12.2f | solve %.2f publish %.2f product %.2f" % (q, r[0], r[1], r[2], r[3], step, (r[2] - us[q - 1][3]) if q else float("nan"), r[1] - r[2], r[3] - r[1], r[4] - r[2], r[5] - r[4], r[1] - r[5]))
 if steps:
     s = np.array(steps)
     print("  median step %.2f us = flag hop %.2f + solve and update %.2f + panel Cholesky and publish %.2f" % tuple(np.median(s, axis=0)))
