@@ -40,6 +40,17 @@ class _CSettings(ctypes.Structure):
                 ("computation_model", ctypes.POINTER(ctypes.c_double))]
 
 
+_HIP_OPTION_INTS = ["lookahead", "due_stream", "split_k", "gather_max_pairs", "gather_overlap",
+                    "sub_batch_min", "sub_batches", "tail_blocks", "lazy_plan", "block_solve", "solve_inv",
+                    "solve_sweep", "sweep_min_width", "chain_contraction", "dense_merge", "expected_batch"]
+_HIP_OPTION_REALS = ["lookahead_min_gf", "bulk_ahead"]
+
+
+class _CHipOptions(ctypes.Structure):
+    """bsp_hip_options (include/baspacho_amd.h): negative / NaN = the library's default"""
+    _fields_ = [(n, ctypes.c_int32) for n in _HIP_OPTION_INTS] + [(n, ctypes.c_double) for n in _HIP_OPTION_REALS]
+
+
 class _CPlanStats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in
                 ["flops", "upd_elems", "upd_flops", "elim_pair_elems", "elim_pair_flops",
@@ -50,7 +61,8 @@ class _CPlanStats(ctypes.Structure):
                 ["num_launches", "num_levels", "num_panels", "num_segs", "num_upd_tasks",
                  "num_trsm_tasks", "chain_tab_entries", "max_panels_in_level",
                  "num_atomic_upd_tasks", "num_gather_groups", "num_fork_levels"]] + \
-               [("deferred_flops", ctypes.c_double)]
+               [("deferred_flops", ctypes.c_double), ("tail_upd_flops", ctypes.c_double),
+                ("num_tail_panels", ctypes.c_int64)]
 
 
 class _CRunCounters(ctypes.Structure):
@@ -68,6 +80,9 @@ class Settings:
     backend: int = BackendHip
     addFillPolicy: int = AddFillComplete
     computationModel: Optional[Sequence[float]] = None  # 20 coefficients, see C header
+    # extension: schedule switches of the MI355X backend, {field of bsp_hip_options: value}; fields left
+    # out keep the library's default (the BSP_* environment variables override both, for A/B scripts)
+    hipOptions: Optional[dict] = None
 
 
 @dataclass
@@ -588,8 +603,21 @@ def create_solver(settings: Optional[Settings], param_sizes, ss: SparseStructure
         raise ValueError("param_sizes and sparse structure disagree on the number of params")
     er, el = _i64(sparse_elim_ranges), _i64(sorted(elim_last_ids))
     h = ctypes.c_void_p()
-    _check(lib.bsp_create_solver(
-        ctypes.byref(cs), ctypes.c_int64(len(ps)), ps.ctypes.data_as(_I64P),
+    ho = None
+    if st.hipOptions:
+        ho = _CHipOptions()
+        lib.bsp_hip_options_default(ctypes.byref(ho))
+        for k, v in st.hipOptions.items():
+            if k in _HIP_OPTION_INTS:
+                setattr(ho, k, int(v))
+            elif k in _HIP_OPTION_REALS:
+                setattr(ho, k, float(v))
+            else:
+                raise ValueError("unknown backend option %r (bsp_hip_options has: %s)" %
+                                 (k, ", ".join(_HIP_OPTION_INTS + _HIP_OPTION_REALS)))
+    _check(lib.bsp_create_solver_opts(
+        ctypes.byref(cs), ctypes.byref(ho) if ho is not None else None,
+        ctypes.c_int64(len(ps)), ps.ctypes.data_as(_I64P),
         ss.ptrs.ctypes.data_as(_I64P), ss.inds.ctypes.data_as(_I64P), ctypes.c_int64(len(er)),
         er.ctypes.data_as(_I64P), ctypes.c_int64(len(el)), el.ctypes.data_as(_I64P),
         ctypes.byref(h)))

@@ -1,4 +1,7 @@
 #include "bsp_utils.h"
+#include "backend_options.h"
+#include <cstdlib>
+#include <algorithm>
 
 #include <chrono>
 #include <cmath>
@@ -68,6 +71,37 @@ std::string OpStat::toString() const {
   os << "#=" << numRuns << ", time=" << secondsToString(totTime)
      << ", last=" << secondsToString(lastTime) << ", max=" << secondsToString(maxTime);
   return os.str();
+}
+
+// the ONLY place the schedule switches are read from the environment (backend_options.h)
+void HipBackendOptions::applyEnv() {
+  auto flag = [](const char* name, int32_t& dst, bool invert = false) {
+    if (const char* e = std::getenv(name)) dst = ((e[0] != '0') != invert) ? 1 : 0;
+  };
+  auto num = [](const char* name, int32_t& dst, long lo) {
+    if (const char* e = std::getenv(name)) dst = (int32_t)std::max<long>(lo, std::strtol(e, nullptr, 0));
+  };
+  auto real = [](const char* name, double& dst) {
+    if (const char* e = std::getenv(name)) dst = std::atof(e);
+  };
+  flag("BSP_NO_LOOKAHEAD", lookahead, /*invert=*/true);
+  flag("BSP_DUE_STREAM", dueStream);
+  flag("BSP_SPLIT_K", splitK);
+  num("BSP_GATHER_MAX_PAIRS", gatherMaxPairs, 8);
+  flag("BSP_GATHER_OVERLAP", gatherOverlap);
+  num("BSP_SUB_BATCH_MIN", subBatchMin, 0);
+  num("BSP_SUB_BATCHES", subBatches, 2);
+  num("BSP_TAIL_BLOCKS", tailBlocks, 0);
+  if (std::getenv("BSP_LAZY_PLAN")) lazyPlan = 1;
+  flag("BSP_BLOCK_SOLVE", blockSolve);
+  flag("BSP_SOLVE_INV", solveInv);
+  flag("BSP_SOLVE_SWEEP", solveSweep);
+  num("BSP_SWEEP_MIN_WIDTH", sweepMinWidth, 1);
+  flag("BSP_CHAIN_CONTRACTION", chainContraction);
+  if (std::getenv("BSP_DENSE_MERGE_OFF")) denseMerge = 0;
+  num("BSP_EXPECTED_BATCH", expectedBatch, 1);
+  real("BSP_LOOKAHEAD_MIN_GF", lookaheadMinGF);
+  real("BSP_BULK_AHEAD", bulkAhead);
 }
 
 }  // namespace BaSpaCho

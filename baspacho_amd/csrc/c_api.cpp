@@ -2,6 +2,7 @@
 // boundary: they become a non-zero return code + bsp_last_error().
 #include "../../include/baspacho_amd.h"
 
+#include <cmath>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -41,14 +42,43 @@ const char* bsp_version(void) { return "baspacho_amd 0.1 (gfx950)"; }
   }                                    \
   return 0;
 
-int bsp_create_solver(const bsp_settings* st, int64_t numParams, const int64_t* paramSizes,
-                      const int64_t* ptrs, const int64_t* inds, int64_t numElimRanges,
-                      const int64_t* elimRanges, int64_t numElimLast, const int64_t* elimLast,
-                      bsp_solver** out) {
+void bsp_hip_options_default(bsp_hip_options* o) {
+  o->lookahead = o->due_stream = o->split_k = o->gather_max_pairs = o->gather_overlap = o->sub_batch_min =
+      o->sub_batches = o->tail_blocks = o->lazy_plan = o->block_solve = o->solve_inv = o->solve_sweep =
+          o->sweep_min_width = o->chain_contraction = o->dense_merge = o->expected_batch = -1;
+  o->lookahead_min_gf = o->bulk_ahead = NAN;
+}
+
+int bsp_create_solver_opts(const bsp_settings* st, const bsp_hip_options* ho, int64_t numParams,
+                           const int64_t* paramSizes, const int64_t* ptrs, const int64_t* inds,
+                           int64_t numElimRanges, const int64_t* elimRanges, int64_t numElimLast,
+                           const int64_t* elimLast, bsp_solver** out) {
   BSP_TRY
   BASPACHO_CHECK_NOTNULL(out);
   std::unique_ptr<bsp_solver> h(new bsp_solver);
   Settings settings;
+  HipBackendOptions options;
+  if (ho) {
+    options.lookahead = ho->lookahead;
+    options.dueStream = ho->due_stream;
+    options.splitK = ho->split_k;
+    options.gatherMaxPairs = ho->gather_max_pairs;
+    options.gatherOverlap = ho->gather_overlap;
+    options.subBatchMin = ho->sub_batch_min;
+    options.subBatches = ho->sub_batches;
+    options.tailBlocks = ho->tail_blocks;
+    options.lazyPlan = ho->lazy_plan;
+    options.blockSolve = ho->block_solve;
+    options.solveInv = ho->solve_inv;
+    options.solveSweep = ho->solve_sweep;
+    options.sweepMinWidth = ho->sweep_min_width;
+    options.chainContraction = ho->chain_contraction;
+    options.denseMerge = ho->dense_merge;
+    options.expectedBatch = ho->expected_batch;
+    options.lookaheadMinGF = ho->lookahead_min_gf;
+    options.bulkAhead = ho->bulk_ahead;
+    settings.hipOptions = &options;
+  }
   if (st) {
     settings.findSparseEliminationRanges = st->find_sparse_elimination_ranges != 0;
     settings.numThreads = st->num_threads;
@@ -71,6 +101,14 @@ int bsp_create_solver(const bsp_settings* st, int64_t numParams, const int64_t* 
   h->solver = createSolver(settings, sizes, ss, ranges, last);
   *out = h.release();
   BSP_CATCH
+}
+
+int bsp_create_solver(const bsp_settings* st, int64_t numParams, const int64_t* paramSizes,
+                      const int64_t* ptrs, const int64_t* inds, int64_t numElimRanges,
+                      const int64_t* elimRanges, int64_t numElimLast, const int64_t* elimLast,
+                      bsp_solver** out) {
+  return bsp_create_solver_opts(st, nullptr, numParams, paramSizes, ptrs, inds, numElimRanges, elimRanges,
+                                numElimLast, elimLast, out);
 }
 
 int bsp_create_solver_from_skeleton(int64_t numSpans, const int64_t* spanStart, int64_t numLumps,
@@ -597,6 +635,8 @@ int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out) {
   out->num_gather_groups = p.numGatherGroups;
   out->num_fork_levels = p.numForkLevels;
   out->deferred_flops = p.deferredFlops;
+  out->tail_upd_flops = p.tailUpdFlops;
+  out->num_tail_panels = p.numTailPanels;
   BSP_CATCH
 }
 

@@ -164,7 +164,7 @@ void EliminationTree::computeMerges() {
   }
 
   vector<NodeStats> mergedStats;
-  const bool denseMergeOn = std::getenv("BSP_DENSE_MERGE_OFF") == nullptr;  // (read once, not per candidate)
+  const bool denseMergeOn = denseMergeRule;
   while (!queue.empty()) {
     Cand top = queue.top();
     queue.pop();

@@ -35,6 +35,8 @@ struct EliminationTree {
   void collapseMergePointers();
 
   // inputs
+  bool denseMergeRule = true;  // HipBackendOptions::denseMerge ("rows >= 90 % of the parent" merges)
+  int expectedBatch = 1;       // matrices per factor() the merge model plans for (computeMerges)
   std::vector<int64_t> paramSize;
   const SparseStructure& ss;  // csr, lower half, already fill-reducing ordered
   const ComputationModel& compMod;

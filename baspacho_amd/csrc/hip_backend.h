@@ -37,6 +37,8 @@ struct HipPlanStats {
           numGatherGroups = 0,  // (always 0 since round 4: the overlapped elimination was removed)
           numForkLevels = 0;
   double deferredFlops = 0;
+  double tailUpdFlops = 0;  // update flops done inside persistent tail launches (not part of updFlops)
+  int64_t numTailPanels = 0;
 };
 
 // while `prof` is non-null every kernel launch of the context is bracketed by HIP events and

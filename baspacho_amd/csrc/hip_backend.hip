@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 
+#include "backend_options.h"
 #include "hip_backend.h"
 #include "hip_kernels.h"
 #include "hip_solve_kernels.h"
@@ -420,24 +421,33 @@ struct FlagOff {
 };
 
 struct HipSymbolicCtx : SymbolicCtx {
-  HipSymbolicCtx(const CoalescedBlockMatrixSkel& skel_, const vector<int64_t>& permutation_)
+  // `o`: the caller's switches with the environment already applied (backend_options.h)
+  HipSymbolicCtx(const CoalescedBlockMatrixSkel& skel_, const vector<int64_t>& permutation_,
+                 const HipBackendOptions& o)
       : skel(skel_), permutation(permutation_) {
-    if (const char* e = std::getenv("BSP_NO_LOOKAHEAD")) lookaheadEnabled = e[0] == '0';
-    if (const char* e = std::getenv("BSP_BLOCK_SOLVE")) blockSolve = e[0] != '0';
-    if (const char* e = std::getenv("BSP_SOLVE_INV")) solveInv = e[0] != '0';
-    if (const char* e = std::getenv("BSP_SUB_BATCH_MIN")) subBatchMin = std::max(2, std::atoi(e));
-    if (const char* e = std::getenv("BSP_SUB_BATCHES")) subBatchParts = std::max(2, std::atoi(e));
-    if (const char* e = std::getenv("BSP_SPLIT_K")) splitK = e[0] != '0';
-    if (const char* e = std::getenv("BSP_SOLVE_SWEEP")) sweepEnabled = e[0] != '0';
-    if (const char* e = std::getenv("BSP_GATHER_OVERLAP")) gatherOverlap = e[0] != '0';
+    lookaheadEnabled = HipBackendOptions::on(o.lookahead, true);
+    blockSolve = HipBackendOptions::on(o.blockSolve, true);
+    solveInv = HipBackendOptions::on(o.solveInv, true);
+    if (o.subBatchMin >= 0) subBatchMin = o.subBatchMin == 0 ? INT32_MAX : std::max(2, o.subBatchMin);
+    if (o.subBatches >= 0) subBatchParts = std::max(2, o.subBatches);
+    splitK = HipBackendOptions::on(o.splitK, true);
+    sweepEnabled = HipBackendOptions::on(o.solveSweep, true);
+    gatherOverlap = HipBackendOptions::on(o.gatherOverlap, false);
+    if (o.sweepMinWidth >= 0) sweepMinWidth = std::max(1, o.sweepMinWidth);
+    lazyPlan = HipBackendOptions::on(o.lazyPlan, false);
+    if (!std::isnan(o.lookaheadMinGF)) lookaheadMinFlops = 1e9 * o.lookaheadMinGF;
+    // the plan builder's switches: handed to every buildHipPlan call and recorded in the plan;
+    // launchLevels takes dueStream from the plan it runs
+    planOpts.dueStream = HipBackendOptions::on(o.dueStream, planOpts.dueStream);
+    if (o.gatherMaxPairs >= 0) planOpts.gatherMaxPairs = std::max(8, o.gatherMaxPairs);
+    if (!std::isnan(o.bulkAhead)) planOpts.bulkAhead = o.bulkAhead;
+    if (o.tailBlocks >= 0) planOpts.tailBlocks = o.tailBlocks;
+    planOpts.gatherOverlap = gatherOverlap;
+    planOpts.applyDeveloperEnv();
+    // developer aids and experiment parameters that are not options of the product
     if (const char* e = std::getenv("BSP_TAIL_FLAGS")) tailFlags = std::atoi(e);
     if (const char* e = std::getenv("BSP_GATHER_OVERLAP_LDS")) gatherOverlapLds = (unsigned)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("BSP_SWEEP_MIN_WIDTH")) sweepMinWidth = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BSP_SWEEP_TRACE")) sweepTraceOn = e[0] != '0';
-    // the plan builder's switches: read here, once per Solver, handed to every buildHipPlan call
-    // and recorded in the plan; launchLevels takes dueStream from the plan it runs
-    planOpts = HipPlanOptions::fromEnv();
-    if (const char* e = std::getenv("BSP_LOOKAHEAD_MIN_GF")) lookaheadMinFlops = 1e9 * std::atof(e);
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -504,7 +514,7 @@ struct HipSymbolicCtx : SymbolicCtx {
       (void)hipGetLastError();
       return;
     }
-    if (std::getenv("BSP_LAZY_PLAN")) return;  // (A/B: the lazy behaviour of rounds 1-3)
+    if (lazyPlan) return;  // (A/B: the lazy behaviour of rounds 1-3)
     struct Scope {
       bool& f;
       explicit Scope(bool& f_) : f(f_) { f = true; }
@@ -669,6 +679,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipKernelProfile* profile = nullptr;
   bool profileInSitu = false;  // profile with the lookahead schedule left on (two streams)
   bool lookaheadEnabled = true;
+  bool lazyPlan = false;  // HipBackendOptions::lazyPlan
   // LDS padding of side-stream launches: three bulk workgroups per CU, so that a chain workgroup
   // always finds a slot
   static constexpr unsigned bulkExtraLds = 6 * 1024, dueExtraLds = 6 * 1024;
@@ -685,7 +696,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   unsigned gatherOverlapLds = 0;  // dynamic LDS of the overlapped chunks' launches (throttle; BSP_GATHER_OVERLAP_LDS)
   bool gatherOverlap = false;  // gather chunks beside the dense chain (BSP_GATHER_OVERLAP=1; off: the plan is not chunked either)
   static constexpr int64_t splitKMaxWgs = 1024;  // ... launches of at most this many workgroups (a batch of 8: 2.26 = 2.26 ms at 1024, 2.48 at 4096)
-  int subBatchMin = 16;     // batches of at least this many matrices are factored as concurrent sub-batches (BSP_SUB_BATCH_MIN; 0x7fffffff: never)
+  int subBatchMin = 16;     // batches of at least this many matrices are factored as concurrent sub-batches (BSP_SUB_BATCH_MIN; 0: never)
   int subBatchParts = 2;    // ... this many (BSP_SUB_BATCHES, at most 4, at least subBatchMin / 2 matrices each)
   vector<hipEvent_t> events;
   size_t nextEvent = 0;
@@ -2108,15 +2119,22 @@ SolveCtxBase* HipSymbolicCtx::createSolveCtxForType(std::type_index tIdx, int nR
 }
 
 struct HipOps : Ops {
+  explicit HipOps(const HipBackendOptions& o) : options(o) {}
   virtual SymbolicCtxPtr createSymbolicCtx(const CoalescedBlockMatrixSkel& skel,
                                            const vector<int64_t>& permutation) override {
-    return SymbolicCtxPtr(new HipSymbolicCtx(skel, permutation));
+    return SymbolicCtxPtr(new HipSymbolicCtx(skel, permutation, options));
   }
+  HipBackendOptions options;
 };
 
 }  // namespace
 
-OpsPtr hipOps() { return OpsPtr(new HipOps); }
+OpsPtr hipOps(const HipBackendOptions* options) {
+  if (options) return OpsPtr(new HipOps(*options));
+  HipBackendOptions o;  // (callers that build a Solver from a skeleton: defaults + environment)
+  o.applyEnv();
+  return OpsPtr(new HipOps(o));
+}
 
 int hipBackendReadExtents(unsigned long long* out, int maxLaunches) {
 #if defined(BSP_KTRACE) && defined(BSP_TRACE_TILE)
@@ -2277,6 +2295,8 @@ HipPlanStats hipBackendPlanStats(SymbolicCtx& sym, int64_t startLump, int64_t up
   s.numAtomicUpdTasks = atomicTasks;
   s.numForkLevels = p.numForkLevels;
   s.deferredFlops = p.deferredFlops;
+  s.tailUpdFlops = p.tailUpdFlops;
+  for (const LevelRange& lr : p.levels) s.numTailPanels += lr.tail ? 1 : 0;
   return s;
 }
 

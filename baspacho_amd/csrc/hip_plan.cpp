@@ -330,17 +330,11 @@ struct PanelBuild {
 
 }  // namespace
 
-HipPlanOptions HipPlanOptions::fromEnv() {
-  HipPlanOptions o;
-  if (const char* e = std::getenv("BSP_DUE_STREAM")) o.dueStream = e[0] != '0';
-  o.planTiming = std::getenv("BSP_TIMING") != nullptr;
-  if (const char* e = std::getenv("BSP_GATHER_MAX_PAIRS")) o.gatherMaxPairs = std::max(8, atoi(e));
-  if (const char* e = std::getenv("BSP_BULK_AHEAD")) o.bulkAhead = std::atof(e);
-  if (const char* e = std::getenv("BSP_TAIL_BLOCKS")) o.tailBlocks = std::max(0, std::atoi(e));
-  if (const char* e = std::getenv("BSP_GATHER_OVERLAP")) o.gatherOverlap = e[0] != '0';
-  if (const char* e = std::getenv("BSP_GATHER_OVERLAP_FIRST")) o.overlapFirst = std::max(1, std::atoi(e));
-  if (const char* e = std::getenv("BSP_GATHER_OVERLAP_STEP")) o.overlapStep = std::max(1, std::atoi(e));
-  return o;
+// (the product's switches arrive through HipBackendOptions; these are developer aids)
+void HipPlanOptions::applyDeveloperEnv() {
+  planTiming = std::getenv("BSP_TIMING") != nullptr;
+  if (const char* e = std::getenv("BSP_GATHER_OVERLAP_FIRST")) overlapFirst = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("BSP_GATHER_OVERLAP_STEP")) overlapStep = std::max(1, std::atoi(e));
 }
 
 HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_t>& elimRangesIn,

@@ -227,8 +227,8 @@ struct ElimRangePlan {
   int64_t overlapLump = -1;
 };
 
-// Every switch the plan builder honours, read ONCE (HipPlanOptions::fromEnv, called when a
-// SymbolicCtx is created) and recorded in the plan it produced: the launch code takes the
+// Every switch the plan builder honours, resolved ONCE when a SymbolicCtx is created (from
+// HipBackendOptions, backend_options.h) and recorded in the plan it produced: the launch code takes the
 // schedule-shaping ones (dueStream, dueSplit) from the plan it runs, never from a second read of
 // the environment, so the builder's "two streams may meet" bits and the launcher's choice of
 // streams cannot disagree.
@@ -246,7 +246,7 @@ struct HipPlanOptions {
   // (BSP_TAIL_BLOCKS; 0: the level schedule to the end)
   int32_t tailBlocks = 6;
   int32_t tailMinBlocks = 6;
-  static HipPlanOptions fromEnv();
+  void applyDeveloperEnv();  // BSP_TIMING, chunk sizes of the gather-overlap experiment
 };
 
 struct HipPlanHost {

@@ -241,6 +241,8 @@ SolveCtxPtr<T> SymbolicCtx::createSolveCtx(int nRHS, const T* data) {
 // MI355X backend (hand-written HIP for gfx950).  The CPU backends of the reference
 // (simpleOps/fastOps) are deliberately NOT part of the product: a CPU restatement lives under
 // oracle/ as test infrastructure only.
-OpsPtr hipOps();
+struct HipBackendOptions;
+// (options: already resolved against the environment by the caller, or null = defaults + environment)
+OpsPtr hipOps(const HipBackendOptions* options = nullptr);
 
 }  // namespace BaSpaCho

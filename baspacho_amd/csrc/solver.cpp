@@ -491,8 +491,8 @@ BSP_INSTANTIATE(std::vector<double*>)
 BSP_INSTANTIATE(std::vector<float*>)
 #undef BSP_INSTANTIATE
 
-static OpsPtr getBackend(const Settings& settings) {
-  if (settings.backend == BackendHip || settings.backend == BackendCuda) return hipOps();
+static OpsPtr getBackend(const Settings& settings, const HipBackendOptions& options) {
+  if (settings.backend == BackendHip || settings.backend == BackendCuda) return hipOps(&options);
   throw std::runtime_error(
       "baspacho_amd: only the MI355X HIP backend (BackendHip, alias BackendCuda) is part of "
       "this build; the CPU restatement lives under oracle/ as test infrastructure");
@@ -504,6 +504,9 @@ SolverPtr createSolver(const Settings& settings, const vector<int64_t>& paramSiz
   BASPACHO_CHECK(settings.addFillPolicy == AddFillComplete || elimLastIds.empty());
   BASPACHO_CHECK((int64_t)sparseElimRanges.size() != 1);
   BASPACHO_CHECK_EQ((int64_t)paramSize.size(), ssIn.order());
+  // the backend's switches: the caller's, then the environment on top (A/B scripts), resolved once
+  HipBackendOptions options = settings.hipOptions ? *settings.hipOptions : HipBackendOptions();
+  options.applyEnv();
   const int64_t nParams = (int64_t)paramSize.size();
   const int64_t givenElimEnd = sparseElimRanges.empty() ? 0 : sparseElimRanges.back();
   if (!sparseElimRanges.empty()) {
@@ -532,7 +535,7 @@ SolverPtr createSolver(const Settings& settings, const vector<int64_t>& paramSiz
     CoalescedBlockMatrixSkel skel(spanStart, lumpToSpan, cols.ptrs, cols.inds);
     vector<int64_t> ranges = sparseElimRanges;
     return SolverPtr(new Solver(std::move(skel), std::move(ranges), std::move(identity),
-                                getBackend(settings),
+                                getBackend(settings, options),
                                 settings.addFillPolicy == AddFillNone ? 0 : givenElimEnd));
   }
 
@@ -549,7 +552,7 @@ SolverPtr createSolver(const Settings& settings, const vector<int64_t>& paramSiz
   // fill-reducing ordering of what is left after the given eliminations
   SparseStructure bottom = ss.extractRightBottom(givenElimEnd);
   lap("elim fill + extract");
-  vector<int64_t> perm = bottom.fillReducingPermutation(/* contractChains */ true);
+  vector<int64_t> perm = bottom.fillReducingPermutation(HipBackendOptions::on(options.chainContraction, true));
   lap("min-degree ordering");
   vector<int64_t> noCrossPoints;
   if (!elimLastIds.empty()) {  // stable partition: "last" ids go to the end
@@ -570,6 +573,8 @@ SolverPtr createSolver(const Settings& settings, const vector<int64_t>& paramSiz
       settings.computationModel ? settings.computationModel : &ComputationModel::model_Hip_MI355X;
 
   EliminationTree et(sortedBottomSize, sortedBottom, model);
+  et.denseMergeRule = HipBackendOptions::on(options.denseMerge, true);
+  et.expectedBatch = std::max(1, options.expectedBatch);
   et.buildTree();
   lap("etree build");
   et.processTree(settings.findSparseEliminationRanges, noCrossPoints,
@@ -617,7 +622,7 @@ SolverPtr createSolver(const Settings& settings, const vector<int64_t>& paramSiz
   const int64_t fullElimEnd = fullRanges.empty() ? 0 : fullRanges.back();
 
   return SolverPtr(new Solver(std::move(skel), std::move(fullRanges), std::move(fullInvPerm),
-                              getBackend(settings),
+                              getBackend(settings, options),
                               settings.addFillPolicy == AddFillForAutoElims ? fullElimEnd : nParams));
 }
 

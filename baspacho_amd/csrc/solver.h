@@ -9,6 +9,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "backend_options.h"
 #include "mat_ops.h"
 #include "skeleton.h"
 #include "sparse_structure.h"
@@ -152,6 +153,8 @@ struct Settings {
   BackendType backend = BackendHip;
   AddFillPolicy addFillPolicy = AddFillComplete;
   const ComputationModel* computationModel = nullptr;
+  // extension: schedule switches of the MI355X backend (backend_options.h); null = defaults
+  const HipBackendOptions* hipOptions = nullptr;
 };
 
 SolverPtr createSolver(const Settings& settings, const std::vector<int64_t>& paramSizes,

@@ -160,11 +160,7 @@ SparseStructure SparseStructure::addFullEliminationFill() const {
 
 std::vector<int64_t> SparseStructure::fillReducingPermutation(bool contractChains) const {
   // 50 = the smallest set elimination_tree.cpp turns into a sparse-elimination range
-  static const bool enabled = [] {
-    const char* e = std::getenv("BSP_CHAIN_CONTRACTION");
-    return !(e && e[0] == '0');
-  }();
-  return minimumDegreeOrdering(ptrs, inds, contractChains && enabled ? 50 : 0);
+  return minimumDegreeOrdering(ptrs, inds, contractChains ? 50 : 0);
 }
 
 SparseStructure SparseStructure::extractRightBottom(int64_t start) const {

@@ -46,6 +46,33 @@ typedef struct bsp_settings {
   const double* computation_model;
 } bsp_settings;
 
+/* Extension (no counterpart in the reference): the schedule switches of the MI355X backend
+   (csrc/backend_options.h).  Every field: a negative value (NaN for the doubles) = the library's
+   default; a zeroed struct is NOT "all defaults" -- start from bsp_hip_options_default().  The
+   environment variables of the same names (BSP_TAIL_BLOCKS, BSP_SOLVE_SWEEP, ...) still override what
+   is passed here: they exist for A/B scripts. */
+typedef struct bsp_hip_options {
+  int32_t lookahead;         /* 0: lookahead units in line */
+  int32_t due_stream;        /* 0: one auxiliary stream */
+  int32_t split_k;           /* 0: no split-K tile lists */
+  int32_t gather_max_pairs;  /* pairs per sparse-elimination gather item */
+  int32_t gather_overlap;    /* 1: gather chunks beside the dense chain (measured: no gain) */
+  int32_t sub_batch_min;     /* batches of at least this many as concurrent sub-batches; 0: never */
+  int32_t sub_batches;       /* ... this many parts */
+  int32_t tail_blocks;       /* outer blocks of a wide root lump for the persistent tail launch; 0: off */
+  int32_t lazy_plan;         /* 1: no eager device plan when the solver is created */
+  int32_t block_solve;       /* 0: wide lumps solved panel by panel */
+  int32_t solve_inv;         /* 0: substitution instead of inverted diagonal blocks */
+  int32_t solve_sweep;       /* 0: no persistent solve sweeps */
+  int32_t sweep_min_width;   /* narrowest run of columns a sweep takes */
+  int32_t chain_contraction; /* 0: no contraction of pivot chains before the ordering */
+  int32_t dense_merge;       /* 0: no "rows >= 90 % of the parent's column" merge rule */
+  int32_t expected_batch;    /* matrices per factor() call the supernode-merge model plans for (default 1) */
+  double lookahead_min_gf;   /* GF per fork below which lookahead units stay in line */
+  double bulk_ahead;         /* share of the next block's chain handed out as optional lookahead units */
+} bsp_hip_options;
+void bsp_hip_options_default(bsp_hip_options* out);
+
 const char* bsp_last_error(void);
 const char* bsp_version(void);
 
@@ -56,6 +83,12 @@ int bsp_create_solver(const bsp_settings* settings, int64_t num_params, const in
                       const int64_t* ptrs, const int64_t* inds, int64_t num_elim_ranges,
                       const int64_t* elim_ranges, int64_t num_elim_last, const int64_t* elim_last,
                       bsp_solver** out);
+
+/* ... the same with the backend's switches (NULL = bsp_create_solver) */
+int bsp_create_solver_opts(const bsp_settings* settings, const bsp_hip_options* options,
+                           int64_t num_params, const int64_t* param_sizes, const int64_t* ptrs,
+                           const int64_t* inds, int64_t num_elim_ranges, const int64_t* elim_ranges,
+                           int64_t num_elim_last, const int64_t* elim_last, bsp_solver** out);
 
 /* Solver::Solver(CoalescedBlockMatrixSkel&&, sparseElimRanges, permutation, ops)
    Solver.h:37-38 -- solver from a RAW skeleton, as the reference's tests build it
@@ -266,6 +299,9 @@ typedef struct bsp_plan_stats {
       num_fork_levels;   /* levels that hand lookahead units to the auxiliary streams */
   double deferred_flops; /* flops of those units; the lookahead schedule is used when they are worth
                             the forks (HipPlanHost::lookaheadPays) */
+  double tail_upd_flops; /* update flops done inside the persistent tail launch (csrc/hip_tail_kernel.h);
+                            not part of upd_flops */
+  int64_t num_tail_panels;
 } bsp_plan_stats;
 int bsp_plan_stats_full(bsp_solver* s, bsp_plan_stats* out);
 

@@ -140,7 +140,10 @@ def test_batch_as_concurrent_halves(bs, monkeypatch):
                 B.create_solver(B.Settings(), np.full(n, 2, dtype=np.int64), T.columns_to_structure(cols))):
         datas = [spd_data(sol, 300 + q) for q in range(bs)]
         devs = [to_dev(d) for d in datas]
+        before = sol.runCounters()["sub_batches_enqueued"]
         sol.factor(devs)
+        # (the run counters say which path ran: two halves, each enqueued on a stream of its own)
+        assert sol.runCounters()["sub_batches_enqueued"] == before + 2, "the batch was not split"
         for q in range(bs):
             L, _ = dense_lower_chol(sol, datas[q])
             err = np.linalg.norm(lower_of(sol, devs[q].cpu().numpy()) - L) / np.linalg.norm(L)
@@ -338,6 +341,10 @@ def test_schedule_variants(monkeypatch, knob):
     _, A = dense_lower_chol(sol, data)
     Lg = lower_of(sol, _gpu_factor(sol, data))
     assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < 1e-10
+    # (the switch was honoured: no launch went to the auxiliary streams with the lookahead off or
+    #  priced out; the 700-wide lump is too small for the lookahead to pay in any variant)
+    if k in ("BSP_NO_LOOKAHEAD", "BSP_LOOKAHEAD_MIN_GF"):
+        assert sol.runCounters()["lookahead_forks"] == 0
     sizes, ss, _, _ = T.gen_bal_synthetic(num_cams=60, num_pts=6000, band=8, seed=5)
     sol = B.create_solver(B.Settings(), sizes, ss, [0, 6000])
     data = spd_data(sol, 11, beta_factor=1.2)
@@ -369,7 +376,10 @@ def test_split_k_tiles_of_small_levels(monkeypatch, split, dtype):
     for bs in (1, 3):
         datas = [spd_data(sol, 70 + q, beta_factor=1.2) for q in range(bs)]
         devs = [to_dev(d.astype(dtype)) for d in datas]
+        before = sol.runCounters()["split_lists_used"]
         sol.factor(devs if bs > 1 else devs[0])
+        used = sol.runCounters()["split_lists_used"] - before
+        assert (used > 0) == (split == "1"), ("split-K lists used by %d launches" % used, split)
         for q in range(bs):
             _, A = dense_lower_chol(sol, datas[q])
             Lg = lower_of(sol, devs[q].cpu().numpy()).astype(np.float64)
@@ -405,6 +415,10 @@ def test_wide_dense_lump_residual():
     _, A = dense_lower_chol(sol, data)
     Lg = lower_of(sol, _gpu_factor(sol, data))
     assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < 1e-10
+    # (the switch was honoured: no launch went to the auxiliary streams with the lookahead off or
+    #  priced out; the 700-wide lump is too small for the lookahead to pay in any variant)
+    if k in ("BSP_NO_LOOKAHEAD", "BSP_LOOKAHEAD_MIN_GF"):
+        assert sol.runCounters()["lookahead_forks"] == 0
 
 
 def test_errors_are_loud():

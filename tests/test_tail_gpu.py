@@ -96,3 +96,27 @@ def test_no_tail_for_a_lump_with_rows_below_or_a_narrow_one(monkeypatch):
     L, _ = dense_lower_chol(sol, data)
     got = lower_of(sol, dev.cpu().numpy())
     assert np.linalg.norm(got - L) / np.linalg.norm(L) < 1e-12
+
+
+def test_backend_options_reach_the_schedule_without_the_environment():
+    """Settings.hipOptions -> bsp_hip_options -> HipBackendOptions (csrc/backend_options.h): the switches
+    of the tail launch and of the persistent sweeps, set by the CALLER (no environment variable)"""
+    sizes = [8] * 200  # one dense lump of 1600 columns
+    ss = T.columns_to_structure([list(range(c, len(sizes))) for c in range(len(sizes))])
+    for opts, want_tail, want_sweep in (({}, True, True), ({"tail_blocks": 0}, False, True),
+                                        ({"solve_sweep": 0, "tail_blocks": 3}, True, False)):
+        st = B.Settings(findSparseEliminationRanges=False, hipOptions=opts or None)
+        sol = B.create_solver(st, np.asarray(sizes, dtype=np.int64), ss, [])
+        data = spd_data(sol, 8)
+        _, A = dense_lower_chol(sol, data)
+        dev = to_dev(data)
+        sol.factor(dev)
+        n = sol.order()
+        rhs = np.random.default_rng(2).standard_normal(n)
+        v = to_dev(rhs.copy())
+        sol.solve(dev, v, n, 1)
+        X = np.linalg.solve(A, rhs)
+        assert np.linalg.norm(v.cpu().numpy() - X) / np.linalg.norm(X) < 1e-10, opts
+        c = sol.runCounters()
+        assert (c["tail_launches"] > 0) == want_tail and (c["sweep_launches"] > 0) == want_sweep, (opts, c)
+        assert (sol.planStats()["num_tail_panels"] > 0) == want_tail
