@@ -69,7 +69,7 @@ class _CRunCounters(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
                 ["sweep_launches", "sweep_timeouts", "split_lists_used", "sub_batches_enqueued",
                  "lookahead_forks", "sweeps_retired", "sweep_error_pending",
-                 "gather_chunks_overlapped", "tail_launches"]]
+                 "gather_chunks_overlapped", "tail_launches", "sweep_mfma_launches"]]
 
 
 @dataclass

@@ -652,6 +652,7 @@ int bsp_run_counters_get(bsp_solver* s, bsp_run_counters* out) {
   out->sweep_error_pending = c.sweepErrorPending;
   out->gather_chunks_overlapped = c.gatherChunksOverlapped;
   out->tail_launches = c.tailLaunches;
+  out->sweep_mfma_launches = c.sweepMfmaLaunches;
   BSP_CATCH
 }
 

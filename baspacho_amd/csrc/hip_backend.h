@@ -75,6 +75,7 @@ struct HipRunCounters {
   int64_t lookaheadForks = 0;      // lookahead launches handed to the auxiliary streams
   int64_t gatherChunksOverlapped = 0;  // sparse-elimination gather chunks launched beside the dense chain
   int64_t tailLaunches = 0;        // persistent tail launches (hip_tail_kernel.h)
+  int64_t sweepMfmaLaunches = 0;   // ... of sweepLaunches: the matrix-core form for several right-hand sides
   int64_t sweepsRetired = 0;       // 1: a time-out retired the sweeps of this Solver
   int64_t sweepErrorPending = 0;   // 1: a time-out has been raised and not been reported yet
 };

@@ -16,6 +16,7 @@
 #include "hip_kernels.h"
 #include "hip_solve_kernels.h"
 #include "hip_sweep_kernels.h"
+#include "hip_sweep_mfma.h"
 #include "hip_tail_kernel.h"
 #include "mat_ops.h"
 
@@ -85,7 +86,7 @@ struct SolveInvList {
   vector<SolveSchedItem> items;
   int32_t numSweeps = 0;
   int64_t sweepInstStride = 0;  // values per (right-hand side, batch entry) of the exchange buffer
-  int64_t maxSweepWgs = 0;
+  int64_t maxSweepWgs = 0, maxSweepWgsM = 0;  // (M: the matrix-core sweep, hip_sweep_mfma.h)
   int32_t maxSweepW = 0, maxSweepBelow = 0;
 };
 
@@ -448,6 +449,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_TAIL_FLAGS")) tailFlags = std::atoi(e);
     if (const char* e = std::getenv("BSP_GATHER_OVERLAP_LDS")) gatherOverlapLds = (unsigned)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BSP_SWEEP_TRACE")) sweepTraceOn = e[0] != '0';
+    if (const char* e = std::getenv("BSP_SWEEP_MFMA_MIN")) sweepMfmaMinRhs = std::max(1, std::atoi(e));
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -715,6 +717,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   // ---- persistent sweeps over wide lumps (hip_sweep_kernels.h, round 6)
   bool sweepEnabled = true;   // BSP_SOLVE_SWEEP=0: the multi-launch block path
   int sweepMinWidth = 768;    // runs of one-panel levels at least this wide (BSP_SWEEP_MIN_WIDTH)
+  int sweepMfmaMinRhs = 8;    // right-hand sides from which the matrix-core sweep takes over (BAL-871: equal to the multi-launch path at 6, -5 % at 10, -10 % at 16; developer: BSP_SWEEP_MFMA_MIN)
   bool sweepBroken = false;   // a sweep timed out or cannot be launched here: multi-launch path for good
   int sweepFault = 0;         // TESTING (bsp_test_set_fault kind 2): spine of block 1 never publishes
   double sweepSpinLimitS = 2.0;  // watchdog: a spin that lasts longer aborts the launch
@@ -730,7 +733,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   int sweepAttr[2] = {0, 0};  // per value size (8, 4): 0 not tried, 1 ready, -1 failed
   struct RunCounters {
     int64_t sweepLaunches = 0, sweepTimeouts = 0, splitListsUsed = 0, subBatchesEnqueued = 0,
-            lookaheadForks = 0, gatherChunksOverlapped = 0, tailLaunches = 0;
+            lookaheadForks = 0, gatherChunksOverlapped = 0, tailLaunches = 0, sweepMfmaLaunches = 0;
   } counters;
   // a timed-out persistent launch (solve sweep, factor tail) is reported ONCE, by the next factor()
   // or solve() on this Solver; the persistent kernels are then retired for good
@@ -789,6 +792,10 @@ struct HipSymbolicCtx : SymbolicCtx {
         bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&hipk::solveSweep<BT, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&hipk::solveSweep<BT, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&hipk::solveSweepM<BT, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&hipk::solveSweepM<BT, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
         if (ok && !sweepHostErr) {
           void* hp = nullptr;
@@ -1691,6 +1698,8 @@ struct HipSolveCtx : SolveCtx<T> {
                            (sd.rowsBelow + hipk::kSweepFarRows - 1) / hipk::kSweepFarRows;
           it.sweepBwdWgs = hipk::kSweepBwdGroup * sd.nBlocks;
           ent.maxSweepWgs = std::max<int64_t>(ent.maxSweepWgs, std::max(it.sweepFwdWgs, it.sweepBwdWgs));
+          ent.maxSweepWgsM = std::max<int64_t>(ent.maxSweepWgsM,
+                                               std::max<int64_t>(it.sweepFwdWgs, hipk::kSweepFwdGroup * sd.nBlocks));
           ent.maxSweepW = std::max(ent.maxSweepW, sd.w);
           ent.maxSweepBelow = std::max(ent.maxSweepBelow, sd.rowsBelow);
           ent.numSweeps++;
@@ -1734,9 +1743,15 @@ struct HipSolveCtx : SolveCtx<T> {
   // may this call run the sweeps of `ent`?  Every workgroup of a sweep launch should be resident at
   // once (correct either way -- roles are dealt by ticket -- but a far role that starts late has a
   // whole row strip to catch up on at one CU's bandwidth), and its LDS must fit.
+  // (several right-hand sides: the matrix-core sweep, 16 right-hand sides per set of workgroups)
+  bool sweepMfma() const { return nRHS >= sym.sweepMfmaMinRhs; }
   bool sweepsFit(const SolveInvList& ent) {
     if (ent.numSweeps == 0) return false;
     if (!sym.sweepReady<BT>()) return false;
+    if (sweepMfma()) {
+      const int64_t inst = (int64_t)((nRHS + hipk::kSweepR - 1) / hipk::kSweepR) * batch;
+      return ent.maxSweepWgsM * inst <= sym.sweepCapacity && hipk::sweepMLdsBytes<BT>() <= sym.sweepMaxLds;
+    }
     const int64_t inst = (int64_t)nRHS * batch;
     if (ent.maxSweepWgs * inst > sym.sweepCapacity) return false;
     const size_t lds = std::max(hipk::sweepLdsBytes<BT>(ent.maxSweepW, ent.maxSweepBelow, false),
@@ -1770,7 +1785,10 @@ struct HipSolveCtx : SolveCtx<T> {
     int64_t invBatchStride = 0;
     BT* xchg = nullptr;
     hipk::SweepShared sh{};
-    const int64_t nInst = (int64_t)nRHS * batch;
+    const bool mfma = sweeps && sweepMfma();
+    const int64_t rhsGroups = mfma ? (nRHS + hipk::kSweepR - 1) / hipk::kSweepR : nRHS;
+    const int64_t nInst = rhsGroups * batch;
+    const int64_t instStride = ent.sweepInstStride * (mfma ? hipk::kSweepR : 1);
     if (ent.count > 0) {
       invBatchStride = ent.count * kPanelWidth * kPanelWidth;
       sym.solveInvScratch.resize((size_t)(invBatchStride * batch) * sizeof(BT));
@@ -1779,7 +1797,7 @@ struct HipSolveCtx : SolveCtx<T> {
       int64_t armWords = 0;
       if (sweeps) {
         const size_t ctlBytes = (((size_t)(1 + ent.numSweeps * nInst) * sizeof(unsigned)) + 255) / 256 * 256;
-        const size_t bytes = (ctlBytes + (size_t)(nInst * ent.sweepInstStride) * sizeof(BT) + 7) / 8 * 8;
+        const size_t bytes = (ctlBytes + (size_t)(nInst * instStride) * sizeof(BT) + 7) / 8 * 8;
         sym.sweepXchg.resize(bytes);
         arm = reinterpret_cast<unsigned long long*>(sym.sweepXchg.ptr);
         armWords = (int64_t)(bytes / 8);
@@ -1787,7 +1805,7 @@ struct HipSolveCtx : SolveCtx<T> {
         sh.ctl = reinterpret_cast<unsigned*>(sym.sweepXchg.ptr);
         sh.hostErr = sym.sweepHostErrDev;
         sh.spinLimit = (long long)(sym.sweepSpinLimitS * 1e8);
-        sh.instStride = ent.sweepInstStride;
+        sh.instStride = instStride;
         sh.fault = sym.sweepFault;
         sh.pad = 0;
         sh.trace = nullptr;
@@ -1808,6 +1826,15 @@ struct HipSolveCtx : SolveCtx<T> {
         hipk::SweepDesc sd = item.sweep;
         sd.ticketOff = (int32_t)((BACKWARD ? ent.numSweeps - 1 - sweepOrd : sweepOrd) * nInst);
         sweepOrd++;
+        if (mfma) {
+          const unsigned gx = (unsigned)(BACKWARD ? hipk::kSweepFwdGroup * sd.nBlocks : item.sweepFwdWgs);
+          hipk::solveSweepM<BT, BACKWARD><<<dim3(gx, (unsigned)rhsGroups, (unsigned)batch), 256,
+                                           hipk::sweepMLdsBytes<BT>(), sym.stream>>>(
+              sd, nRHS, invBase, invBatchStride, xchg, sh, plan.rowGlobal.as<int32_t>(), ref);
+          sym.counters.sweepLaunches++;
+          sym.counters.sweepMfmaLaunches++;
+          continue;
+        }
         const size_t lds = hipk::sweepLdsBytes<BT>(sd.w, sd.rowsBelow, BACKWARD);
         const unsigned gx = (unsigned)(BACKWARD ? item.sweepBwdWgs : item.sweepFwdWgs);
         hipk::solveSweep<BT, BACKWARD><<<grid(gx), 256, lds, sym.stream>>>(
@@ -2251,6 +2278,7 @@ HipRunCounters hipBackendRunCounters(SymbolicCtx& sym) {
   c.lookaheadForks = h->counters.lookaheadForks;
   c.gatherChunksOverlapped = h->counters.gatherChunksOverlapped;
   c.tailLaunches = h->counters.tailLaunches;
+  c.sweepMfmaLaunches = h->counters.sweepMfmaLaunches;
   c.sweepsRetired = h->sweepBroken ? 1 : 0;
   c.sweepErrorPending = (h->sweepHostErr && *reinterpret_cast<volatile unsigned*>(h->sweepHostErr)) ? 1 : 0;
   return c;

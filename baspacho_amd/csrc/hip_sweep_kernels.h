@@ -202,6 +202,22 @@ __device__ __forceinline__ T sweepRowSum16(T (&v)[16], int lane) {
   return d;
 }
 
+// ... the same, but spinning on ONE of the words (the one published last) until it is there: a
+// poll of N words by a few hundred waiting waves is N times the traffic on the lines everybody is
+// waiting for, and slows the very publish it waits for (matrix-core sweep: 48 words per lane and poller)
+template <typename T, int N>
+__device__ __forceinline__ bool sweepWaitCanary(GP<const T> (&p)[N], const bool (&need)[N], T (&out)[N],
+                                                SweepWatch& watch, int canary) {
+  watch.reset();
+  for (;;) {
+    const bool ok = !need[canary] || sweepValid(sweepPeek<T>(p[canary]));
+    if (__all(ok)) break;
+    if (watch.expired()) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return sweepWait<T, N>(p, need, out, watch);
+}
+
 // position in the vector of row q below the run
 __device__ __forceinline__ int sweepTargetRow(const SweepDesc& sd, const int32_t* rowGlobal, int q) {
   return q < sd.nRest ? sd.vecOff + sd.w + q : rowGlobal[sd.lumpRowBase + (q - sd.nRest)];
@@ -231,7 +247,7 @@ __device__ __forceinline__ void sweepSpine(const SweepDesc& sd, int b, GP<const 
   const int cp = bp * W;
   const bool hasFar = BACKWARD ? (sd.rowsBelow > 0 || b + 2 < sd.nBlocks) : b >= 2;
   const int ur = sweepRowOf(lane);
-  if (trace && tid == 0) trace[4 * b] = (long long)wall_clock64();
+  if (trace && tid == 0) trace[8 * b] = (long long)wall_clock64();
 
   // everything the step needs, requested before the wait.  Forward: tile rows are matrix rows, a lane
   // reads along a row.  Backward the tiles (and the inverses) are needed TRANSPOSED: read the natural,
@@ -354,7 +370,7 @@ __device__ __forceinline__ void sweepSpine(const SweepDesc& sd, int b, GP<const 
   }
   if (tid < W) xs[tid] = T(0);
   __syncthreads();
-  if (trace && tid == 0) trace[4 * b + 1] = (long long)wall_clock64();
+  if (trace && tid == 0) trace[8 * b + 1] = (long long)wall_clock64();
 
   GP<const T> pp[2 * Q];
   bool need[2 * Q];
@@ -370,7 +386,7 @@ __device__ __forceinline__ void sweepSpine(const SweepDesc& sd, int b, GP<const 
     got[Q + q] = T(0);
   }
   if (!sweepWait<T, 2 * Q>(pp, need, got, watch)) return;
-  if (trace && tid == 0) trace[4 * b + 2] = (long long)wall_clock64();
+  if (trace && tid == 0) trace[8 * b + 2] = (long long)wall_clock64();
 
   T t[Q];
 #pragma unroll
@@ -420,7 +436,7 @@ __device__ __forceinline__ void sweepSpine(const SweepDesc& sd, int b, GP<const 
       __syncthreads();
     }
   }
-  if (trace && tid == 0) trace[4 * b + 3] = (long long)wall_clock64();
+  if (trace && tid == 0) trace[8 * b + 3] = (long long)wall_clock64();
 }
 
 // ---- far, forward: rows [row0, row0 + 48) against source blocks 0 .. nSrc-1 ------------------------

@@ -319,6 +319,7 @@ typedef struct bsp_run_counters {
   int64_t sweep_error_pending;  /* 1: a time-out has been raised and not been reported yet */
   int64_t gather_chunks_overlapped; /* sparse-elimination gather chunks launched beside the dense chain */
   int64_t tail_launches;        /* persistent tail launches (csrc/hip_tail_kernel.h) */
+  int64_t sweep_mfma_launches;  /* ... of sweep_launches: the matrix-core form (several right-hand sides) */
 } bsp_run_counters;
 int bsp_run_counters_get(bsp_solver* s, bsp_run_counters* out);
 

@@ -71,8 +71,8 @@ def test_sweep_run_widths(monkeypatch, dtype, tail):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_sweep_default_threshold_and_rhs_counts(dtype):
     """the default configuration: a 1500-wide root lump + a 2100-wide lump with 500 rows below it,
-    1 .. 5 right-hand sides (each right-hand side is its own set of workgroups of the launch: 40 for
-    the first structure, 66 for the second -- three of those still fit the 256 CUs)"""
+    1 .. 5 right-hand sides, each its own set of workgroups of the launch (40 for the first structure,
+    66 for the second -- three of those still fit the 256 CUs)"""
     for W, tail, counts in ((1500, 0, (1, 3, 5)), (2100, 500, (1, 2, 3))):
         sol = _wide_solver(W, tail)
         data = spd_data(sol, 77 + W, dtype=dtype)
@@ -85,7 +85,7 @@ def test_sweep_falls_back_when_the_launch_would_not_be_resident():
     path runs instead, same results"""
     sol = _wide_solver(1100, 140)
     data = spd_data(sol, 3)
-    _check_all_solves(sol, data, np.float64, 40, want_sweeps=False)
+    _check_all_solves(sol, data, np.float64, 150, want_sweeps=False)  # ten groups of 16 x 41 workgroups
 
 
 def test_sweep_switched_off(monkeypatch):
@@ -174,3 +174,40 @@ def test_sweep_watchdog_ends_a_stuck_launch_and_retires_the_sweeps():
     want = np.linalg.solve(A, rhs)
     assert np.linalg.norm(v.cpu().numpy() - want) / np.linalg.norm(want) < 1e-10
     assert sol.runCounters()["sweep_launches"] == launched
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("tail", [0, 420])
+def test_matrix_core_sweep_several_right_hand_sides(monkeypatch, dtype, tail):
+    """csrc/hip_sweep_mfma.h: from eight right-hand sides on (here: three), ONE set of workgroups carries up to 16 of
+    them (products on v_mfma, x exchanged as [row][16]); 3 .. 16 right-hand sides in one group, 17 and 35
+    in two and three, run widths around the panel / block boundaries, rows below the run"""
+    monkeypatch.setenv("BSP_SWEEP_MIN_WIDTH", "128")
+    monkeypatch.setenv("BSP_SWEEP_MFMA_MIN", "3")  # (product default: 8)
+    for W, nrhs in ((130, 3), (192, 5), (193, 16), (385, 4), (577, 10), (641, 17), (960, 7), (1101, 35)):
+        sol = _wide_solver(W, tail, span=8 if W % 2 == 0 else 5)
+        data = spd_data(sol, 5 + W, dtype=dtype)
+        before = sol.runCounters()["sweep_mfma_launches"]
+        _check_all_solves(sol, data, dtype, nrhs)
+        assert sol.runCounters()["sweep_mfma_launches"] - before >= 4, "the matrix-core sweep was not the path taken"
+
+
+def test_matrix_core_sweep_batched_and_default_threshold():
+    sol = _wide_solver(1500, 140)
+    n, nrhs, batch = sol.order(), 10, 2
+    mats, rhs, dense = [], [], []
+    for q in range(batch):
+        data = spd_data(sol, 20 + q)
+        d = to_dev(data)
+        sol.factor(d)
+        mats.append(d)
+        dense.append(dense_lower_chol(sol, data)[1])
+        rhs.append(np.random.default_rng(q).standard_normal((nrhs, n)))
+    before = sol.runCounters()["sweep_mfma_launches"]
+    vecs = [to_dev(r.reshape(-1).copy()) for r in rhs]
+    sol.solve(mats, vecs, n, nrhs)
+    for q in range(batch):
+        got = vecs[q].cpu().numpy().reshape(nrhs, n).T
+        want = np.linalg.solve(dense[q], rhs[q].T)
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-9, q
+    assert sol.runCounters()["sweep_mfma_launches"] - before >= 2

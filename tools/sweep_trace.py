@@ -32,7 +32,7 @@ for part, fn, backward in (("solveL", sol.solveL, False), ("solveLt", sol.solveL
     buf = (ctypes.c_longlong * (4 * 4096))()
     nb = ctypes.c_int32(0)
     assert sol._lib.bsp_test_read_sweep_trace(sol._h, buf, 4096, ctypes.byref(nb)) == 0
-    t = np.array(buf[:4 * nb.value], dtype=np.int64).reshape(-1, 4)
+    t = np.array(buf[:4 * nb.value], dtype=np.int64).reshape(-1, 8)
     t = t[(t[:, 3] > 0) & (t[:, 0] > 0)]
     order = np.argsort(t[:, 3])
     t = t[order]
@@ -48,7 +48,7 @@ for part, fn, backward in (("solveL", sol.solveL, False), ("solveLt", sol.solveL
         if prev is not None:
             steps.append(step); waits.append(wait); comps.append(r[3] - r[2])
         if i < 6 or i >= len(us) - 3 or i % 8 == 0:
-            print("  %3d %7.2f %7.2f %7.2f %7.2f | %6.2f %8.2f %12.2f" % (order[i], r[0], r[1], r[2], r[3], step, wait, r[3] - r[2]))
+            print("  %3d %7.2f %7.2f %7.2f %7.2f | %6.2f %8.2f %12.2f   far-in %.2f" % (order[i], r[0], r[1], r[2], r[3], step, wait, r[3] - r[2], r[4] - t0 / 100.0 * 0 if r[4] > 0 else -1))
         prev = r[3]
     if steps:
         print("  median step %.2f us = hop %.2f + compute %.2f" % (np.median(steps), np.median(waits), np.median(comps)))
