@@ -320,3 +320,71 @@ def gen_bal_synthetic(num_cams=871, num_pts=527480, mean_track=5.8, band=48, far
     sizes = np.concatenate([np.full(num_pts, 3, dtype=np.int64), np.full(num_cams, 9, dtype=np.int64)])
     ss = structure_from_pairs(n, num_pts + cam, pt)
     return sizes, ss, cam, pt
+
+
+def gen_bal_clustered(num_cams=871, num_pts=527480, mean_track=8.0, cluster_min=8, cluster_max=30,
+                      link_prob=0.12, far_prob=0.01, degree_power=0.6, seed=37):
+    """A second stand-in for a BAL problem, with CLUSTERED co-visibility (round 6: the headline's
+    default stand-in draws a point's cameras uniformly in a +-48 band, so two cameras share few points;
+    real structure-from-motion scenes are groups of cameras looking at the same thing).
+
+    Cameras are cut into consecutive clusters of cluster_min .. cluster_max cameras; a point belongs to
+    one cluster (bigger clusters get more points) and sees cameras of THAT cluster, drawn with a
+    power-law popularity inside the cluster (camera of rank k with weight k^-degree_power: a few
+    cameras see most of the scene); an observation leaves for the next / previous cluster with
+    probability link_prob (what keeps the reduced camera system connected) and for a uniformly random
+    camera with probability far_prob.  Track lengths and sizes as gen_bal_synthetic.
+    returns (param_sizes, SparseStructure, obs_cam, obs_pt)
+    """
+    rng = Rng(seed)
+    bounds = [0]
+    k = 0
+    while bounds[-1] < num_cams:
+        width = cluster_min + int(hash_unit(seed + 11, np.array([k], dtype=np.uint64))[0] * (cluster_max - cluster_min + 1))
+        bounds.append(min(num_cams, bounds[-1] + width))
+        k += 1
+    if bounds[-1] - bounds[-2] < 2 and len(bounds) > 2:
+        bounds.pop(-2)
+    bounds = np.array(bounds, dtype=np.int64)
+    n_cl = len(bounds) - 1
+    csize = np.diff(bounds)
+    # cluster of every point: weight size^1.3, points ordered by cluster (as a pipeline emits them)
+    wts = csize.astype(np.float64) ** 1.3
+    cdf = np.cumsum(wts) / wts.sum()
+    cl = np.sort(np.searchsorted(cdf, rng.unit(num_pts), side="right").clip(0, n_cl - 1))
+    u = rng.unit(num_pts)
+    tail = rng.unit(num_pts) < 0.06
+    body_mean = max(mean_track - 2.0 - 0.06 * 18.0, 0.5)
+    p_body = 1.0 / (1.0 + body_mean)
+    extra = np.floor(np.log1p(-u) / np.log1p(-p_body)).astype(np.int64)
+    extra_tail = np.floor(np.log1p(-u) / np.log1p(-1.0 / 19.0)).astype(np.int64)
+    track = 2 + np.where(tail, extra_tail, extra)
+    track = np.minimum(track, np.maximum(2, csize[cl] + 4))
+    n_obs = int(track.sum())
+    pt = np.repeat(np.arange(num_pts, dtype=np.int64), track)
+    hop = rng.unit(n_obs)
+    oc = cl[pt] + np.where(hop < link_prob / 2, -1, np.where(hop < link_prob, 1, 0))
+    oc = np.clip(oc, 0, n_cl - 1)
+    # power-law rank inside the cluster: rank = floor(size * v^(1 / (1 - p))) concentrates on rank 0
+    v = rng.unit(n_obs)
+    rank = np.floor(csize[oc] * v ** (1.0 / (1.0 - degree_power))).astype(np.int64)
+    cam = bounds[oc] + np.minimum(rank, csize[oc] - 1)
+    far = rng.unit(n_obs) < far_prob
+    cam = np.where(far, np.floor(rng.unit(n_obs) * num_cams).astype(np.int64), cam)
+    key = np.unique(pt * num_cams + cam)
+    pt, cam = key // num_cams, key % num_cams
+    cnt = np.bincount(pt, minlength=num_pts)
+    lonely = np.nonzero(cnt < 2)[0]
+    if len(lonely):
+        first_cam = np.full(num_pts, -1, dtype=np.int64)
+        first_cam[pt[::-1]] = cam[::-1]
+        extra_cam = (first_cam[lonely] + 1) % num_cams
+        pt = np.concatenate([pt, lonely])
+        cam = np.concatenate([cam, extra_cam])
+        key = np.unique(pt * num_cams + cam)
+        pt, cam = key // num_cams, key % num_cams
+    n = num_pts + num_cams
+    sizes = np.concatenate([np.full(num_pts, 3, dtype=np.int64), np.full(num_cams, 9, dtype=np.int64)])
+    ss = structure_from_pairs(n, num_pts + cam, pt)
+    return sizes, ss, cam, pt
+

@@ -62,6 +62,14 @@ def build_problem(name, bal_file=None):
         sizes, ss, cam, pt = T.gen_bal_synthetic()
         return sizes, ss, [0, 527480], ("synthetic BAL-871 stand-in: 871 cams x 9, 527480 pts x 3, "
                                         "%d obs" % len(cam)), "synthetic"
+    if name == "bal871-clustered":   # generator sensitivity (round 6): clustered co-visibility
+        sizes, ss, cam, pt = T.gen_bal_clustered()
+        return sizes, ss, [0, 527480], ("synthetic BAL-871 stand-in, CLUSTERED co-visibility (clusters of 8-30 "
+                                        "cameras, power-law camera degree): %d obs" % len(cam)), "synthetic"
+    if name == "bal871-banded":      # ... and a narrow band with few loop closures
+        sizes, ss, cam, pt = T.gen_bal_synthetic(band=16, far_prob=0.005)
+        return sizes, ss, [0, 527480], ("synthetic BAL-871 stand-in, band +-16, far_prob 0.005: %d obs"
+                                        % len(cam)), "synthetic"
     if name == "bal1723":
         sizes, ss, cam, pt = T.gen_bal_synthetic(num_cams=1723, num_pts=156502, mean_track=4.4,
                                                  band=24, far_prob=0.02, seed=41)
