@@ -43,7 +43,7 @@ class _CSettings(ctypes.Structure):
 _HIP_OPTION_INTS = ["lookahead", "due_stream", "split_k", "gather_max_pairs", "gather_overlap",
                     "sub_batch_min", "sub_batches", "tail_blocks", "lazy_plan", "block_solve", "solve_inv",
                     "solve_sweep", "sweep_min_width", "chain_contraction", "dense_merge", "expected_batch"]
-_HIP_OPTION_REALS = ["lookahead_min_gf", "bulk_ahead"]
+_HIP_OPTION_REALS = ["lookahead_min_gf", "bulk_ahead", "level_cost_us"]
 
 
 class _CHipOptions(ctypes.Structure):

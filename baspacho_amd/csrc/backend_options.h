@@ -32,6 +32,7 @@ struct HipBackendOptions {
   int32_t expectedBatch = -1;     // matrices per factor() call the merge model plans for (BSP_EXPECTED_BATCH); default 1
   double lookaheadMinGF = NAN;    // GF per fork below which lookahead units stay in line (BSP_LOOKAHEAD_MIN_GF)
   double bulkAhead = NAN;         // share of the next block's chain handed out as optional units (BSP_BULK_AHEAD)
+  double levelCostUs = NAN;       // supernode merges: what one level on the critical path costs (BSP_LEVEL_COST_US); default 28
 
   // the environment on top (A/B scripts); called once per Solver
   void applyEnv();

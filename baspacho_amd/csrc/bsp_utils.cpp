@@ -102,6 +102,7 @@ void HipBackendOptions::applyEnv() {
   num("BSP_EXPECTED_BATCH", expectedBatch, 1);
   real("BSP_LOOKAHEAD_MIN_GF", lookaheadMinGF);
   real("BSP_BULK_AHEAD", bulkAhead);
+  real("BSP_LEVEL_COST_US", levelCostUs);
 }
 
 }  // namespace BaSpaCho

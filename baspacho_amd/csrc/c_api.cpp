@@ -46,7 +46,7 @@ void bsp_hip_options_default(bsp_hip_options* o) {
   o->lookahead = o->due_stream = o->split_k = o->gather_max_pairs = o->gather_overlap = o->sub_batch_min =
       o->sub_batches = o->tail_blocks = o->lazy_plan = o->block_solve = o->solve_inv = o->solve_sweep =
           o->sweep_min_width = o->chain_contraction = o->dense_merge = o->expected_batch = -1;
-  o->lookahead_min_gf = o->bulk_ahead = NAN;
+  o->lookahead_min_gf = o->bulk_ahead = o->level_cost_us = NAN;
 }
 
 int bsp_create_solver_opts(const bsp_settings* st, const bsp_hip_options* ho, int64_t numParams,
@@ -77,6 +77,7 @@ int bsp_create_solver_opts(const bsp_settings* st, const bsp_hip_options* ho, in
     options.expectedBatch = ho->expected_batch;
     options.lookaheadMinGF = ho->lookahead_min_gf;
     options.bulkAhead = ho->bulk_ahead;
+    options.levelCostUs = ho->level_cost_us;
     settings.hipOptions = &options;
   }
   if (st) {

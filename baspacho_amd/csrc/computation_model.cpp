@@ -23,24 +23,28 @@ const ComputationModel ComputationModel::model_Cuda117_2080Ti{
     {1.975089750288875748e-06, -1.339369810950508464e-10, -3.758728373628488434e-10,
      1.745285595679570848e-13}};
 
-// MI355X / level-scheduled HIP backend: the least-squares fit of the per-op samples taken on an
-// MI355X (tools/op_stats_dump.py -> profiles/r02_opstats_*.csv -> tools/fit_computation_model.py ->
-// profiles/r02_model_fit.json, the pipeline of Bench.cpp:72-124 + examples/OptimizeCompModel.cpp:64-275)
-// with every op's CONSTANT term multiplied by kLevelBatchingShare = 0.03: the samples time an op as a
-// launch of its own, while a level of the fused path batches the ops of all its lumps into one
-// launch, so the marginal fixed cost of one more lump is a small share of a kernel boundary and
-// the fill a merge adds is paid in full.  The share was chosen on the device (tools/model_eval.py,
-// profiles/r02_model_eval.txt): 64 x GRID 82x82 12.44 ms at the round-1 hand-set constants, 14.6 /
-// 11.84 / 11.42 / 11.37 at shares 0.3 / 0.1 / 0.03 / 0.01; FLAT-50k 28.5 -> 27.1; BAL-871 unchanged (its
-// camera block is merged by the dense-merge rule of elimination_tree.cpp whatever the model says).
+// MI355X / level-scheduled HIP backend.  Round 6: re-fitted on the round-6 kernels -- the least-squares
+// fit of the per-op samples taken on an MI355X (tools/op_stats_dump.py -> profiles/r06_opstats_*.csv ->
+// tools/fit_computation_model.py -> profiles/r06_model_fit.json, the pipeline of Bench.cpp:72-124 +
+// examples/OptimizeCompModel.cpp:64-275) with every op's CONSTANT term multiplied by the level-batching
+// share 0.03.  What the share means, and why it is not zero: the samples time an op as a launch of
+// its own, while a level of the fused path runs the ops of all its lumps (and of all matrices of a
+// batch) in ONE launch, so the marginal fixed cost of one more lump is a few per cent of a kernel
+// boundary.  profiles/r06_model_batch_sweep.txt is the measurement: plans from "no merge that adds
+// fill" (share 0: 2.45 GF, 42 levels) to "everything the per-op driver would merge" (share 1: 6.5 GF,
+// 51 levels) on GRID 82x82 for batches of 1 / 8 / 64 -- the optimum is flat between shares 0.01 and
+// 0.03 for ALL three batch sizes (within 1 %), an explicit level term (csrc/elimination_tree.cpp) and
+// the expected batch size (HipBackendOptions::expectedBatch) change the partition by 0-2 lumps of
+// 1446, and no plan within +-20 % of the flops is faster: the level count of such a structure is its
+// elimination tree's height in columns / 64, which merging cannot shorten.
 const ComputationModel ComputationModel::model_Hip_MI355X{
     // potrf: a + b n + c n^2 + d n^3
-    {3.618102371671751e-08, 3.804901435864945e-07, 6.981640690980229e-11, 8.536479805489468e-16},
+    {4.842342370685720e-08, 2.543247713289900e-07, 6.834653829137758e-11, 9.975328171884997e-16},
     // trsm: a + b n + c n^2 + (d + e n + f n^2) k
-    {1.709462696726716e-07, 1.114928057617138e-07, 4.611165305099729e-10, 5.116797002889815e-10, 1.341879640359843e-11, 0.000000000000000e+00},
+    {1.645234651723887e-07, 1.095388935580508e-07, 3.684825255567626e-10, 7.028454342479416e-10, 0.000000000000000e+00, 0.000000000000000e+00},
     // syge: a + b u + c v + k (d + e u + f v)
-    {2.083655120359462e-07, 7.425127963497075e-10, 1.910711883161907e-12, 6.123296965670030e-08, 2.127243764724589e-12, 2.085578751310278e-15},
+    {2.091125895395996e-07, 5.866009986064752e-10, 1.749721373224342e-12, 5.301820950214163e-08, 0.000000000000000e+00, 8.030970513286191e-15},
     // asmbl: a + b br + c bc + d br bc
-    {1.819244623955457e-07, 0.000000000000000e+00, 1.854767815091107e-08, 1.095148499821501e-09}};
+    {1.768453072613642e-07, 0.000000000000000e+00, 1.884331035327229e-08, 1.103342015203656e-09}};
 
 }  // namespace BaSpaCho

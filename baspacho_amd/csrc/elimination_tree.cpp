@@ -1,5 +1,7 @@
 #include "elimination_tree.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstdlib>
 #include <cmath>
@@ -149,12 +151,22 @@ void EliminationTree::computeMerges() {
   // update, ~20 us of launches and dependent round trips) per 64-column panel, with nothing else
   // of that subtree to overlap; merging such a pair saves the levels the panel count drops by.
   // Siblings share their levels, so the term is not charged for them.
-  constexpr double kChainLevelCost = 2.0e-5, kPanel = 64.0;
+  const double kChainLevelCost = levelCost;
+  constexpr double kPanel = 64.0;
   vector<int64_t> childCount(n, 0);
   for (int64_t k = 0; k < n; k++) {
     if (parent[k] >= 0) childCount[parent[k]]++;
   }
   auto levelsOf = [&](double size) { return std::ceil(size / kPanel); };
+  // Round 6: the same credit for the child that is its parent's DEEPEST subtree (in panels = levels):
+  // the parent's first panel comes one level after the last panel of that child, whatever the
+  // siblings do, so a merge that drops a panel there drops a level of the whole factor.  Depths are
+  // those of the un-merged tree, refreshed for a parent when a child is merged into it.
+  vector<double> depth(n, 0.0), deepestChild(n, 0.0);  // depth[k]: panels from the leaves up to and incl. k
+  for (int64_t k = 0; k < n; k++) {  // (parents have larger indices)
+    depth[k] = deepestChild[k] + levelsOf(double(nodeSize[k]));
+    if (parent[k] >= 0) deepestChild[parent[k]] = std::max(deepestChild[parent[k]], depth[k]);
+  }
 
   using Cand = std::tuple<double, int64_t, int64_t>;  // (score, child, parent)
   std::priority_queue<Cand> queue;
@@ -165,6 +177,8 @@ void EliminationTree::computeMerges() {
 
   vector<NodeStats> mergedStats;
   const bool denseMergeOn = denseMergeRule;
+  const bool dbg = std::getenv("BSP_MERGE_DEBUG") != nullptr;  // developer aid
+  long dbgCand = 0;
   while (!queue.empty()) {
     Cand top = queue.top();
     queue.pop();
@@ -184,7 +198,7 @@ void EliminationTree::computeMerges() {
     const double tSeparate = nodeTime(k, sk, rk, double(numMergedNodes[k])) +
                              nodeTime(p, sp, rp, double(numMergedNodes[p]));
     double tMerged = nodeTime(p, sp + sk, rp, double(numMergedNodes[k] + numMergedNodes[p]));
-    if (childCount[p] == 1) {
+    if (childCount[p] == 1 || depth[k] >= deepestChild[p]) {
       tMerged -= kChainLevelCost * (levelsOf(sk) + levelsOf(sp) - levelsOf(sk + sp));
     }
     // Extension: a child whose rows are (nearly) all of its parent's column -- the nodes of a dense
@@ -192,8 +206,14 @@ void EliminationTree::computeMerges() {
     // merged lump adds < 10 % of explicit zeros and is one chain of panels with lookahead, the
     // split one pays a lump boundary (BAL-871 with a model of lower fixed costs: 8.5 against 7.7 ms)
     const bool denseMerge = denseMergeOn && score(k, p) >= 0.9;
+    if (dbg) {
+      dbgCand++;
+      if (dbgCand <= 12) fprintf(stderr, "[merge] k %ld (size %g rows %g depth %g) p %ld (size %g rows %g deepest %g children %ld): separate %.3e merged %.3e\n", (long)k, sk, rk, depth[k], (long)p, sp, rp, deepestChild[p], (long)childCount[p], tSeparate, tMerged);
+    }
     if (!(tMerged < tSeparate) && !denseMerge) continue;
     childCount[p] += childCount[k] - 1;
+    deepestChild[p] = std::max(deepestChild[p] == depth[k] ? 0.0 : deepestChild[p], deepestChild[k]);
+    depth[p] = deepestChild[p] + levelsOf(sk + sp);
 
     const int64_t oldSizeP = nodeSize[p], oldMergedP = numMergedNodes[p];
     mergeWith[k] = p;
@@ -244,6 +264,7 @@ void EliminationTree::computeMerges() {
 }
 
 void EliminationTree::collapseMergePointers() {
+  if (std::getenv("BSP_MERGE_DEBUG")) fprintf(stderr, "[merge] %ld merges of %ld nodes\n", (long)numMerges, (long)ss.order());
   // parents have larger indices, so a descending sweep sees final roots first
   for (int64_t k = ss.order() - 1; k >= 0; k--) {
     int64_t p = mergeWith[k];

@@ -36,7 +36,8 @@ struct EliminationTree {
 
   // inputs
   bool denseMergeRule = true;  // HipBackendOptions::denseMerge ("rows >= 90 % of the parent" merges)
-  int expectedBatch = 1;       // matrices per factor() the merge model plans for (computeMerges)
+  int expectedBatch = 1;       // matrices per factor() call (createSolver scales the model's throughput terms by it)
+  double levelCost = 2.8e-5;   // seconds one level on the critical path costs (HipBackendOptions::levelCostUs)
   std::vector<int64_t> paramSize;
   const SparseStructure& ss;  // csr, lower half, already fill-reducing ordered
   const ComputationModel& compMod;

@@ -5,6 +5,7 @@
 // bypassed and the whole range is handed to NumericCtx::factorRange / SolveCtx::solve*Range.
 #include "solver.h"
 
+#include <cmath>
 #include <algorithm>
 #include <iostream>
 #include <numeric>
@@ -569,12 +570,28 @@ SolverPtr createSolver(const Settings& settings, const vector<int64_t>& paramSiz
   vector<int64_t> sortedBottomSize(nBottom);
   for (int64_t i = 0; i < nBottom; i++) sortedBottomSize[invPerm[i]] = paramSize[givenElimEnd + i];
 
-  const ComputationModel* model =
-      settings.computationModel ? settings.computationModel : &ComputationModel::model_Hip_MI355X;
+  // EXPLICIT merge model of the level-scheduled backend (round 6): time = levels on the critical path x
+  // levelCost + batch x (throughput terms of the ops).  A level runs the ops of all its lumps -- and of
+  // all matrices of a batch -- in one launch, so an op's own fixed cost is not paid per lump (the
+  // built-in model carries none) and what a merge adds in fill is paid once per matrix of the batch,
+  // while the levels it saves (elimination_tree.cpp, computeMerges) are saved once per CALL: a batch of
+  // 64 wants fewer merges than a single matrix.  expectedBatch scales every coefficient; a caller's own
+  // model is taken as it is (its constants included) and scaled the same way.
+  ComputationModel adjusted =
+      settings.computationModel ? *settings.computationModel : ComputationModel::model_Hip_MI355X;
+  {
+    const double bs = double(std::max(1, options.expectedBatch));
+    for (double& v : adjusted.potrfParams) v *= bs;
+    for (double& v : adjusted.trsmParams) v *= bs;
+    for (double& v : adjusted.sygeParams) v *= bs;
+    for (double& v : adjusted.asmblParams) v *= bs;
+  }
+  const ComputationModel* model = &adjusted;
 
   EliminationTree et(sortedBottomSize, sortedBottom, model);
   et.denseMergeRule = HipBackendOptions::on(options.denseMerge, true);
   et.expectedBatch = std::max(1, options.expectedBatch);
+  if (!std::isnan(options.levelCostUs)) et.levelCost = 1e-6 * options.levelCostUs;
   et.buildTree();
   lap("etree build");
   et.processTree(settings.findSparseEliminationRanges, noCrossPoints,

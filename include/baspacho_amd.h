@@ -70,6 +70,7 @@ typedef struct bsp_hip_options {
   int32_t expected_batch;    /* matrices per factor() call the supernode-merge model plans for (default 1) */
   double lookahead_min_gf;   /* GF per fork below which lookahead units stay in line */
   double bulk_ahead;         /* share of the next block's chain handed out as optional lookahead units */
+  double level_cost_us;      /* supernode merges: cost of one level on the critical path (default 28 us) */
 } bsp_hip_options;
 void bsp_hip_options_default(bsp_hip_options* out);
 
