@@ -202,7 +202,12 @@ __global__ __launch_bounds__(256) void elimFactorSmall(SkelDev sk, DataRef<T> dr
 // lumps of width <= 4 (the 3-wide point columns of bundle adjustment) are driven by ElimLumpDesc: one
 // descriptor load, the n x n Cholesky redundantly in every lane's registers (hardware rsq + Newton,
 // no wave synchronisation, no division), kTinyPerWave lumps per wave.
-constexpr int kTinyPerWave = 4;
+#ifndef BSP_TINY_PER_WAVE
+#define BSP_TINY_PER_WAVE 4
+#endif
+// (round 6, BAL-871: 8 per wave in two passes of four, twice the bytes in flight per wave: 0.393 against
+//  0.301-0.309 ms; profiles/r06_ab_elim_factor_tiny.txt)
+constexpr int kTinyPerWave = BSP_TINY_PER_WAVE;
 // K1s  the eliminated columns STAGED through LDS.  A wave's four lumps are neighbours in
 // memory (an elimination range is laid out lump after lump, each column one dense (n + rows) x n
 // block), so the wave reads its whole stretch -- typically ~600 values -- with fully coalesced
@@ -276,51 +281,67 @@ __device__ __forceinline__ void tinyLumpBody(P D, int n, int rowsBelow, int sub)
   }
 }
 
+// Round 6: kTinyPerWave lumps per wave in PASSES of four (16 lanes per lump), every load of the whole
+// stretch issued before the first LDS store, and the copy loops bounded by the stretch's own length
+// (uniform) instead of 20 predicated iterations -- a predicated load is a branch around it.
 template <typename T>
 __global__ __launch_bounds__(256) void elimFactorTinyStaged(const ElimLumpDesc* descs,
                                                             DataRef<T> dref, int numLumps) {
   __shared__ T scratch[4][kStagedCap];
+  constexpr int PASSES = kTinyPerWave / 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, sub = lane & 15, q = lane >> 4;
   const int first = (blockIdx.x * 4 + wave) * kTinyPerWave;
   if (first >= numLumps) return;
   const int last = min(first + kTinyPerWave - 1, numLumps - 1);
-  const bool live = first + q <= last;
-  const ElimLumpDesc ld = descs[live ? first + q : last];
+  ElimLumpDesc ld[PASSES];
+  bool live[PASSES];
+  bool narrow = true;
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ps++) {
+    live[ps] = first + 4 * ps + q <= last;
+    ld[ps] = descs[live[ps] ? first + 4 * ps + q : last];
+    narrow = narrow && ld[ps].n <= 4;
+  }
   const ElimLumpDesc ld0 = descs[first], ldL = descs[last];  // (wave-uniform)
   const int64_t start = ld0.diagOff;
   const int64_t len = ldL.diagOff + (int64_t)ldL.n * (ldL.n + ldL.rowsBelow) - start;
   GP<T> data = pickData(dref);
-  if (ld.n > 4) return;  // (the caller checks the range's maximum width)
+  if (!narrow) return;  // (the caller checks the range's maximum width)
   // the lumps of a range follow one another in memory; anything else takes the direct path
   if (len <= 0 || len > kStagedCap) {
-    if (live) tinyLumpBody<T>(data + ld.diagOff, ld.n, ld.rowsBelow, sub);
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ps++) {
+      if (live[ps]) tinyLumpBody<T>(data + ld[ps].diagOff, ld[ps].n, ld[ps].rowsBelow, sub);
+    }
     return;
   }
   // (Round 4: 16 bytes per lane in and out -- half the wave loads and stores; the stretch starts at
   //  an 8-byte boundary, which global accesses tolerate -- measured SLOWER: 0.364 against 0.335 ms.)
   constexpr int IT = kStagedCap / 64;
   const int E = (int)len;
+  const int nIt = __builtin_amdgcn_readfirstlane((E + 63) >> 6);
   GP<T> D0 = data + start;
   LP<T> sc = (LP<T>)scratch[wave];
   T v[IT];
 #pragma unroll
   for (int it = 0; it < IT; it++) {
-    const int e = it * 64 + lane;
-    v[it] = e < E ? D0[e] : T(0);
+    if (it < nIt) v[it] = D0[min(it * 64 + lane, E - 1)];
   }
 #pragma unroll
   for (int it = 0; it < IT; it++) {
-    const int e = it * 64 + lane;
-    if (e < E) sc[e] = v[it];
+    if (it < nIt) sc[it * 64 + lane] = v[it];  // (values beyond E: copies of the last one, never stored back)
   }
   waveSync();
-  if (live) tinyLumpBody<T>(sc + (int)(ld.diagOff - start), ld.n, ld.rowsBelow, sub);
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ps++) {
+    if (live[ps]) tinyLumpBody<T>(sc + (int)(ld[ps].diagOff - start), ld[ps].n, ld[ps].rowsBelow, sub);
+  }
   waveSync();
 #pragma unroll
   for (int it = 0; it < IT; it++) {
     const int e = it * 64 + lane;
-    if (e < E) D0[e] = sc[e];
+    if (it < nIt && e < E) D0[e] = sc[e];
   }
 }
 
