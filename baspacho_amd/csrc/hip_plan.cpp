@@ -376,7 +376,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     {
       const int64_t numBlocks = (n + kOuterWidth - 1) / kOuterWidth;
       if (opts.tailBlocks > 0 && g.rowsBelow == 0 && numBlocks >= opts.tailMinBlocks) {
-        tailFrom = kOuterWidth * std::max<int64_t>(1, numBlocks - opts.tailBlocks);
+        // (at most 32 blocks = 128 panels: tile (q, q-2) waits for a word of spine q, whose ticket is one
+        //  column group -- at most 128 roles -- later; the 512 roles the GPU holds always include it)
+        tailFrom = kOuterWidth * std::max<int64_t>(1, numBlocks - std::min(opts.tailBlocks, 32));
       }
     }
     for (int64_t blockStart = 0; blockStart < n; blockStart += kOuterWidth) {

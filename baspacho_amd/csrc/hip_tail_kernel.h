@@ -26,7 +26,10 @@
 // repeat the solve and STORE the result in place for everybody else.
 // Roles are dealt by ticket in an order in which a role only waits for smaller tickets (spine 0; then
 // per column j: spine j+1, tiles (j+2.., j)), so the launch cannot deadlock whether or not all of it
-// is resident; a role that starts late replays the finished panels at L2 speed.  Flags: release
+// is resident (one exception, bounded: the tile roles (q, q-1) and (q, q-2) also wait for spine q's word
+// that it has taken its copy of the unsolved tile, and spine q sits at most one column group later in
+// the order -- the plan caps a tail at 128 panels, far inside the 512 roles the GPU holds at once);
+// a role that starts late replays the finished panels at L2 speed.  Flags: release
 // (agent) after the stores, relaxed polls, one acquire fence per wait (tools/flag_hop_probe.hip: 2.05
 // us per hop with a 32-KB tile read and written).  Every spin is bounded by the watchdog of the
 // persistent sweeps (SweepWatch): on expiry the launch aborts and the host retires the kernel.
