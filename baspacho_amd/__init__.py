@@ -42,7 +42,7 @@ class _CSettings(ctypes.Structure):
 
 _HIP_OPTION_INTS = ["lookahead", "due_stream", "split_k", "gather_max_pairs", "gather_overlap",
                     "sub_batch_min", "sub_batches", "tail_blocks", "lazy_plan", "block_solve", "solve_inv",
-                    "solve_sweep", "sweep_min_width", "chain_contraction", "dense_merge", "expected_batch"]
+                    "solve_sweep", "sweep_min_width", "solve_wide", "chain_contraction", "dense_merge", "expected_batch"]
 _HIP_OPTION_REALS = ["lookahead_min_gf", "bulk_ahead", "level_cost_us"]
 
 
@@ -69,7 +69,8 @@ class _CRunCounters(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
                 ["sweep_launches", "sweep_timeouts", "split_lists_used", "sub_batches_enqueued",
                  "lookahead_forks", "sweeps_retired", "sweep_error_pending",
-                 "gather_chunks_overlapped", "tail_launches", "sweep_mfma_launches"]]
+                 "gather_chunks_overlapped", "tail_launches", "sweep_mfma_launches",
+                 "solve_wide_launches", "inv_reused"]]
 
 
 @dataclass

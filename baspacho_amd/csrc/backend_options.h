@@ -26,6 +26,7 @@ struct HipBackendOptions {
   int32_t solveInv = -1;          // 0: substitution instead of inverted diagonal blocks (BSP_SOLVE_INV)
   int32_t solveSweep = -1;        // 0: no persistent sweeps (BSP_SOLVE_SWEEP)
   int32_t sweepMinWidth = -1;     // narrowest run a sweep takes (BSP_SWEEP_MIN_WIDTH)
+  int32_t solveWide = -1;         // 0: no right-hand-sides-across-the-lanes backward elimination pass (BSP_SOLVE_WIDE)
   // symbolic analysis
   int32_t chainContraction = -1;  // 0: no contraction of pivot chains before the ordering (BSP_CHAIN_CONTRACTION)
   int32_t denseMerge = -1;        // 0: no "rows >= 90 % of the parent" merge rule (BSP_DENSE_MERGE_OFF=1)

@@ -97,6 +97,7 @@ void HipBackendOptions::applyEnv() {
   flag("BSP_SOLVE_INV", solveInv);
   flag("BSP_SOLVE_SWEEP", solveSweep);
   num("BSP_SWEEP_MIN_WIDTH", sweepMinWidth, 1);
+  flag("BSP_SOLVE_WIDE", solveWide);
   flag("BSP_CHAIN_CONTRACTION", chainContraction);
   if (std::getenv("BSP_DENSE_MERGE_OFF")) denseMerge = 0;
   num("BSP_EXPECTED_BATCH", expectedBatch, 1);

@@ -45,7 +45,7 @@ const char* bsp_version(void) { return "baspacho_amd 0.1 (gfx950)"; }
 void bsp_hip_options_default(bsp_hip_options* o) {
   o->lookahead = o->due_stream = o->split_k = o->gather_max_pairs = o->gather_overlap = o->sub_batch_min =
       o->sub_batches = o->tail_blocks = o->lazy_plan = o->block_solve = o->solve_inv = o->solve_sweep =
-          o->sweep_min_width = o->chain_contraction = o->dense_merge = o->expected_batch = -1;
+          o->sweep_min_width = o->solve_wide = o->chain_contraction = o->dense_merge = o->expected_batch = -1;
   o->lookahead_min_gf = o->bulk_ahead = o->level_cost_us = NAN;
 }
 
@@ -72,6 +72,7 @@ int bsp_create_solver_opts(const bsp_settings* st, const bsp_hip_options* ho, in
     options.solveInv = ho->solve_inv;
     options.solveSweep = ho->solve_sweep;
     options.sweepMinWidth = ho->sweep_min_width;
+    options.solveWide = ho->solve_wide;
     options.chainContraction = ho->chain_contraction;
     options.denseMerge = ho->dense_merge;
     options.expectedBatch = ho->expected_batch;
@@ -654,6 +655,8 @@ int bsp_run_counters_get(bsp_solver* s, bsp_run_counters* out) {
   out->gather_chunks_overlapped = c.gatherChunksOverlapped;
   out->tail_launches = c.tailLaunches;
   out->sweep_mfma_launches = c.sweepMfmaLaunches;
+  out->solve_wide_launches = c.solveWideLaunches;
+  out->inv_reused = c.invReused;
   BSP_CATCH
 }
 

@@ -16,6 +16,7 @@
 #include "hip_kernels.h"
 #include "hip_solve_kernels.h"
 #include "hip_sweep_kernels.h"
+#include "hip_solve_wide.h"
 #include "hip_sweep_mfma.h"
 #include "hip_tail_kernel.h"
 #include "mat_ops.h"
@@ -433,6 +434,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (o.subBatches >= 0) subBatchParts = std::max(2, o.subBatches);
     splitK = HipBackendOptions::on(o.splitK, true);
     sweepEnabled = HipBackendOptions::on(o.solveSweep, true);
+    solveWide = HipBackendOptions::on(o.solveWide, true);
     gatherOverlap = HipBackendOptions::on(o.gatherOverlap, false);
     if (o.sweepMinWidth >= 0) sweepMinWidth = std::max(1, o.sweepMinWidth);
     lazyPlan = HipBackendOptions::on(o.lazyPlan, false);
@@ -450,6 +452,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_GATHER_OVERLAP_LDS")) gatherOverlapLds = (unsigned)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BSP_SWEEP_TRACE")) sweepTraceOn = e[0] != '0';
     if (const char* e = std::getenv("BSP_SWEEP_MFMA_MIN")) sweepMfmaMinRhs = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("BSP_SOLVE_WIDE_MIN")) solveWideMinRhs = std::max(2, std::atoi(e));
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -713,6 +716,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   // block solves through inverted diagonal blocks (denseLevels): the inverses of one solve call, and
   // per level list the panels whose diagonal blocks are inverted (uploaded once)
   DevBuf solveInvScratch;
+  uint64_t solveInvGen = 0;  // bumped by every launch that writes solveInvScratch
   bool solveInv = true;  // BSP_SOLVE_INV=0: the substitution kernels of rounds 1-2
   // ---- persistent sweeps over wide lumps (hip_sweep_kernels.h, round 6)
   bool sweepEnabled = true;   // BSP_SOLVE_SWEEP=0: the multi-launch block path
@@ -723,6 +727,10 @@ struct HipSymbolicCtx : SymbolicCtx {
   double sweepSpinLimitS = 2.0;  // watchdog: a spin that lasts longer aborts the launch
   int tailFlags = 1;          // TailDesc::flags (BSP_TAIL_FLAGS)
   DevBuf tailCtl, tailDinv;   // persistent tail (hip_tail_kernel.h): control words, inverted diagonal blocks
+  bool solveWide = true;      // backward elimination pass with the right-hand sides across the lanes (hip_solve_wide.h)
+  int solveWideMinRhs = 2;    // (developer: BSP_SOLVE_WIDE_MIN)
+  size_t solveWideMaxBytes = (size_t)1 << 30;
+  DevBuf solveWideBuf;        // [row][16] copy of the rows below an elimination range (hip_solve_wide.h)
   DevBuf sweepXchg;           // control words + exchange values of one denseLevels call
   DevBuf sweepTrace;          // developer aid (BSP_SWEEP_TRACE=1): clock stamps of the spines of the last sweep
   bool sweepTraceOn = false;
@@ -733,7 +741,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   int sweepAttr[2] = {0, 0};  // per value size (8, 4): 0 not tried, 1 ready, -1 failed
   struct RunCounters {
     int64_t sweepLaunches = 0, sweepTimeouts = 0, splitListsUsed = 0, subBatchesEnqueued = 0,
-            lookaheadForks = 0, gatherChunksOverlapped = 0, tailLaunches = 0, sweepMfmaLaunches = 0;
+            lookaheadForks = 0, gatherChunksOverlapped = 0, tailLaunches = 0, sweepMfmaLaunches = 0, invReused = 0, solveWideLaunches = 0;
   } counters;
   // a timed-out persistent launch (solve sweep, factor tail) is reported ONCE, by the next factor()
   // or solve() on this Solver; the persistent kernels are then retired for good
@@ -1612,10 +1620,38 @@ struct HipSolveCtx : SolveCtx<T> {
                    256, 0, sym.stream>>>(plan.solveLumpDescs.as<SolveLumpDesc>() + d0,
                                          plan.solveLumpBlocks.as<SolveLumpBlock>(), ref, (int)nLumps, nRHS);
           };
+          const auto wide = plan.solveGather.rangeWide[&er - plan.host.elimRanges.data()];
+          const int64_t wideRows = sym.skel.order() - wide.rowBelow;
+          const int64_t wideSpans = (int64_t)sym.skel.spanStart.size() - 1 - wide.spanBelow;
+          const unsigned wideGroups = (unsigned)((nRHS + hipk::kWideRhs - 1) / hipk::kWideRhs);
+          const size_t wideBytes = (size_t)hipk::wideGroupStride(wideRows) * wideGroups * (size_t)batch * sizeof(BT);
           if (nRHS == 1) {
             hipk::solveElimLumpsLt<BT><<<grid((unsigned)((nLumps + 15) / 16)), 256, 0, sym.stream>>>(
                 plan.solveLumpDescs.as<SolveLumpDesc>() + d0, plan.solveLumpBlocks.as<SolveLumpBlock>(),
                 ref, (int)nLumps);
+          } else if (sym.solveWide && wide.n >= 1 && nRHS >= sym.solveWideMinRhs &&
+                     wideBytes <= sym.solveWideMaxBytes) {
+            // right-hand sides across the lanes (hip_solve_wide.h): the rows below the range, final by
+            // now, go span by span into [16][rows] blocks first
+            sym.solveWideBuf.resize(wideBytes);
+            BT* yW = const_cast<BT*>(sym.solveWideBuf.as<BT>());
+            if (wideSpans > 0) {
+              hipk::solveRowsToWide<BT><<<dim3((unsigned)((wideSpans + 3) / 4), wideGroups, (unsigned)batch),
+                                          256, 0, sym.stream>>>(ref, nRHS, sk.spanStart, wide.spanBelow,
+                                                                wideSpans, wide.rowBelow, wideRows, yW);
+            }
+            auto launchW = [&](auto kern) {
+              kern<<<dim3((unsigned)((nLumps + 15) / 16), wideGroups, (unsigned)batch), 256, 0, sym.stream>>>(
+                  plan.solveLumpDescs.as<SolveLumpDesc>() + d0, plan.solveLumpBlocks.as<SolveLumpBlock>(),
+                  ref, (int)nLumps, nRHS, yW, wide.rowBelow, wideRows);
+            };
+            switch (wide.n) {
+              case 1: launchW(hipk::solveElimLumpsLtWide<BT, 1>); break;
+              case 2: launchW(hipk::solveElimLumpsLtWide<BT, 2>); break;
+              case 3: launchW(hipk::solveElimLumpsLtWide<BT, 3>); break;
+              default: launchW(hipk::solveElimLumpsLtWide<BT, 4>); break;
+            }
+            sym.counters.solveWideLaunches++;
           } else if (nRHS <= 2) {
             launch(hipk::solveElimLumpsLtMulti<BT, 2>, 2);
           } else if (nRHS <= 4) {
@@ -1814,8 +1850,18 @@ struct HipSolveCtx : SolveCtx<T> {
           sh.trace = reinterpret_cast<long long*>(sym.sweepTrace.ptr);
         }
       }
-      hipk::solveInvertPanels<BT><<<dim3((unsigned)ent.count, 1, (unsigned)batch), 64, 0, sym.stream>>>(
-          ent.list.as<PanelDesc>(), scratch, invBatchStride, ref, arm, armWords);
+      // (solve() = solveL then solveLt through ONE context, on the same factor: the backward pass finds
+      //  the inverses its forward pass left in the scratch -- nothing else has written it in between --
+      //  and only arms the exchange buffer)
+      if (invCacheList == &ent && invCacheGen == sym.solveInvGen && invCacheGen != 0) {
+        if (arm) hipCHECK(hipMemsetAsync(arm, 0xff, (size_t)armWords * 8, sym.stream));
+        sym.counters.invReused++;
+      } else {
+        hipk::solveInvertPanels<BT><<<dim3((unsigned)ent.count, 1, (unsigned)batch), 64, 0, sym.stream>>>(
+            ent.list.as<PanelDesc>(), scratch, invBatchStride, ref, arm, armWords);
+        invCacheList = &ent;
+        invCacheGen = ++sym.solveInvGen;
+      }
       invBase = scratch;
     }
     int32_t sweepOrd = 0;
@@ -2110,6 +2156,8 @@ struct HipSolveCtx : SolveCtx<T> {
 
   HipSymbolicCtx& sym;
   int nRHS, batch;
+  const SolveInvList* invCacheList = nullptr;  // inverses this context computed last (denseLevels)
+  uint64_t invCacheGen = 0;
   DevBuf tmp;
   vector<std::unique_ptr<DevPlan>> opPlans;
 };
@@ -2279,6 +2327,8 @@ HipRunCounters hipBackendRunCounters(SymbolicCtx& sym) {
   c.gatherChunksOverlapped = h->counters.gatherChunksOverlapped;
   c.tailLaunches = h->counters.tailLaunches;
   c.sweepMfmaLaunches = h->counters.sweepMfmaLaunches;
+  c.solveWideLaunches = h->counters.solveWideLaunches;
+  c.invReused = h->counters.invReused;
   c.sweepsRetired = h->sweepBroken ? 1 : 0;
   c.sweepErrorPending = (h->sweepHostErr && *reinterpret_cast<volatile unsigned*>(h->sweepHostErr)) ? 1 : 0;
   return c;

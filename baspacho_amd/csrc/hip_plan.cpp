@@ -335,6 +335,7 @@ void HipPlanOptions::applyDeveloperEnv() {
   planTiming = std::getenv("BSP_TIMING") != nullptr;
   if (const char* e = std::getenv("BSP_GATHER_OVERLAP_FIRST")) overlapFirst = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BSP_GATHER_OVERLAP_STEP")) overlapStep = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("BSP_SOLVE_SORT_WINDOW")) solveSortWindow = std::max(1, std::atoi(e));
 }
 
 HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_t>& elimRangesIn,
@@ -1032,8 +1033,10 @@ SolveGatherPlan buildSolveGather(const CoalescedBlockMatrixSkel& sk, const HipPl
     out.rangeItems.emplace_back(itemBegin, (int64_t)out.items.size());
     // lump-major lists for the backward pass
     out.rangeLumpDesc.push_back((int64_t)out.lumpDescs.size());
+    int64_t commonN = -1, spanBelow = nSpans;
     for (int64_t l = er.lumpBegin; l < er.lumpEnd; l++) {
       const int64_t n = sk.lumpStart[l + 1] - sk.lumpStart[l];
+      commonN = (commonN < 0 || commonN == n) ? n : 0;
       const int64_t c0 = sk.chainColPtr[l], cEnd = sk.chainColPtr[l + 1];
       const int64_t diagCh = sk.boardChainColOrd[sk.boardColPtr[l] + 1];
       SolveLumpDesc d{};
@@ -1044,12 +1047,33 @@ SolveGatherPlan buildSolveGather(const CoalescedBlockMatrixSkel& sk, const HipPl
           const int64_t span = sk.chainRowSpan[c];
           out.lumpBlocks.push_back({sk.chainData[c], (int32_t)sk.spanStart[span],
                                     (int32_t)(sk.spanStart[span + 1] - sk.spanStart[span])});
+          spanBelow = std::min(spanBelow, span);
         }
       }
       d.blockEnd = (int32_t)out.lumpBlocks.size();
       d.xOff = (int32_t)sk.lumpStart[l];
       d.n = (int32_t)n;
       out.lumpDescs.push_back(d);
+    }
+    out.rangeWide.push_back({(int32_t)(commonN >= 1 && commonN <= 4 ? commonN : 0), spanBelow,
+                             sk.spanStart[spanBelow]});
+    {
+      // The backward kernels give a lump 16 lanes and a wave four lumps: a wave runs as long as its
+      // longest lump, and track lengths have a heavy tail (BAL-871: mean 5.6 blocks, 6 % of the points
+      // beyond 20; PMC: twice the wave loads the blocks need).  Nothing depends on the order of the
+      // descriptors, so the 16 lumps of a workgroup are sorted by block count: its waves get lumps of
+      // similar length, the workgroup still reads one contiguous piece of L.
+      // (tried: windows of 1024 lumps -- solveLt 0.56 -> 0.73 ms with one right-hand side, 1.49 -> 2.21
+      //  with ten: the lumps of a wave then sit 100 KB apart and share neither lines nor rows)
+      const int64_t kWindow = plan.opts.solveSortWindow;
+      auto first = out.lumpDescs.begin() + out.rangeLumpDesc.back();
+      const int64_t cnt = out.lumpDescs.end() - first;
+      for (int64_t w0 = 0; kWindow > 1 && w0 < cnt; w0 += kWindow) {
+        std::stable_sort(first + w0, first + std::min(cnt, w0 + kWindow),
+                         [](const SolveLumpDesc& a, const SolveLumpDesc& b) {
+                           return a.blockEnd - a.blockBegin > b.blockEnd - b.blockBegin;
+                         });
+      }
     }
     BASPACHO_CHECK_LT((int64_t)out.lumpBlocks.size(), (int64_t)1 << 31);
   }

@@ -246,6 +246,7 @@ struct HipPlanOptions {
   // (BSP_TAIL_BLOCKS; 0: the level schedule to the end)
   int32_t tailBlocks = 6;
   int32_t tailMinBlocks = 6;
+  int32_t solveSortWindow = 16;  // lumps per sorting window of the backward elimination lists (= a workgroup; developer: BSP_SOLVE_SORT_WINDOW)
   void applyDeveloperEnv();  // BSP_TIMING, chunk sizes of the gather-overlap experiment
 };
 
@@ -351,6 +352,13 @@ struct SolveGatherPlan {
   std::vector<SolveLumpBlock> lumpBlocks;
   std::vector<SolveLumpDesc> lumpDescs;                  // one per lump of every range, in order
   std::vector<int64_t> rangeLumpDesc;                    // first SolveLumpDesc of every range
+  // per range: the common width of its lumps (0: mixed, or wider than 4) and the first span any of their
+  // blocks reaches (= from where K-S3t of hip_solve_wide.h copies; the number of spans if there is none)
+  struct RangeWide {
+    int32_t n;
+    int64_t spanBelow, rowBelow;
+  };
+  std::vector<RangeWide> rangeWide;
 };
 SolveGatherPlan buildSolveGather(const CoalescedBlockMatrixSkel& skel, const HipPlanHost& plan);
 

@@ -65,6 +65,7 @@ typedef struct bsp_hip_options {
   int32_t solve_inv;         /* 0: substitution instead of inverted diagonal blocks */
   int32_t solve_sweep;       /* 0: no persistent solve sweeps */
   int32_t sweep_min_width;   /* narrowest run of columns a sweep takes */
+  int32_t solve_wide;        /* 0: no right-hand-sides-across-the-lanes backward elimination pass */
   int32_t chain_contraction; /* 0: no contraction of pivot chains before the ordering */
   int32_t dense_merge;       /* 0: no "rows >= 90 % of the parent's column" merge rule */
   int32_t expected_batch;    /* matrices per factor() call the supernode-merge model plans for (default 1) */
@@ -321,6 +322,8 @@ typedef struct bsp_run_counters {
   int64_t gather_chunks_overlapped; /* sparse-elimination gather chunks launched beside the dense chain */
   int64_t tail_launches;        /* persistent tail launches (csrc/hip_tail_kernel.h) */
   int64_t sweep_mfma_launches;  /* ... of sweep_launches: the matrix-core form (several right-hand sides) */
+  int64_t solve_wide_launches;  /* backward elimination passes with the right-hand sides across the lanes */
+  int64_t inv_reused;           /* backward passes that found the inverted diagonal blocks of their forward pass */
 } bsp_run_counters;
 int bsp_run_counters_get(bsp_solver* s, bsp_run_counters* out);
 
