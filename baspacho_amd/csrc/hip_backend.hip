@@ -626,13 +626,17 @@ struct HipSymbolicCtx : SymbolicCtx {
   }
 
   // plan of a fused factor over lumps [startLump, upToLump), built and uploaded on first use
+  // tag 0: factor() / solve(); tag 1: one elimination range; tag 2: factor() of a BATCH when plan 0 gave a
+  // narrow root lump a persistent tail (HipPlanOptions::tailNarrowMin) -- the same plan without it
   DevPlan& planFor(const vector<int64_t>& ranges, int64_t startLump, int64_t upToLump, int tag) {
     checkDevice();
     auto key = std::make_tuple(tag, startLump, upToLump);
     auto it = plans.find(key);
     if (it == plans.end()) {
       std::unique_ptr<DevPlan> p(new DevPlan);
-      p->host = buildHipPlan(skel, ranges, startLump, upToLump, planOpts);
+      HipPlanOptions po = planOpts;
+      if (tag == 2) po.tailNarrowMin = 0;
+      p->host = buildHipPlan(skel, ranges, startLump, upToLump, po);
       p->upload();
       it = plans.emplace(key, std::move(p)).first;
     }
@@ -1378,7 +1382,11 @@ struct HipNumericCtx : NumericCtx<T> {
   //  graph back as the same packets on the same queues -- and removed in round 4)
   virtual void factorRange(T* data, int64_t startLump, int64_t upToLump) override {
     sym.checkAsyncError();
-    DevPlan& plan = sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
+    DevPlan* planPtr = &sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
+    if (batchSize > 1 && planPtr->host.narrowTail) {
+      planPtr = &sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/2);
+    }
+    DevPlan& plan = *planPtr;
     hipk::DataRef<BT> ref = makeRef(data);
     LaunchTimer timer(sym.stream, sym.profile);
     enqueueFactor(plan, ref, timer);

@@ -336,6 +336,8 @@ void HipPlanOptions::applyDeveloperEnv() {
   if (const char* e = std::getenv("BSP_GATHER_OVERLAP_FIRST")) overlapFirst = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BSP_GATHER_OVERLAP_STEP")) overlapStep = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BSP_SOLVE_SORT_WINDOW")) solveSortWindow = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("BSP_TAIL_MIN_BLOCKS")) tailMinBlocks = std::max(2, std::atoi(e));
+  if (const char* e = std::getenv("BSP_TAIL_NARROW_MIN")) tailNarrowMin = std::max(0, std::atoi(e));
 }
 
 HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_t>& elimRangesIn,
@@ -365,23 +367,39 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
   // Segments of a panel: the remaining columns of its outer block (source = the panel, K = nb);
   // the last panel of an outer block also carries the segments of the block-wide source
   // (K = block width): rest of the lump and, if requested, every board of the lump column.
+  // first column of a lump's persistent tail (-1: none): the last tailBlocks outer blocks of a lump with
+  // nothing below it that is at least tailMinBlocks blocks wide; of a NARROW one (tailNarrowMin), all but
+  // the first block
+  auto tailFromOf = [&](int64_t n, int64_t rowsBelow) -> int64_t {
+    const int64_t numBlocks = (n + kOuterWidth - 1) / kOuterWidth;
+    if (opts.tailBlocks <= 0 || rowsBelow != 0) return -1;
+    if (numBlocks >= opts.tailMinBlocks) {
+      // (at most 32 blocks = 128 panels: tile (q, q-2) waits for a word of spine q, whose ticket is one
+      //  column group -- at most 128 roles -- later; the 512 roles the GPU holds always include it)
+      return kOuterWidth * std::max<int64_t>(1, numBlocks - std::min(opts.tailBlocks, 32));
+    }
+    if (opts.tailNarrowMin >= 2 && numBlocks >= opts.tailNarrowMin && n - kOuterWidth > 5 * kPanelWidth) {
+      return kOuterWidth;  // (at least six panels of tail; one matrix only, see hip_plan.h)
+    }
+    return -1;
+  };
+  auto panelsOf = [](int64_t n) -> int32_t {
+    int32_t c = 0;
+    for (int64_t b = 0; b < n; b += kOuterWidth) {
+      c += (int32_t)((std::min<int64_t>(n, b + kOuterWidth) - b + kPanelWidth - 1) / kPanelWidth);
+    }
+    return c;
+  };
   auto addPanels = [&](int64_t l, const LumpCols& g, int32_t lumpRowBase, bool withBoards,
-                       const vector<SegDesc>& boardSegTemplates) {
+                       const vector<SegDesc>& boardSegTemplates, bool tailAllowed) {
     int32_t count = 0;
     const int64_t n = g.width;
     vector<int64_t> pendingFrom;  // per column block of this lump (lookahead schedule, see below)
     // PERSISTENT TAIL: columns from tailFrom on belong to one launch of hip_tail_kernel.h -- their
     // panels exist (the solves walk them) but carry no segments, and the block before them hands ALL
     // its pending lookahead units over at once
-    int64_t tailFrom = -1;
-    {
-      const int64_t numBlocks = (n + kOuterWidth - 1) / kOuterWidth;
-      if (opts.tailBlocks > 0 && g.rowsBelow == 0 && numBlocks >= opts.tailMinBlocks) {
-        // (at most 32 blocks = 128 panels: tile (q, q-2) waits for a word of spine q, whose ticket is one
-        //  column group -- at most 128 roles -- later; the 512 roles the GPU holds always include it)
-        tailFrom = kOuterWidth * std::max<int64_t>(1, numBlocks - std::min(opts.tailBlocks, 32));
-      }
-    }
+    const int64_t tailFrom = tailAllowed ? tailFromOf(n, g.rowsBelow) : -1;
+    if (tailFrom >= 0 && (n + kOuterWidth - 1) / kOuterWidth < opts.tailMinBlocks) plan.narrowTail = true;
     for (int64_t blockStart = 0; blockStart < n; blockStart += kOuterWidth) {
       const int64_t blockEnd = std::min<int64_t>(n, blockStart + kOuterWidth);
       for (int64_t c0 = blockStart; c0 < blockEnd; c0 += kPanelWidth, count++) {
@@ -591,7 +609,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         const int32_t first = (int32_t)plan.panels.size();
         const int32_t rowBase = (int32_t)plan.rowChain.size();
         appendLumpRows(l, g);
-        int32_t n = addPanels(l, g, rowBase, /*withBoards=*/false, {});
+        int32_t n = addPanels(l, g, rowBase, /*withBoards=*/false, {}, /*tailAllowed=*/false);
         for (int32_t j = 0; j < n; j++) bucketAt(big, j).push_back({first + j, j});
       }
     }
@@ -607,6 +625,36 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
   // ---- dense lumps
   const int64_t denseBegin = std::max(startLump, denseFrom);
   vector<int32_t> lastLevelOfLump(nLumps, -1);
+  // A tail level is ONE launch that factors nothing but the tail (emitLevels): a lump may only hand
+  // columns to the tail if each of those panels is ALONE in its level.  Forests with several wide roots
+  // and deep side branches (MERI, block-diagonal problems) put other lumps' panels on the same levels;
+  // levels are known before any panel is built, so: one dry pass over the level numbers.
+  vector<char> tailOk(nLumps, 0);
+  {
+    vector<int32_t> lastLv(nLumps, -1), firstLv(nLumps, 0), occupancy;
+    for (int64_t l = denseBegin; l < upToLump; l++) {
+      int32_t level = 0;
+      for (int64_t q = sk.boardRowPtr[l]; q < sk.boardRowPtr[l + 1] - 1; q++) {
+        const int64_t s = sk.boardColLump[q];
+        if (s >= denseBegin && s < l) level = std::max(level, lastLv[s] + 1);
+      }
+      const int32_t n = panelsOf(sk.lumpStart[l + 1] - sk.lumpStart[l]);
+      firstLv[l] = level;
+      lastLv[l] = level + n - 1;
+      if ((int64_t)occupancy.size() < level + n) occupancy.resize(level + n, 0);
+      for (int32_t j = 0; j < n; j++) occupancy[level + j]++;
+    }
+    for (int64_t l = denseBegin; l < upToLump; l++) {
+      const LumpCols g = lumpCols(sk, l);
+      const int64_t tf = tailFromOf(g.width, g.rowsBelow);
+      if (tf < 0) continue;
+      bool alone = true;
+      for (int32_t j = (int32_t)(tf / kOuterWidth) * (kOuterWidth / kPanelWidth); j <= lastLv[l] - firstLv[l]; j++) {
+        alone = alone && occupancy[firstLv[l] + j] == 1;
+      }
+      tailOk[l] = alone;
+    }
+  }
   for (int64_t l = denseBegin; l < upToLump; l++) {
     LumpCols g = lumpCols(sk, l);
     plan.flops += double(g.width) * g.width * g.width / 3.0 +
@@ -653,7 +701,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       if (s >= denseBegin && s < l) level = std::max(level, lastLevelOfLump[s] + 1);
     }
     const int32_t first = (int32_t)plan.panels.size();
-    const int32_t n = addPanels(l, g, lumpRowBase, /*withBoards=*/true, boardSegs);
+    const int32_t n = addPanels(l, g, lumpRowBase, /*withBoards=*/true, boardSegs, tailOk[l] != 0);
     for (int32_t j = 0; j < n; j++) bucketAt(levelBuckets, level + j).push_back({first + j, level + j});
     lastLevelOfLump[l] = level + n - 1;
   }
@@ -677,6 +725,9 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
                          buckets[bi + 1].size() == 1 &&
                          plan.panels[buckets[bi + 1][0].panel].lump == plan.panels[bucket[0].panel].lump &&
                          plan.panels[buckets[bi + 1][0].panel].pad == 0;
+      for (const auto& pb : bucket) {  // (tailOk above: a tail panel never shares its level)
+        BASPACHO_CHECK(bucket.size() == 1 || plan.panels[pb.panel].pad == 0);
+      }
       if (bucket.size() == 1 && plan.panels[bucket[0].panel].pad == 1) {
         const bool first = out.empty() || out.back().tail == 0;
         // (the panel and its row tiles stay listed: the solves walk a tail level like any other

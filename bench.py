@@ -858,7 +858,7 @@ def main():
         out["residual_probe_kind"] = "vector probe ||L(L^T x) - A x|| / ||A x||, 2 random x (not the Frobenius norm)"
         st = sol.planStats()
         out["plan"] = {k: st[k] for k in ("num_launches", "num_levels", "num_panels",
-                                          "num_upd_tasks", "num_atomic_upd_tasks")}
+                                          "num_upd_tasks", "num_atomic_upd_tasks", "num_tail_panels")}
         out["analysis_s"] = round(main_run.t_sym, 3)
         if not args.no_profile:
             out.update(roofline_block(sol, main_run.A_devs[0], main_run.flops, res["ms_per_step"]

@@ -86,9 +86,10 @@ def test_tail_batched(monkeypatch):
         assert np.linalg.norm(got - dense[q]) / np.linalg.norm(dense[q]) < 1e-12, q
 
 
-def test_no_tail_for_a_lump_with_rows_below_or_a_narrow_one(monkeypatch):
+def test_no_tail_for_a_narrow_lump_when_switched_off(monkeypatch):
     monkeypatch.setenv("BSP_TAIL_BLOCKS", "4")
-    sol = _dense_solver(1100)  # five outer blocks: below the minimum
+    monkeypatch.setenv("BSP_TAIL_NARROW_MIN", "0")
+    sol = _dense_solver(1100)  # five outer blocks: below the minimum of the wide-lump rule
     data = spd_data(sol, 5)
     dev = to_dev(data)
     sol.factor(dev)
@@ -96,6 +97,78 @@ def test_no_tail_for_a_lump_with_rows_below_or_a_narrow_one(monkeypatch):
     L, _ = dense_lower_chol(sol, data)
     got = lower_of(sol, dev.cpu().numpy())
     assert np.linalg.norm(got - L) / np.linalg.norm(L) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tail_of_a_narrow_root_lump(dtype):
+    """round 6, verdict item 1b: a root lump of 2 .. 5 outer blocks (GRID 82x82: 990 columns) hands
+    everything after its first block to the persistent tail when ONE matrix is factored; a batch takes
+    the second plan without it (the tail loses there: profiles/r06_tail_narrow.txt)"""
+    for W in (577, 600, 640, 822, 990, 1100, 1279, 1281, 1535):
+        sol = _dense_solver(W, span=8 if W % 2 == 0 else 7)
+        want = 1 if W - 256 > 5 * 64 else 0
+        assert (sol.planStats()["num_tail_panels"] > 0) == bool(want), W
+        data = spd_data(sol, 11 + W, dtype=dtype)
+        L, A = dense_lower_chol(sol, data)
+        dev = to_dev(data)
+        before = sol.runCounters()["tail_launches"]
+        sol.factor(dev)
+        assert sol.runCounters()["tail_launches"] == before + want, W
+        got = lower_of(sol, dev.cpu().numpy())
+        err = np.linalg.norm(got - L) / np.linalg.norm(L)
+        assert err < (1e-12 if dtype == np.float64 else 2e-5), (W, err)
+        worst = np.abs(got - L).max() / np.abs(L).max()
+        assert worst < (1e-11 if dtype == np.float64 else 1e-4), (W, worst)
+        # a batch of the same solver: the plan without the narrow tail
+        mats = [to_dev(spd_data(sol, 70 + q, dtype=dtype)) for q in range(3)]
+        dense = [dense_lower_chol(sol, m.cpu().numpy())[0] for m in mats]
+        before = sol.runCounters()["tail_launches"]
+        sol.factor(mats)
+        narrow = (W + 255) // 256 < 6  # (six blocks and more: the wide-lump rule, batches included)
+        assert sol.runCounters()["tail_launches"] == before + (0 if narrow else 1), W
+        for q in range(3):
+            got = lower_of(sol, mats[q].cpu().numpy())
+            assert np.linalg.norm(got - dense[q]) / np.linalg.norm(dense[q]) < (1e-12 if dtype == np.float64 else 2e-5), (W, q)
+
+
+def _cliques(widths, span=8):
+    cols, base = [], 0
+    for w in widths:
+        k = w // span
+        cols += [list(range(base + c, base + k)) for c in range(k)]
+        base += k
+    return np.full(base, span, dtype=np.int64), T.columns_to_structure(cols)
+
+
+@pytest.mark.parametrize("widths", [(1600, 1600), (1600, 3200), (900, 900), (832, 1216, 640)])
+def test_tails_in_a_forest_of_wide_roots(widths):
+    """A tail level is ONE launch that factors nothing but the tail, so a lump may hand columns to it only
+    if those panels are alone in their levels.  Block-diagonal problems (two cliques = two root lumps on
+    the same levels) used to take the tail path for panels that shared a level and came out WRONG
+    (found in round 6 on the reference's MERI family); the plan now checks the level occupancy first."""
+    sizes, ss = _cliques(widths)
+    sol = B.create_solver(B.Settings(findSparseEliminationRanges=False), sizes, ss, [])
+    data = spd_data(sol, 21 + len(widths))
+    L, _ = dense_lower_chol(sol, data)
+    dev = to_dev(data)
+    sol.factor(dev)
+    got = lower_of(sol, dev.cpu().numpy())
+    err = np.abs(got - L).max() / np.abs(L).max()
+    assert err < 1e-11, (widths, err, sol.planStats()["num_tail_panels"])
+
+
+def test_meri_family_with_a_narrow_root():
+    """the reference's 40_MERI problem (Bench.cpp:355-360): its 822-column root lump takes the narrow
+    tail; vector residual probe against the CPU oracle"""
+    import bench
+    name = [k for k in bench.ref_suite_problems() if k.startswith("40_MERI")][0]
+    sizes, ss = bench.ref_suite_problems()[name](37)
+    sol = B.create_solver(B.Settings(findSparseEliminationRanges=True), sizes, ss)
+    h = T.random_data(sol.dataSize(), -1.0, 1.0, 37)
+    sol.damp(h, 0.0, sol.order() * 1.2)
+    dev = to_dev(h)
+    sol.factor(dev)
+    assert bench.residual_probe(sol, h, dev, nprobe=2) < 1e-13
 
 
 def test_backend_options_reach_the_schedule_without_the_environment():
