@@ -70,7 +70,7 @@ class _CRunCounters(ctypes.Structure):
                 ["sweep_launches", "sweep_timeouts", "split_lists_used", "sub_batches_enqueued",
                  "lookahead_forks", "sweeps_retired", "sweep_error_pending",
                  "gather_chunks_overlapped", "tail_launches", "sweep_mfma_launches",
-                 "solve_wide_launches", "inv_reused"]]
+                 "solve_wide_launches", "inv_reused", "potrf_folded_levels"]]
 
 
 @dataclass

@@ -657,6 +657,7 @@ int bsp_run_counters_get(bsp_solver* s, bsp_run_counters* out) {
   out->sweep_mfma_launches = c.sweepMfmaLaunches;
   out->solve_wide_launches = c.solveWideLaunches;
   out->inv_reused = c.invReused;
+  out->potrf_folded_levels = c.potrfFoldedLevels;
   BSP_CATCH
 }
 

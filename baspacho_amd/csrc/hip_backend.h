@@ -77,6 +77,7 @@ struct HipRunCounters {
   int64_t tailLaunches = 0;        // persistent tail launches (hip_tail_kernel.h)
   int64_t solveWideLaunches = 0;   // backward elimination passes of hip_solve_wide.h
   int64_t invReused = 0;           // backward passes that reused the inverses of their forward pass
+  int64_t potrfFoldedLevels = 0;   // tree levels whose potrf launch was folded into their trsm launch
   int64_t sweepMfmaLaunches = 0;   // ... of sweepLaunches: the matrix-core form for several right-hand sides
   int64_t sweepsRetired = 0;       // 1: a time-out retired the sweeps of this Solver
   int64_t sweepErrorPending = 0;   // 1: a time-out has been raised and not been reported yet

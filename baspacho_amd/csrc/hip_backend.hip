@@ -107,6 +107,16 @@ struct DevPlan {
   static constexpr int32_t kSplitMinK = 128, kSplitK = 96;
   DevBuf updTasksSplit;
   std::map<int64_t, std::pair<int64_t, int64_t>> splitRange;
+  // POTRF FOLDED INTO THE TRSM LAUNCH of small multi-panel levels (trsmPanelPotrf, round 6): the levels
+  // of host.levels that may take it (every panel has rows below, at most kFoldMaxTiles row tiles),
+  // sorted by their number of row tiles -- the levels a call of batch b folds (tiles x b <=
+  // kFoldMaxTiles) are then a PREFIX of this order, and so are their panels' descriptors in
+  // foldDescs, which ONE potrfPanel launch at the end of the factorisation walks to store the factors
+  static constexpr int64_t kFoldMaxTiles = 512;
+  DevBuf foldDescs;
+  vector<int32_t> foldRank;      // per level of host.levels: position in the sorted order, -1: not foldable
+  vector<int64_t> foldTiles;     // sorted order: row tiles of the level
+  vector<int64_t> foldPanelEnd;  // ... panels of the levels up to and including this one
   // forward-solve gather lists, built on the first solve that needs them
   bool solveGatherReady = false;
   SolveGatherPlan solveGather;
@@ -144,6 +154,29 @@ struct DevPlan {
         tf[i] = TrsmTaskFat{pd.diagOff, pd.lda, pd.nb, pd.rowsBelow, host.trsmTasks[i].rowTile, 0, 0};
       }
       trsmTasksFat.upload(tf);
+      // levels whose potrf may be folded into their trsm launch
+      foldRank.assign(host.levels.size(), -1);
+      vector<std::pair<int64_t, size_t>> cand;  // (row tiles, level)
+      for (size_t li = 0; li < host.levels.size(); li++) {
+        const LevelRange& lr = host.levels[li];
+        const int64_t nT = lr.trsmEnd - lr.trsmBegin;
+        if (lr.tail || lr.directPanel >= 0 || lr.panelEnd <= lr.panelBegin || nT < 1 || nT > kFoldMaxTiles) continue;
+        bool allBelow = true;
+        for (int64_t q = lr.panelBegin; q < lr.panelEnd; q++) allBelow = allBelow && lp[q].rowsBelow > 0;
+        if (allBelow) cand.push_back({nT, li});
+      }
+      std::stable_sort(cand.begin(), cand.end());
+      vector<PanelDesc> fd;
+      foldTiles.clear();
+      foldPanelEnd.clear();
+      for (size_t k = 0; k < cand.size(); k++) {
+        const LevelRange& lr = host.levels[cand[k].second];
+        foldRank[cand[k].second] = (int32_t)k;
+        fd.insert(fd.end(), lp.begin() + lr.panelBegin, lp.begin() + lr.panelEnd);
+        foldTiles.push_back(cand[k].first);
+        foldPanelEnd.push_back((int64_t)fd.size());
+      }
+      foldDescs.upload(fd);
     }
     {
       vector<UpdTaskFat> fat(host.updTasks.size());
@@ -453,6 +486,8 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_SWEEP_TRACE")) sweepTraceOn = e[0] != '0';
     if (const char* e = std::getenv("BSP_SWEEP_MFMA_MIN")) sweepMfmaMinRhs = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BSP_SOLVE_WIDE_MIN")) solveWideMinRhs = std::max(2, std::atoi(e));
+    if (const char* e = std::getenv("BSP_POTRF_IN_TRSM")) potrfInTrsm = e[0] != '0';
+    if (const char* e = std::getenv("BSP_FOLD_MAX_TILES")) foldMaxTiles = std::min<int64_t>(DevPlan::kFoldMaxTiles, std::max(1, std::atoi(e)));
   }
 
   virtual ~HipSymbolicCtx() override {
@@ -701,6 +736,8 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipPlanOptions planOpts;     // the plan builder's switches (BSP_DUE_STREAM, BSP_BULK_AHEAD, ...)
   double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
+  bool potrfInTrsm = true;  // small multi-panel levels: potrf folded into the trsm launch (developer: BSP_POTRF_IN_TRSM=0)
+  int64_t foldMaxTiles = 512;  // ... levels of at most this many row tiles x batch (developer: BSP_FOLD_MAX_TILES)
   bool splitK = true;       // split-K tile lists for small multi-panel levels (BSP_SPLIT_K=0: off)
   unsigned gatherOverlapLds = 0;  // dynamic LDS of the overlapped chunks' launches (throttle; BSP_GATHER_OVERLAP_LDS)
   bool gatherOverlap = false;  // gather chunks beside the dense chain (BSP_GATHER_OVERLAP=1; off: the plan is not chunked either)
@@ -745,7 +782,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   int sweepAttr[2] = {0, 0};  // per value size (8, 4): 0 not tried, 1 ready, -1 failed
   struct RunCounters {
     int64_t sweepLaunches = 0, sweepTimeouts = 0, splitListsUsed = 0, subBatchesEnqueued = 0,
-            lookaheadForks = 0, gatherChunksOverlapped = 0, tailLaunches = 0, sweepMfmaLaunches = 0, invReused = 0, solveWideLaunches = 0;
+            lookaheadForks = 0, gatherChunksOverlapped = 0, tailLaunches = 0, sweepMfmaLaunches = 0, invReused = 0, solveWideLaunches = 0, potrfFoldedLevels = 0;
   } counters;
   // a timed-out persistent launch (solve sweep, factor tail) is reported ONCE, by the next factor()
   // or solve() on this Solver; the persistent kernels are then retired for good
@@ -902,6 +939,15 @@ struct HipNumericCtx : NumericCtx<T> {
     //  the tasks' "two streams may meet" bit is masked off)
     const bool dueStream = plan.host.opts.dueStream && sizeof(BT) == 8;
     const int sideMask = dueStream ? 3 : 1;
+    // levels whose potrf is folded into their trsm launch in THIS call (DevPlan::foldRank): the first
+    // nFold levels of the plan's order by row tiles
+    int64_t nFold = 0;
+    if (sym.potrfInTrsm && &levels == &plan.host.levels) {
+      while (nFold < (int64_t)plan.foldTiles.size() &&
+             plan.foldTiles[nFold] * (int64_t)batchSize <= sym.foldMaxTiles) {
+        nFold++;
+      }
+    }
     // fork level of the same lump's previous block (-1: none)
     auto prevFork = [&](int64_t f) -> int64_t { return f >= 0 ? levels[f].waitDefLevel : -1; };
     auto waitDeferred = [&](int64_t f) {
@@ -1000,8 +1046,11 @@ struct HipNumericCtx : NumericCtx<T> {
       BT* dinvNext = dinvBase + (slot ^ 1) * hipk::kDinvSlot;
       BT* rawCur = rawBase ? rawBase + slot * rawSlot : nullptr;
       BT* rawNext = rawBase ? rawBase + (slot ^ 1) * rawSlot : nullptr;
+      const bool fold = nFold > 0 && !potrfFused && plan.foldRank[li] >= 0 && plan.foldRank[li] < nFold;
       if (potrfFused) {
         potrfFused = false;
+      } else if (fold) {
+        sym.counters.potrfFoldedLevels++;  // (trsmPanelPotrf below; the factors are stored after the last level)
       } else if (nP) {
         timer.begin(kProfPotrf);
         if (direct) {
@@ -1060,6 +1109,9 @@ struct HipNumericCtx : NumericCtx<T> {
         } else if (direct) {
           hipk::trsmPanelDirect<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
               plan.host.panels[lr.directPanel], ref, dinvCur);
+        } else if (fold) {
+          hipk::trsmPanelPotrf<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
+              plan.trsmTasksFat.as<TrsmTaskFat>() + lr.trsmBegin, ref);
         } else {
           hipk::trsmPanel<BT><<<dim3(nT, gy.y), 256, 0, sym.stream>>>(
               plan.trsmTasksFat.as<TrsmTaskFat>() + lr.trsmBegin, ref);
@@ -1207,6 +1259,14 @@ struct HipNumericCtx : NumericCtx<T> {
           timer.end();
         }
       }
+    }
+    if (nFold > 0) {
+      // the diagonal blocks of the folded levels: factored (again) and stored, all in one launch --
+      // nothing in the factorisation reads them, the solves do
+      timer.begin(kProfPotrf);
+      hipk::potrfPanel<BT><<<dim3((unsigned)plan.foldPanelEnd[nFold - 1], gy.y), 256, 0, sym.stream>>>(
+          plan.foldDescs.as<PanelDesc>(), ref);
+      timer.end();
     }
     if (sideUsed) {  // join: everything on the side stream(s) happens-before what follows
       hipEvent_t join = sym.eventFromPool();
@@ -2337,6 +2397,7 @@ HipRunCounters hipBackendRunCounters(SymbolicCtx& sym) {
   c.sweepMfmaLaunches = h->counters.sweepMfmaLaunches;
   c.solveWideLaunches = h->counters.solveWideLaunches;
   c.invReused = h->counters.invReused;
+  c.potrfFoldedLevels = h->counters.potrfFoldedLevels;
   c.sweepsRetired = h->sweepBroken ? 1 : 0;
   c.sweepErrorPending = (h->sweepHostErr && *reinterpret_cast<volatile unsigned*>(h->sweepHostErr)) ? 1 : 0;
   return c;

@@ -999,10 +999,13 @@ __device__ __forceinline__ void potrfBlockColumn(T* buf, int R) {
   staticFor<0, 16>(column);
 }
 
-template <typename T, typename Pre = NoPreUpdate>
+// GLOBAL = false (trsmPanelPotrf): nothing is written to memory; the factor goes to `Lfull` (LDS, row
+// stride ldFull) only.
+template <typename T, typename Pre = NoPreUpdate, bool GLOBAL = true>
 __device__ __forceinline__ void potrfTilesBlocked(GP<T> A, int nb, int lda, T* colbuf0, T* colbuf1,
                                                   Pre pre = Pre(), T* Ld = nullptr,
-                                                  GP<T> dinvOut = nullptr) {
+                                                  GP<T> dinvOut = nullptr, T* Lfull = nullptr,
+                                                  int ldFull = 0) {
   constexpr int NT = 4;
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
@@ -1066,7 +1069,8 @@ __device__ __forceinline__ void potrfTilesBlocked(GP<T> A, int nb, int lda, T* c
         const int col = 16 * (J - 1) + 4 * g4 + c;
         if (row < nb && col < nb && col <= row) {
           const T v = other[potrfColbufAt(row, 4 * g4 + c)];
-          A[(int64_t)row * lda + col] = v;
+          if (GLOBAL) A[(int64_t)row * lda + col] = v;
+          if (Lfull) Lfull[row * ldFull + col] = v;
           if (Ld && (row >> 4) == J - 1) Ld[row * kInvLd + 4 * g4 + c] = v;
         }
       }
@@ -1094,7 +1098,8 @@ __device__ __forceinline__ void potrfTilesBlocked(GP<T> A, int nb, int lda, T* c
         const int col = 16 * J + 4 * g4 + c;
         if (row < nb && col < nb && col <= row) {
           const T v = cur[potrfColbufAt(row, 4 * g4 + c)];
-          A[(int64_t)row * lda + col] = v;
+          if (GLOBAL) A[(int64_t)row * lda + col] = v;
+          if (Lfull) Lfull[row * ldFull + col] = v;
           if (Ld && (row >> 4) == J) Ld[row * kInvLd + 4 * g4 + c] = v;
         }
       }
@@ -1188,6 +1193,63 @@ __global__ __launch_bounds__(256) void potrfPanelDirect(PanelDesc pd, DataRef<T>
 // the place of the diagonal blocks).
 constexpr int kTrsmLd = 66;
 constexpr int kTrsmLdsElems = kPanelWidth * kTrsmLd;
+// the solve of trsmTileMfma once L is in Ls and the tile's rows are in x (wave w: rows 16 w ..):
+// inversion of the four diagonal blocks, the four dependent stages, the store
+template <typename T>
+__device__ __forceinline__ void trsmTileSolveStore(GP<T> row, bool active, int nb, T* Ls,
+                                                   typename Mfma<T>::Acc (&x)[4]) {
+  constexpr int LDT = kTrsmLd;
+  typedef T TV2 __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, q = lane >> 4;
+  using Acc = typename Mfma<T>::Acc;
+  __syncthreads();
+  {  // wave w inverts diagonal block w
+    T y[16];
+    invertColumn16(Ls + (16 * w) * LDT + 16 * w, LDT, n, y);
+    // (round 4: written over the diagonal block itself -- only this wave reads it, all its reads
+    //  precede these writes, and the stages below use the off-diagonal blocks only: 33.8 instead of
+    //  43 KB of LDS, four workgroups per CU instead of three)
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) Ls[(16 * w + i) * LDT + 16 * w + n] = y[i];
+    }
+  }
+  __syncthreads();
+  const int pm = Mfma<T>::colOfRow(n);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (16 * j < nb) {
+#pragma unroll
+      for (int l = 0; l < j; l++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          x[j] = Mfma<T>::run(-Ls[(16 * j + pm) * LDT + 16 * l + 4 * q + r], x[l][r], x[j]);
+        }
+      }
+      Acc y = {0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        y = Mfma<T>::run(Ls[(16 * j + pm) * LDT + 16 * j + 4 * q + r], x[j][r], y);
+      }
+      x[j] = y;
+    }
+  }
+  typedef __attribute__((address_space(1))) TV2* GP2w;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c = 16 * j + 4 * q;
+    if (active && c + 3 < nb) {
+      *(GP2w)(row + c) = TV2{x[j][0], x[j][1]};
+      *(GP2w)(row + c + 2) = TV2{x[j][2], x[j][3]};
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (active && c + r < nb) row[c + r] = x[j][r];
+      }
+    }
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void trsmTileMfma(GP<const T> A, GP<T> P, int lda, int nb, int rows,
                                              T* Ls) {
@@ -1257,52 +1319,7 @@ __device__ __forceinline__ void trsmTileMfma(GP<const T> A, GP<T> P, int lda, in
 #pragma unroll
     for (int r = 0; r < 4; r++) x[j][r] = (active && 16 * j + 4 * q + r < nb) ? x[j][r] : T(0);
   }
-  __syncthreads();
-  {  // wave w inverts diagonal block w
-    T y[16];
-    invertColumn16(Ls + (16 * w) * LDT + 16 * w, LDT, n, y);
-    // (round 4: written over the diagonal block itself -- only this wave reads it, all its reads
-    //  precede these writes, and the stages below use the off-diagonal blocks only: 33.8 instead of
-    //  43 KB of LDS, four workgroups per CU instead of three)
-    if (lane < 16) {
-#pragma unroll
-      for (int i = 0; i < 16; i++) Ls[(16 * w + i) * LDT + 16 * w + n] = y[i];
-    }
-  }
-  __syncthreads();
-  const int pm = Mfma<T>::colOfRow(n);
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (16 * j < nb) {
-#pragma unroll
-      for (int l = 0; l < j; l++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          x[j] = Mfma<T>::run(-Ls[(16 * j + pm) * LDT + 16 * l + 4 * q + r], x[l][r], x[j]);
-        }
-      }
-      Acc y = {0, 0, 0, 0};
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        y = Mfma<T>::run(Ls[(16 * j + pm) * LDT + 16 * j + 4 * q + r], x[j][r], y);
-      }
-      x[j] = y;
-    }
-  }
-  typedef __attribute__((address_space(1))) TV2* GP2w;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int c = 16 * j + 4 * q;
-    if (active && c + 3 < nb) {
-      *(GP2w)(row + c) = TV2{x[j][0], x[j][1]};
-      *(GP2w)(row + c + 2) = TV2{x[j][2], x[j][3]};
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        if (active && c + r < nb) row[c + r] = x[j][r];
-      }
-    }
-  }
+  trsmTileSolveStore<T>(row, active, nb, Ls, x);
 }
 
 // Register-only form for the chain (single-panel levels): the inverses of the diagonal blocks
@@ -1438,6 +1455,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   GP<T> P = data + pd.diagOff + (int64_t)(nb + task.rowTile) * lda;
   const int rows = min(kTile, pd.rowsBelow - task.rowTile);
   trsmTileMfma<T>(data + pd.diagOff, P, lda, nb, rows, lds);
+}
+
+// K4p  (round 6) the trsm of a SMALL tree level with the level's potrf folded in: every row tile factors
+// its own copy of the panel's diagonal block in LDS (same code as potrfPanel: bitwise the same factor)
+// before it solves, so the level is two launches instead of three; nothing is written to the diagonal
+// block here -- its workgroups all read the unfactored block -- and ONE potrfPanel launch over all such
+// panels stores the factors at the end of the factorisation (nothing reads them before: update tiles
+// take the solved rows, the chain its own panel).  Taken for multi-panel levels whose trsm launch is
+// one round of workgroups (tasks x batch <= 512; launchLevels).  Measured in round 4 (-4 % on GRID
+// 82x82, profiles/r04_ab_potrf_in_trsm.txt), built into the library in round 6.
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void trsmPanelPotrf(
+    const TrsmTaskFat* tasks, DataRef<T> dref) {
+  constexpr int LDT = kTrsmLd;
+  __shared__ T Ls[kTrsmLdsElems];
+  __shared__ T blk[8 * kPanelWidth][4];
+  const TrsmTaskFat pd = tasks[blockIdx.x];
+  GP<T> data = pickData(dref);
+  const int nb = pd.nb, lda = pd.lda;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, q = lane >> 4;
+  const int rows = min(kTile, pd.rowsBelow - pd.rowTile);
+  const bool active = 16 * w + n < rows;
+  GP<T> row = data + pd.diagOff + (int64_t)(nb + pd.rowTile + (active ? 16 * w + n : 0)) * lda;
+  using Acc = typename Mfma<T>::Acc;
+  Acc x[4];
+  // the tile's rows first: they travel while the diagonal block is factored
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[j][r] = row[min(16 * j + 4 * q + r, nb - 1)];
+  }
+  for (int e = tid; e < kPanelWidth * LDT; e += 256) {
+    const int i = e / LDT, jj = e - i * LDT;
+    Ls[e] = (i >= nb && i == jj) ? T(1) : T(0);
+  }
+  __syncthreads();
+  potrfTilesBlocked<T, NoPreUpdate, false>(data + pd.diagOff, nb, lda, &blk[0][0], &blk[4 * kPanelWidth][0],
+                                           NoPreUpdate(), nullptr, nullptr, Ls, LDT);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[j][r] = (active && 16 * j + 4 * q + r < nb) ? x[j][r] : T(0);
+  }
+  trsmTileSolveStore<T>(row, active, nb, Ls, x);
 }
 
 template <typename T>

@@ -324,6 +324,7 @@ typedef struct bsp_run_counters {
   int64_t sweep_mfma_launches;  /* ... of sweep_launches: the matrix-core form (several right-hand sides) */
   int64_t solve_wide_launches;  /* backward elimination passes with the right-hand sides across the lanes */
   int64_t inv_reused;           /* backward passes that found the inverted diagonal blocks of their forward pass */
+  int64_t potrf_folded_levels;  /* tree levels whose potrf launch was folded into their trsm launch */
 } bsp_run_counters;
 int bsp_run_counters_get(bsp_solver* s, bsp_run_counters* out);
 

@@ -386,6 +386,51 @@ def test_split_k_tiles_of_small_levels(monkeypatch, split, dtype):
             assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < (1e-10 if dtype == np.float64 else 5e-5), q
 
 
+@pytest.mark.parametrize("fold", ["1", "0"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_potrf_folded_into_the_trsm_launch_of_small_levels(monkeypatch, fold, dtype):
+    """round 6 (trsmPanelPotrf): a multi-panel level whose trsm launch is one round of workgroups drops its
+    potrf launch -- every row tile factors its own copy of the diagonal block in LDS, ONE potrfPanel launch
+    stores the factors after the last level.  Same arithmetic: the factor must be BITWISE the one of the
+    three-launch form.  Four independent blocks over a separator (levels of four and two panels, ragged
+    widths), one matrix and a batch; the counter says which form ran; the solve reads the stored factors."""
+    widths, sep = [130, 97, 200, 70], 150
+    n = sum(widths) + sep
+    cols, base = [], 0
+    for w in widths:
+        for i in range(w):
+            cols.append(set(range(base + i, base + w)) | set(range(n - sep, n)))
+        base += w
+    for i in range(sep):
+        cols.append(set(range(n - sep + i, n)))
+    ss = T.columns_to_structure(cols)
+    results = {}
+    for f in (fold, "0"):
+        monkeypatch.setenv("BSP_POTRF_IN_TRSM", f)
+        sol = B.create_solver(B.Settings(), np.ones(n, dtype=np.int64), ss)
+        for bs in (1, 3):
+            datas = [spd_data(sol, 90 + q, beta_factor=1.2) for q in range(bs)]
+            devs = [to_dev(d.astype(dtype)) for d in datas]
+            before = sol.runCounters()["potrf_folded_levels"]
+            sol.factor(devs if bs > 1 else devs[0])
+            folded = sol.runCounters()["potrf_folded_levels"] - before
+            assert (folded > 0) == (f == "1"), (folded, f)
+            for q in range(bs):
+                got = devs[q].cpu().numpy()
+                results.setdefault((bs, q), []).append(got)
+                _, A = dense_lower_chol(sol, datas[q])
+                Lg = lower_of(sol, got).astype(np.float64)
+                assert np.linalg.norm(Lg @ Lg.T - A) / np.linalg.norm(A) < (1e-10 if dtype == np.float64 else 5e-5), q
+            if bs == 1 and dtype == np.float64:
+                rhs = np.random.default_rng(5).standard_normal(n)
+                v = to_dev(rhs.copy())
+                sol.solve(devs[0], v, n, 1)
+                X = np.linalg.solve(dense_lower_chol(sol, datas[0])[1], rhs)
+                assert np.linalg.norm(v.cpu().numpy() - X) / np.linalg.norm(X) < 1e-10
+    for key, (a, b) in results.items():
+        assert np.array_equal(a, b), ("folded and three-launch factors differ", key)
+
+
 @pytest.mark.parametrize("ahead", ["0", "0.6", "100"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_lookahead_units_over_many_outer_blocks(monkeypatch, ahead, dtype):
