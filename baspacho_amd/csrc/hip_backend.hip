@@ -485,8 +485,10 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (const char* e = std::getenv("BSP_GATHER_OVERLAP_LDS")) gatherOverlapLds = (unsigned)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BSP_SWEEP_TRACE")) sweepTraceOn = e[0] != '0';
     if (const char* e = std::getenv("BSP_SWEEP_MFMA_MIN")) sweepMfmaMinRhs = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("BSP_SWEEP_MFMA_MIN_WIDTH")) sweepMfmaMinWidth = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BSP_SOLVE_WIDE_MIN")) solveWideMinRhs = std::max(2, std::atoi(e));
     if (const char* e = std::getenv("BSP_POTRF_IN_TRSM")) potrfInTrsm = e[0] != '0';
+    if (const char* e = std::getenv("BSP_TAIL_IN_BATCH")) tailInBatch = e[0] != '0';
     if (const char* e = std::getenv("BSP_FOLD_MAX_TILES")) foldMaxTiles = std::min<int64_t>(DevPlan::kFoldMaxTiles, std::max(1, std::atoi(e)));
   }
 
@@ -661,8 +663,11 @@ struct HipSymbolicCtx : SymbolicCtx {
   }
 
   // plan of a fused factor over lumps [startLump, upToLump), built and uploaded on first use
-  // tag 0: factor() / solve(); tag 1: one elimination range; tag 2: factor() of a BATCH when plan 0 gave a
-  // narrow root lump a persistent tail (HipPlanOptions::tailNarrowMin) -- the same plan without it
+  // tag 0: factor() / solve(); tag 1: one elimination range; tag 2: factor() of a BATCH when plan 0 has a
+  // persistent tail -- the same plan without it.  The tail is a latency device for ONE matrix: in a batch
+  // the chain steps of the matrices already run side by side, and batch x roles exceed what is resident
+  // (batch of 8 GRID 82x82 2.23 -> 2.35 ms with it; the reference's FLAT families at batch 16 +22..+36 % per
+  // matrix, profiles/r06_tail_batches.txt)
   DevPlan& planFor(const vector<int64_t>& ranges, int64_t startLump, int64_t upToLump, int tag) {
     checkDevice();
     auto key = std::make_tuple(tag, startLump, upToLump);
@@ -670,7 +675,7 @@ struct HipSymbolicCtx : SymbolicCtx {
     if (it == plans.end()) {
       std::unique_ptr<DevPlan> p(new DevPlan);
       HipPlanOptions po = planOpts;
-      if (tag == 2) po.tailNarrowMin = 0;
+      if (tag == 2) po.tailBlocks = 0;
       p->host = buildHipPlan(skel, ranges, startLump, upToLump, po);
       p->upload();
       it = plans.emplace(key, std::move(p)).first;
@@ -736,6 +741,7 @@ struct HipSymbolicCtx : SymbolicCtx {
   HipPlanOptions planOpts;     // the plan builder's switches (BSP_DUE_STREAM, BSP_BULK_AHEAD, ...)
   double lookaheadMinFlops = HipPlanHost::kMinDeferredFlopsPerFork;  // BSP_LOOKAHEAD_MIN_GF (0: side streams whenever a plan has lookahead units)
   bool blockSolve = true;   // wide lumps: triangular solves by outer block (BSP_BLOCK_SOLVE=0: by panel)
+  bool tailInBatch = false;  // developer (BSP_TAIL_IN_BATCH=1): batches run the plan WITH the persistent tail (A/B record)
   bool potrfInTrsm = true;  // small multi-panel levels: potrf folded into the trsm launch (developer: BSP_POTRF_IN_TRSM=0)
   int64_t foldMaxTiles = 512;  // ... levels of at most this many row tiles x batch (developer: BSP_FOLD_MAX_TILES)
   bool splitK = true;       // split-K tile lists for small multi-panel levels (BSP_SPLIT_K=0: off)
@@ -762,6 +768,9 @@ struct HipSymbolicCtx : SymbolicCtx {
   // ---- persistent sweeps over wide lumps (hip_sweep_kernels.h, round 6)
   bool sweepEnabled = true;   // BSP_SOLVE_SWEEP=0: the multi-launch block path
   int sweepMinWidth = 768;    // runs of one-panel levels at least this wide (BSP_SWEEP_MIN_WIDTH)
+  // ... and the narrowest run of columns it takes (ten right-hand sides, matrix-core sweep against the block path:
+  // 2751 / 2814 columns +23 / +22 %, 6101 +7 %, 2442 +3 %; 7839 -8 %, 9756 -20 %; developer: BSP_SWEEP_MFMA_MIN_WIDTH)
+  int sweepMfmaMinWidth = 7000;
   int sweepMfmaMinRhs = 8;    // right-hand sides from which the matrix-core sweep takes over (BAL-871: equal to the multi-launch path at 6, -5 % at 10, -10 % at 16; developer: BSP_SWEEP_MFMA_MIN)
   bool sweepBroken = false;   // a sweep timed out or cannot be launched here: multi-launch path for good
   int sweepFault = 0;         // TESTING (bsp_test_set_fault kind 2): spine of block 1 never publishes
@@ -1443,7 +1452,7 @@ struct HipNumericCtx : NumericCtx<T> {
   virtual void factorRange(T* data, int64_t startLump, int64_t upToLump) override {
     sym.checkAsyncError();
     DevPlan* planPtr = &sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/0);
-    if (batchSize > 1 && planPtr->host.narrowTail) {
+    if (batchSize > 1 && planPtr->host.hasTail && !sym.tailInBatch) {
       planPtr = &sym.planFor(sym.sparseElimRanges, startLump, upToLump, /*tag=*/2);
     }
     DevPlan& plan = *planPtr;
@@ -1848,11 +1857,15 @@ struct HipSolveCtx : SolveCtx<T> {
   // once (correct either way -- roles are dealt by ticket -- but a far role that starts late has a
   // whole row strip to catch up on at one CU's bandwidth), and its LDS must fit.
   // (several right-hand sides: the matrix-core sweep, 16 right-hand sides per set of workgroups)
-  bool sweepMfma() const { return nRHS >= sym.sweepMfmaMinRhs; }
+  // (the matrix-core sweep pays on LONG runs only: a step is 16-17 us whatever the width below it, the block
+  //  path's two launches per 256 columns cost less while the rows below are few; profiles/r06_solve10_families.txt)
+  bool sweepMfma(const SolveInvList& ent) const {
+    return nRHS >= sym.sweepMfmaMinRhs && ent.maxSweepW >= sym.sweepMfmaMinWidth;
+  }
   bool sweepsFit(const SolveInvList& ent) {
     if (ent.numSweeps == 0) return false;
     if (!sym.sweepReady<BT>()) return false;
-    if (sweepMfma()) {
+    if (sweepMfma(ent)) {
       const int64_t inst = (int64_t)((nRHS + hipk::kSweepR - 1) / hipk::kSweepR) * batch;
       return ent.maxSweepWgsM * inst <= sym.sweepCapacity && hipk::sweepMLdsBytes<BT>() <= sym.sweepMaxLds;
     }
@@ -1889,7 +1902,7 @@ struct HipSolveCtx : SolveCtx<T> {
     int64_t invBatchStride = 0;
     BT* xchg = nullptr;
     hipk::SweepShared sh{};
-    const bool mfma = sweeps && sweepMfma();
+    const bool mfma = sweeps && sweepMfma(ent);
     const int64_t rhsGroups = mfma ? (nRHS + hipk::kSweepR - 1) / hipk::kSweepR : nRHS;
     const int64_t nInst = rhsGroups * batch;
     const int64_t instStride = ent.sweepInstStride * (mfma ? hipk::kSweepR : 1);

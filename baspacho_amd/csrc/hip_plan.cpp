@@ -399,7 +399,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     // panels exist (the solves walk them) but carry no segments, and the block before them hands ALL
     // its pending lookahead units over at once
     const int64_t tailFrom = tailAllowed ? tailFromOf(n, g.rowsBelow) : -1;
-    if (tailFrom >= 0 && (n + kOuterWidth - 1) / kOuterWidth < opts.tailMinBlocks) plan.narrowTail = true;
+    if (tailFrom >= 0) plan.hasTail = true;
     for (int64_t blockStart = 0; blockStart < n; blockStart += kOuterWidth) {
       const int64_t blockEnd = std::min<int64_t>(n, blockStart + kOuterWidth);
       for (int64_t c0 = blockStart; c0 < blockEnd; c0 += kPanelWidth, count++) {

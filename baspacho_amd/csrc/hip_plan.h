@@ -248,8 +248,9 @@ struct HipPlanOptions {
   int32_t tailMinBlocks = 6;
   // NARROW root lumps (tailNarrowMin <= blocks < tailMinBlocks; GRID 82x82: 990 columns = 4 blocks):
   // everything after the first outer block is the tail.  Pays for ONE matrix (GRID 82x82 1.144 -> 1.089
-  // ms), loses for batches (batch of 8: 2.23 -> 2.35 ms: 8 x 78 resident roles), so factor() of a batch
-  // runs a second plan without it (HipSymbolicCtx::planFor, tag 2).  0: off.  profiles/r06_tail_narrow.txt.
+  // ms), loses for batches (batch of 8: 2.23 -> 2.35 ms: 8 x 78 resident roles) -- like EVERY tail: factor()
+  // of a batch runs a second plan without tails (HipSymbolicCtx::planFor, tag 2).  0: off.
+  // profiles/r06_tail_narrow.txt.
   // A tail needs at least six panels, and -- like every tail -- panels that are alone in their levels.
   int32_t tailNarrowMin = 2;  // (developer: BSP_TAIL_NARROW_MIN; tailBlocks = 0 switches every tail off)
   int32_t solveSortWindow = 16;  // lumps per sorting window of the backward elimination lists (= a workgroup; developer: BSP_SOLVE_SORT_WINDOW)
@@ -258,7 +259,7 @@ struct HipPlanOptions {
 
 struct HipPlanHost {
   HipPlanOptions opts;
-  bool narrowTail = false;  // a narrow root lump got a persistent tail (opts.tailNarrowMin)
+  bool hasTail = false;  // some lump hands its last columns to the persistent tail launch
   int64_t startLump = 0, upToLump = 0;
   std::vector<ElimRangePlan> elimRanges;
   std::vector<int32_t> elimChainLump;  // lump of every chain inside elimination ranges

@@ -452,7 +452,7 @@ def roofline_block(sol, A_dev, flops, ms_per_step, workload):
                          st["upd_flops_direct"] + st["trsm_flops_merged"] + st["potrf_flops_fused"]),
         "elim_update": ("elimGatherMfma<%s>" % DT, "hbm", elim_src_bytes + 16.0 * st["elim_target_elems"]),
         "elim_factor": ("elimFactorTiny|elimFactorSmall<%s>" % DT, "hbm", 16.0 * st["elim_col_elems"]),
-        "trsm": ("trsmPanel<%s>" % DT, "mfma", st["trsm_flops"] - st["trsm_flops_merged"]),
+        "trsm": ("trsmPanel|trsmPanelPotrf<%s>" % DT, "mfma", st["trsm_flops"] - st["trsm_flops_merged"]),
         "potrf": ("potrfPanel<%s>" % DT, "mfma", st["potrf_flops"] - st["potrf_flops_fused"]),
     }
     dom = max(prof, key=lambda k: prof[k][0])

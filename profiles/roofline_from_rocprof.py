@@ -48,7 +48,7 @@ heads = heads[:bench["steps"] + bench["warmup"]] + heads[bench["steps"] + bench[
 stop_at = None
 # a headline factor() = from its elimFactorTiny to the kernel before the next elimFactor* / foreign
 # kernel; solve kernels and copies in between are excluded by name
-FACTOR = ("elimFactor", "elimGather", "chainStep", "updateTile", "potrfPanel", "trsmPanel")
+FACTOR = ("elimFactor", "elimGather", "chainStep", "updateTile", "potrfPanel", "trsmPanel", "tailFactor")
 sel = []
 all_heads = [i for i, r in enumerate(rows) if 'elimFactor' in r[0]]
 for k, i in enumerate(heads):
@@ -69,9 +69,9 @@ head_txt, agg = table(sel, "kernels of the %d headline factor() calls only" % nc
 open(os.path.join(here, "%s_kernel_stats.txt" % tag), "w").write(full + "\n" + head_txt)
 print(head_txt)
 
-CLASS = {"update": ["updateTileBulk", "updateTile"], "chain_update": ["chainStep", "updateTileDirectPotrf", "updateTileDirect"],
+CLASS = {"update": ["updateTileBulk", "updateTile"], "chain_update": ["chainStep", "tailFactor", "updateTileDirectPotrf", "updateTileDirect"],
          "elim_update": ["elimGatherMfma", "elimGather", "elimGatherTiny", "elimUpdate"],
-         "elim_factor": ["elimFactorTiny", "elimFactorSmall"], "trsm": ["trsmPanel", "trsmPanelDirect", "trsmPanelDirectPlus"],
+         "elim_factor": ["elimFactorTiny", "elimFactorSmall"], "trsm": ["trsmPanel", "trsmPanelPotrf", "trsmPanelDirect", "trsmPanelDirectPlus"],
          "potrf": ["potrfPanel", "potrfPanelDirect"]}
 out = {}
 for cls, ent in bench.get("kernel_rates", {}).items():

@@ -16,7 +16,7 @@ gmax = max(rows[i][4] for i in idx)
 heads = [i for i in idx if rows[i][4] == gmax]
 pick = int(sys.argv[2]) if len(sys.argv) > 2 else min(4, len(heads) - 2)
 seg = [r for r in rows[heads[pick]:heads[pick + 1]]
-       if any(t in r[0] for t in ("elimFactor", "elimGather", "chainStep", "updateTile", "potrfPanel", "trsmPanel"))]
+       if any(t in r[0] for t in ("elimFactor", "elimGather", "chainStep", "updateTile", "potrfPanel", "trsmPanel", "tailFactor"))]
 t0 = seg[0][1]
 tg = [r for r in seg if 'elimGather' in r[0]][-1][2]
 tend = max(r[2] for r in seg)

@@ -391,8 +391,8 @@ def test_split_k_tiles_of_small_levels(monkeypatch, split, dtype):
 def test_potrf_folded_into_the_trsm_launch_of_small_levels(monkeypatch, fold, dtype):
     """round 6 (trsmPanelPotrf): a multi-panel level whose trsm launch is one round of workgroups drops its
     potrf launch -- every row tile factors its own copy of the diagonal block in LDS, ONE potrfPanel launch
-    stores the factors after the last level.  Same arithmetic: the factor must be BITWISE the one of the
-    three-launch form.  Four independent blocks over a separator (levels of four and two panels, ragged
+    stores the factors after the last level.  Same arithmetic per panel: the factor must be the one of the
+    three-launch form to rounding.  Four independent blocks over a separator (levels of four and two panels, ragged
     widths), one matrix and a batch; the counter says which form ran; the solve reads the stored factors."""
     widths, sep = [130, 97, 200, 70], 150
     n = sum(widths) + sep
@@ -427,8 +427,11 @@ def test_potrf_folded_into_the_trsm_launch_of_small_levels(monkeypatch, fold, dt
                 sol.solve(devs[0], v, n, 1)
                 X = np.linalg.solve(dense_lower_chol(sol, datas[0])[1], rhs)
                 assert np.linalg.norm(v.cpu().numpy() - X) / np.linalg.norm(X) < 1e-10
+    # (the same arithmetic per panel; the separator's columns take atomics from the four blocks in whatever
+    #  order the launch runs them, so two runs of EITHER form agree to rounding, not bit for bit)
     for key, (a, b) in results.items():
-        assert np.array_equal(a, b), ("folded and three-launch factors differ", key)
+        d = np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / np.abs(b).max()
+        assert d < (1e-13 if dtype == np.float64 else 1e-5), ("folded and three-launch factors differ", key, d)
 
 
 @pytest.mark.parametrize("ahead", ["0", "0.6", "100"])

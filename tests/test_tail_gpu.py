@@ -70,7 +70,9 @@ def test_tail_panels_in_the_multi_launch_solves(monkeypatch):
         assert err < 1e-10, (W, err)
 
 
-def test_tail_batched(monkeypatch):
+def test_a_batch_keeps_the_level_schedule(monkeypatch):
+    """the tail is a latency device for ONE matrix (profiles/r06_tail_batches.txt): factor() of a batch runs
+    the second plan, without it; one matrix on the same Solver takes the tail"""
     monkeypatch.setenv("BSP_TAIL_BLOCKS", "3")
     sol = _dense_solver(1700)
     mats, dense = [], []
@@ -80,7 +82,11 @@ def test_tail_batched(monkeypatch):
         dense.append(dense_lower_chol(sol, data)[0])
     before = sol.runCounters()["tail_launches"]
     sol.factor(mats)
+    assert sol.runCounters()["tail_launches"] == before
+    one = to_dev(spd_data(sol, 40))
+    sol.factor(one)
     assert sol.runCounters()["tail_launches"] == before + 1
+    assert np.linalg.norm(lower_of(sol, one.cpu().numpy()) - dense[0]) / np.linalg.norm(dense[0]) < 1e-12
     for q in range(3):
         got = lower_of(sol, mats[q].cpu().numpy())
         assert np.linalg.norm(got - dense[q]) / np.linalg.norm(dense[q]) < 1e-12, q
@@ -119,13 +125,12 @@ def test_tail_of_a_narrow_root_lump(dtype):
         assert err < (1e-12 if dtype == np.float64 else 2e-5), (W, err)
         worst = np.abs(got - L).max() / np.abs(L).max()
         assert worst < (1e-11 if dtype == np.float64 else 1e-4), (W, worst)
-        # a batch of the same solver: the plan without the narrow tail
+        # a batch of the same solver: the plan without a tail
         mats = [to_dev(spd_data(sol, 70 + q, dtype=dtype)) for q in range(3)]
         dense = [dense_lower_chol(sol, m.cpu().numpy())[0] for m in mats]
         before = sol.runCounters()["tail_launches"]
         sol.factor(mats)
-        narrow = (W + 255) // 256 < 6  # (six blocks and more: the wide-lump rule, batches included)
-        assert sol.runCounters()["tail_launches"] == before + (0 if narrow else 1), W
+        assert sol.runCounters()["tail_launches"] == before, W
         for q in range(3):
             got = lower_of(sol, mats[q].cpu().numpy())
             assert np.linalg.norm(got - dense[q]) / np.linalg.norm(dense[q]) < (1e-12 if dtype == np.float64 else 2e-5), (W, q)

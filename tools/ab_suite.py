@@ -26,6 +26,9 @@ def main():
     flt = ""
     if args and args[0].startswith("--filter="):
         flt = args.pop(0).split("=", 1)[1]
+    batch = 1
+    if args and args[0].startswith("--batch="):
+        batch = int(args.pop(0).split("=")[1])
     settings = [dict(kv.split("=") for kv in a.split()) if a != "-" else {} for a in (args or ["-"])]
     device = torch.device("cuda:0")
     probs = dict(bench.ref_suite_problems())
@@ -47,12 +50,16 @@ def main():
             h = T.random_data(sol.dataSize(), -1.0, 1.0, 37)
             sol.damp(h, 0.0, sol.order() * 1.2)
             A = torch.from_numpy(h).to(device)
-            bufs = [A.clone() for _ in range(reps + 2)]
+            if batch > 1:  # the same matrix `batch` times per call (timing only; per-matrix time reported)
+                bufs = [[A.clone() for _ in range(batch)] for _ in range(reps + 2)]
+            else:
+                bufs = [A.clone() for _ in range(reps + 2)]
             sol.factor(bufs[0])
             sol.factor(bufs[1])
             it = iter(bufs[2:])
             t, _ = bench._timed(device, lambda: sol.factor(next(it)), reps)
-            res = bench.residual_probe(sol, h, bufs[-1], nprobe=1)
+            t /= batch
+            res = bench.residual_probe(sol, h, bufs[-1][-1] if batch > 1 else bufs[-1], nprobe=1)
             st = sol.planStats()
             line.append((t * 1e3, res, st["num_tail_panels"], st["num_levels"], st["num_launches"]))
             del sol, A, bufs, it
