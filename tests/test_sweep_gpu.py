@@ -184,6 +184,7 @@ def test_matrix_core_sweep_several_right_hand_sides(monkeypatch, dtype, tail):
     in two and three, run widths around the panel / block boundaries, rows below the run"""
     monkeypatch.setenv("BSP_SWEEP_MIN_WIDTH", "128")
     monkeypatch.setenv("BSP_SWEEP_MFMA_MIN", "3")  # (product default: 8)
+    monkeypatch.setenv("BSP_SWEEP_MFMA_MIN_WIDTH", "0")  # (product default: runs of at least 7000 columns)
     for W, nrhs in ((130, 3), (192, 5), (193, 16), (385, 4), (577, 10), (641, 17), (960, 7), (1101, 35)):
         sol = _wide_solver(W, tail, span=8 if W % 2 == 0 else 5)
         data = spd_data(sol, 5 + W, dtype=dtype)
@@ -192,7 +193,16 @@ def test_matrix_core_sweep_several_right_hand_sides(monkeypatch, dtype, tail):
         assert sol.runCounters()["sweep_mfma_launches"] - before >= 4, "the matrix-core sweep was not the path taken"
 
 
-def test_matrix_core_sweep_batched_and_default_threshold():
+def test_matrix_core_sweep_batched_and_default_threshold(monkeypatch):
+    """ten right-hand sides, a batch of two; the default width threshold (7000 columns) keeps a 1500-wide run
+    on the block path, with it lowered the matrix-core sweep takes it"""
+    sol0 = _wide_solver(1500, 140)
+    d0 = to_dev(spd_data(sol0, 20))
+    sol0.factor(d0)
+    v0 = to_dev(np.random.default_rng(0).standard_normal((10, sol0.order())).reshape(-1).copy())
+    sol0.solve(d0, v0, sol0.order(), 10)
+    assert sol0.runCounters()["sweep_mfma_launches"] == 0
+    monkeypatch.setenv("BSP_SWEEP_MFMA_MIN_WIDTH", "1024")
     sol = _wide_solver(1500, 140)
     n, nrhs, batch = sol.order(), 10, 2
     mats, rhs, dense = [], [], []
