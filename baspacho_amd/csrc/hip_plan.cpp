@@ -338,6 +338,7 @@ void HipPlanOptions::applyDeveloperEnv() {
   if (const char* e = std::getenv("BSP_SOLVE_SORT_WINDOW")) solveSortWindow = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BSP_TAIL_MIN_BLOCKS")) tailMinBlocks = std::max(2, std::atoi(e));
   if (const char* e = std::getenv("BSP_TAIL_NARROW_MIN")) tailNarrowMin = std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("BSP_TAIL_WHOLE")) tailWholeNarrow = e[0] != '0';
 }
 
 HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_t>& elimRangesIn,
@@ -391,14 +392,15 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
     return c;
   };
   auto addPanels = [&](int64_t l, const LumpCols& g, int32_t lumpRowBase, bool withBoards,
-                       const vector<SegDesc>& boardSegTemplates, bool tailAllowed) {
+                       const vector<SegDesc>& boardSegTemplates, int tailMode) {
     int32_t count = 0;
     const int64_t n = g.width;
     vector<int64_t> pendingFrom;  // per column block of this lump (lookahead schedule, see below)
     // PERSISTENT TAIL: columns from tailFrom on belong to one launch of hip_tail_kernel.h -- their
     // panels exist (the solves walk them) but carry no segments, and the block before them hands ALL
     // its pending lookahead units over at once
-    const int64_t tailFrom = tailAllowed ? tailFromOf(n, g.rowsBelow) : -1;
+    // (tailMode 2: a narrow root lump that follows other levels -- the WHOLE lump is the tail)
+    const int64_t tailFrom = tailMode == 2 ? 0 : (tailMode == 1 ? tailFromOf(n, g.rowsBelow) : -1);
     if (tailFrom >= 0) plan.hasTail = true;
     for (int64_t blockStart = 0; blockStart < n; blockStart += kOuterWidth) {
       const int64_t blockEnd = std::min<int64_t>(n, blockStart + kOuterWidth);
@@ -609,7 +611,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         const int32_t first = (int32_t)plan.panels.size();
         const int32_t rowBase = (int32_t)plan.rowChain.size();
         appendLumpRows(l, g);
-        int32_t n = addPanels(l, g, rowBase, /*withBoards=*/false, {}, /*tailAllowed=*/false);
+        int32_t n = addPanels(l, g, rowBase, /*withBoards=*/false, {}, /*tailMode=*/0);
         for (int32_t j = 0; j < n; j++) bucketAt(big, j).push_back({first + j, j});
       }
     }
@@ -653,6 +655,14 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
         alone = alone && occupancy[firstLv[l] + j] == 1;
       }
       tailOk[l] = alone;
+      // narrow root lump with levels before it: its first outer block too, when those panels are alone as
+      // well (the level before the tail exists: it takes the flushDue mark; GRID 82x82: 16 instead of 12 panels)
+      if (alone && opts.tailWholeNarrow && firstLv[l] > 0 &&
+          (g.width + kOuterWidth - 1) / kOuterWidth < opts.tailMinBlocks) {
+        bool all = true;
+        for (int32_t j = 0; j <= lastLv[l] - firstLv[l]; j++) all = all && occupancy[firstLv[l] + j] == 1;
+        if (all) tailOk[l] = 2;
+      }
     }
   }
   for (int64_t l = denseBegin; l < upToLump; l++) {
@@ -701,7 +711,7 @@ HipPlanHost buildHipPlan(const CoalescedBlockMatrixSkel& sk, const vector<int64_
       if (s >= denseBegin && s < l) level = std::max(level, lastLevelOfLump[s] + 1);
     }
     const int32_t first = (int32_t)plan.panels.size();
-    const int32_t n = addPanels(l, g, lumpRowBase, /*withBoards=*/true, boardSegs, tailOk[l] != 0);
+    const int32_t n = addPanels(l, g, lumpRowBase, /*withBoards=*/true, boardSegs, (int)tailOk[l]);
     for (int32_t j = 0; j < n; j++) bucketAt(levelBuckets, level + j).push_back({first + j, level + j});
     lastLevelOfLump[l] = level + n - 1;
   }

@@ -252,6 +252,7 @@ struct HipPlanOptions {
   // of a batch runs a second plan without tails (HipSymbolicCtx::planFor, tag 2).  0: off.
   // profiles/r06_tail_narrow.txt.
   // A tail needs at least six panels, and -- like every tail -- panels that are alone in their levels.
+  bool tailWholeNarrow = true;  // a narrow root lump that follows other levels: the whole lump (developer: BSP_TAIL_WHOLE=0)
   int32_t tailNarrowMin = 2;  // (developer: BSP_TAIL_NARROW_MIN; tailBlocks = 0 switches every tail off)
   int32_t solveSortWindow = 16;  // lumps per sorting window of the backward elimination lists (= a workgroup; developer: BSP_SOLVE_SORT_WINDOW)
   void applyDeveloperEnv();  // BSP_TIMING, chunk sizes of the gather-overlap experiment

@@ -162,6 +162,46 @@ def test_tails_in_a_forest_of_wide_roots(widths):
     assert err < 1e-11, (widths, err, sol.planStats()["num_tail_panels"])
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_whole_narrow_root_lump_behind_its_children(dtype):
+    """a narrow root lump that FOLLOWS other levels (two dense blocks of 500, each coupled to 150 columns of a 900-column separator:
+    the structure of GRID 82x82's top) is the persistent tail as a whole -- first outer block included:
+    15 panels (all but the first block: 11); the level before it is the children's last one"""
+    widths, sep, link = [500, 500], 900, 150
+    n = sum(widths) + sep
+    cols, base = [], 0
+    for k, w in enumerate(widths):
+        lo = n - sep + (0 if k == 0 else sep - link)
+        for i in range(w):
+            cols.append(set(range(base + i, base + w)) | set(range(lo, lo + link)))
+        base += w
+    for i in range(sep):
+        cols.append(set(range(n - sep + i, n)))
+    sol = B.create_solver(B.Settings(), np.ones(n, dtype=np.int64), T.columns_to_structure(cols))
+    assert sol.planStats()["num_tail_panels"] == 15
+    data = spd_data(sol, 77, beta_factor=1.2, dtype=dtype)
+    L, A = dense_lower_chol(sol, data)
+    dev = to_dev(data)
+    before = sol.runCounters()["tail_launches"]
+    sol.factor(dev)
+    assert sol.runCounters()["tail_launches"] == before + 1
+    got = lower_of(sol, dev.cpu().numpy())
+    assert np.linalg.norm(got - L) / np.linalg.norm(L) < (1e-12 if dtype == np.float64 else 2e-5)
+    assert np.abs(got - L).max() / np.abs(L).max() < (1e-11 if dtype == np.float64 else 1e-4)
+    rhs = np.random.default_rng(3).standard_normal(n)
+    v = to_dev(rhs.astype(dtype))
+    sol.solve(dev, v, n, 1)
+    X = np.linalg.solve(A, rhs)
+    assert np.linalg.norm(v.cpu().numpy().astype(np.float64) - X) / np.linalg.norm(X) < (1e-10 if dtype == np.float64 else 1e-3)
+    mats = [to_dev(spd_data(sol, 80 + q, beta_factor=1.2, dtype=dtype)) for q in range(2)]
+    dense = [dense_lower_chol(sol, m.cpu().numpy())[0] for m in mats]
+    sol.factor(mats)  # (a batch: the plan without tails)
+    assert sol.runCounters()["tail_launches"] == before + 1
+    for q in range(2):
+        got = lower_of(sol, mats[q].cpu().numpy())
+        assert np.linalg.norm(got - dense[q]) / np.linalg.norm(dense[q]) < (1e-12 if dtype == np.float64 else 2e-5), q
+
+
 def test_meri_family_with_a_narrow_root():
     """the reference's 40_MERI problem (Bench.cpp:355-360): its 822-column root lump takes the narrow
     tail; vector residual probe against the CPU oracle"""

@@ -33,3 +33,21 @@ def test_narrow_root_lump_rule():
     assert _tail_panels([990]) == 12             # GRID 82x82's root: all but the first outer block
     assert _tail_panels([576]) == 0              # fewer than six panels of tail
     assert _tail_panels([640]) == 6
+
+
+def test_whole_narrow_root_behind_children():
+    """two blocks of 500, each coupled to 150 columns of a 900-column separator: the root follows other levels and is the tail as a
+    whole (15 panels); alone at level 0 it keeps its first outer block (11 panels)"""
+    widths, sep, link = [500, 500], 900, 150
+    n = sum(widths) + sep
+    cols, base = [], 0
+    for k, w in enumerate(widths):
+        lo = n - sep + (0 if k == 0 else sep - link)
+        for i in range(w):
+            cols.append(set(range(base + i, base + w)) | set(range(lo, lo + link)))
+        base += w
+    for i in range(sep):
+        cols.append(set(range(n - sep + i, n)))
+    sol = B.create_solver(B.Settings(hipOptions={"lazy_plan": 1}), np.ones(n, dtype=np.int64), T.columns_to_structure(cols))
+    assert sol.planStats()["num_tail_panels"] == 15
+    assert _tail_panels([904]) == 11
