@@ -202,6 +202,20 @@ def test_c4_grid_batch_full():
         _against_oracle(sol, hosts[q], L, 1e-11 if weak else FACTOR_TOL, 1e-10 if weak else OFFDIAG_TOL)
 
 
+def test_c4_grid_single_matrix_full():
+    """C4's structure as ONE matrix -- the latency-bound schedule of round 6: the 990-column root as a
+    whole in the persistent tail launch, the potrf of the small tree levels folded into their trsm
+    launches -- entry by entry against the oracle, normally and weakly damped, with the solve"""
+    sol = B.create_solver(B.Settings(), np.full(82 * 82, 3, dtype=np.int64), T.gen_grid(82, 82, 1.0, 2, 37))
+    before = sol.runCounters()
+    _check(sol, _data(sol, 37, 1.2), seeds=(5, 6))
+    _check(sol, _weak_data(sol, 38), tol=1e-11, off_tol=1e-10)
+    after = sol.runCounters()
+    assert after["tail_launches"] - before["tail_launches"] == 2
+    assert after["potrf_folded_levels"] - before["potrf_folded_levels"] >= 2 * 15
+    assert sol.planStats()["num_tail_panels"] == 16
+
+
 def test_c5_bal1723_fp32_refined_full():
     """C5: BAL-1723-shaped problem (1723 cams, 156 502 pts, ~0.68 M observations; synthetic
     stand-in), fp32 factor on the device + fp64 iterative refinement to ||r|| / ||b|| < 1e-10"""
